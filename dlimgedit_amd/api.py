@@ -1,0 +1,535 @@
+"""Python host binding over the C-ABI of libdlimgedit.so (ctypes, no torch types anywhere).
+
+Mirrors the reference's header-only C++ wrapper (reference: src/include/dlimgedit/dlimgedit.hpp and
+detail/dlimgedit.impl.hpp): same class and method names, same argument meaning, errors surface as
+`Error(last_error())` exactly where the C++ wrapper throws `dlimg::Exception`.  Only the slots of
+`dlimg_Api` are used for the drop-in surface; the `ext` namespace exposes the extension entry points
+of include/dlimgedit/dlimgedit_amd.h for benchmarks and parity tests.
+
+The library is the product: if it is missing or the GPU is absent, calls fail loudly; there is no
+fallback implementation in Python.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+LIB_PATH = Path(__file__).resolve().parent / "lib" / "libdlimgedit.so"
+
+
+class Error(RuntimeError):
+    """dlimg::Exception."""
+
+
+class Backend(enum.IntEnum):
+    cpu = 0
+    gpu = 1
+
+
+class Channels(enum.IntEnum):
+    mask = 1
+    rgb = 3
+    rgba = 4
+    bgra = 5
+    argb = 6
+
+
+def count(channels: Channels) -> int:
+    return 4 if int(channels) > 4 else int(channels)
+
+
+@dataclass(frozen=True)
+class Extent:
+    width: int = 0
+    height: int = 0
+
+
+@dataclass(frozen=True)
+class Point:
+    x: int = 0
+    y: int = 0
+
+
+@dataclass(frozen=True)
+class Region:
+    top_left: Point = Point()
+    bottom_right: Point = Point()
+
+    @staticmethod
+    def from_origin(origin: Point, extent: Extent) -> "Region":
+        return Region(origin, Point(origin.x + extent.width, origin.y + extent.height))
+
+
+# ---------------------------------------------------------------------------------------------
+# C structs (layouts: include/dlimgedit/dlimgedit.h)
+
+class _ImageView(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("channels", C.c_int), ("stride", C.c_int),
+                ("pixels", C.c_void_p)]
+
+
+class _Options(C.Structure):
+    _fields_ = [("backend", C.c_int), ("model_directory", C.c_char_p)]
+
+
+_u8pp = C.POINTER(C.c_void_p)
+
+_API_FIELDS = [
+    ("is_backend_supported", C.CFUNCTYPE(C.c_int, C.c_int)),
+    ("create_environment", C.CFUNCTYPE(C.c_int, C.POINTER(C.c_void_p), C.POINTER(_Options))),
+    ("destroy_environment", C.CFUNCTYPE(None, C.c_void_p)),
+    ("process_image_for_segmentation", C.CFUNCTYPE(C.c_int, C.POINTER(C.c_void_p), C.POINTER(_ImageView), C.c_void_p)),
+    ("get_segmentation_mask", C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), _u8pp,
+                                          C.POINTER(C.c_float))),
+    ("get_segmentation_extent", C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int))),
+    ("destroy_segmentation", C.CFUNCTYPE(None, C.c_void_p)),
+    ("segment_objects", C.CFUNCTYPE(C.c_int, C.POINTER(_ImageView), C.c_void_p, C.c_void_p)),
+    ("load_image", C.CFUNCTYPE(C.c_int, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), _u8pp)),
+    ("save_image", C.CFUNCTYPE(C.c_int, C.POINTER(_ImageView), C.c_char_p)),
+    ("create_image", C.CFUNCTYPE(C.c_void_p, C.c_int, C.c_int, C.c_int)),
+    ("destroy_image", C.CFUNCTYPE(None, C.c_void_p)),
+    ("last_error", C.CFUNCTYPE(C.c_char_p)),
+    # additions of this build
+    ("process_images_for_segmentation", C.CFUNCTYPE(C.c_int, C.POINTER(C.c_void_p), C.POINTER(_ImageView), C.c_int,
+                                                    C.c_void_p)),
+    ("get_segmentation_masks", C.CFUNCTYPE(C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int),
+                                           C.POINTER(C.c_int), _u8pp)),
+]
+
+REFERENCE_SLOTS = 13     # the reference's table ends after last_error
+
+
+class _Api(C.Structure):
+    _fields_ = _API_FIELDS
+
+
+_lib = None
+_api = None
+
+
+def library() -> C.CDLL:
+    """Loads libdlimgedit.so; raises if it has not been built (`python -m dlimgedit_amd.build`)."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise Error(f"{LIB_PATH} not found: build it with `python -m dlimgedit_amd.build` "
+                        "(the HIP library is the product; there is no Python fallback)")
+        _lib = C.CDLL(str(LIB_PATH))
+        _lib.dlimg_init.restype = C.POINTER(_Api)
+        _lib.dlimg_init.argtypes = []
+    return _lib
+
+
+def api() -> _Api:
+    """dlimg::api(): the function table, initialised on first use (handle.hpp:27-34 in the reference)."""
+    global _api
+    if _api is None:
+        _api = library().dlimg_init().contents
+    return _api
+
+
+def _check(result: int) -> None:
+    if result != 0:
+        msg = api().last_error()
+        raise Error(msg.decode("utf-8", "replace") if msg else "Unknown error")
+
+
+# ---------------------------------------------------------------------------------------------
+# Image / ImageView
+
+class ImageView:
+    """Non-owning view of u8 pixels (numpy array kept alive by the view)."""
+
+    def __init__(self, pixels: np.ndarray, channels: Channels = Channels.rgba, stride: Optional[int] = None):
+        if pixels.dtype != np.uint8:
+            raise TypeError("pixels must be uint8")
+        if pixels.ndim == 2:
+            pixels = pixels[:, :, None]
+        h, w, c = pixels.shape
+        if c != count(channels):
+            raise ValueError(f"array has {c} channels, {channels!r} needs {count(channels)}")
+        if stride is None:
+            pixels = np.ascontiguousarray(pixels)
+            stride = w * c
+        self._array = pixels
+        self.extent = Extent(w, h)
+        self.channels = Channels(channels)
+        self.stride = int(stride)
+
+    def _c(self) -> _ImageView:
+        return _ImageView(self.extent.width, self.extent.height, int(self.channels), self.stride,
+                          self._array.ctypes.data)
+
+
+class Image:
+    """Owning image allocated by the library (create_image / destroy_image)."""
+
+    def __init__(self, extent: Extent, channels: Channels = Channels.rgba):
+        self._extent, self._channels = extent, Channels(channels)
+        self._ptr = api().create_image(extent.width, extent.height, count(channels))
+        if not self._ptr:
+            raise Error("create_image failed")
+
+    def extent(self) -> Extent:
+        return self._extent
+
+    def channels(self) -> Channels:
+        return self._channels
+
+    def size(self) -> int:
+        return self._extent.width * self._extent.height * count(self._channels)
+
+    def pixels(self) -> np.ndarray:
+        buf = (C.c_uint8 * self.size()).from_address(self._ptr)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(self._extent.height, self._extent.width, count(self._channels))
+
+    def view(self) -> ImageView:
+        return ImageView(self.pixels(), self._channels)
+
+    @staticmethod
+    def load(filepath) -> "Image":
+        ext = (C.c_int * 2)()
+        ch = C.c_int()
+        px = C.c_void_p()
+        _check(api().load_image(str(filepath).encode(), ext, C.byref(ch), C.byref(px)))
+        raise Error("load_image returned success unexpectedly")   # pragma: no cover (not part of this build)
+
+    @staticmethod
+    def save(img: ImageView, filepath) -> None:
+        v = img._c()
+        _check(api().save_image(C.byref(v), str(filepath).encode()))
+
+    def __del__(self):
+        ptr, self._ptr = getattr(self, "_ptr", None), None
+        if ptr and _api is not None:
+            _api.destroy_image(ptr)
+
+
+# ---------------------------------------------------------------------------------------------
+# Environment / Segmentation
+
+@dataclass
+class Options:
+    backend: Backend = Backend.cpu
+    model_directory: str = "models"
+
+
+class Environment:
+    """dlimg::Environment: owns the model cache; must outlive every Segmentation made from it."""
+
+    @staticmethod
+    def is_supported(backend: Backend) -> bool:
+        return api().is_backend_supported(int(backend)) != 0
+
+    def __init__(self, options: Options = Options()):
+        self._handle = C.c_void_p()
+        self._dir = str(options.model_directory).encode()
+        opts = _Options(int(options.backend), self._dir)
+        _check(api().create_environment(C.byref(self._handle), C.byref(opts)))
+
+    def handle(self) -> C.c_void_p:
+        return self._handle
+
+    def close(self) -> None:
+        h, self._handle = self._handle, C.c_void_p()
+        if h and _api is not None:
+            _api.destroy_environment(h)
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+@dataclass
+class Mask:
+    image: np.ndarray        # [H, W] uint8, values 0 or 255
+    accuracy: float = 0.0
+
+
+class Segmentation:
+    """dlimg::Segmentation: cached image embedding + mask queries."""
+
+    def __init__(self, handle: C.c_void_p, env: Environment):
+        self._handle, self._env = handle, env   # keeps the environment alive
+
+    @staticmethod
+    def process(img: ImageView, env: Environment) -> "Segmentation":
+        seg = Segmentation(C.c_void_p(), env)
+        v = img._c()
+        # the handle is assigned before encoding: on failure the wrapper still owns and frees it
+        _check(api().process_image_for_segmentation(C.byref(seg._handle), C.byref(v), env.handle()))
+        return seg
+
+    @staticmethod
+    def process_batch(imgs: Sequence[ImageView], env: Environment) -> list:
+        n = len(imgs)
+        handles = (C.c_void_p * n)()
+        views = (_ImageView * n)(*[i._c() for i in imgs])
+        segs = []
+        try:
+            _check(api().process_images_for_segmentation(handles, views, n, env.handle()))
+        finally:
+            segs = [Segmentation(C.c_void_p(h), env) for h in handles if h]
+        return segs
+
+    def extent(self) -> Extent:
+        out = (C.c_int * 2)()
+        api().get_segmentation_extent(self._handle, out)
+        return Extent(out[0], out[1])
+
+    def _query(self, point, region, n_masks):
+        e = self.extent()
+        masks = [np.empty((e.height, e.width), dtype=np.uint8) for _ in range(n_masks)]
+        ptrs = (C.c_void_p * 3)(*([m.ctypes.data for m in masks] + [None] * (3 - n_masks)))
+        acc = (C.c_float * 3)(0.0, 0.0, 0.0)
+        p = (C.c_int * 2)(point.x, point.y) if point is not None else None
+        r = (C.c_int * 4)(region.top_left.x, region.top_left.y, region.bottom_right.x, region.bottom_right.y) \
+            if region is not None else None
+        _check(api().get_segmentation_mask(self._handle, p, r, ptrs, acc))
+        return masks, list(acc)
+
+    def compute_mask(self, prompt) -> np.ndarray:
+        """Point -> best mask; Region -> mask of the largest object in the box."""
+        if isinstance(prompt, Point):
+            return self._query(prompt, None, 1)[0][0]
+        if isinstance(prompt, Region):
+            return self._query(None, prompt, 1)[0][0]
+        raise TypeError("prompt must be a Point or a Region")
+
+    def compute_masks(self, point: Point) -> list:
+        masks, acc = self._query(point, None, 3)
+        return [Mask(m, a) for m, a in zip(masks, acc)]
+
+    @staticmethod
+    def compute_mask_batch(segs: Sequence["Segmentation"], points: Optional[Sequence[Point]] = None,
+                           regions: Optional[Sequence[Region]] = None) -> list:
+        n = len(segs)
+        handles = (C.c_void_p * n)(*[s._handle for s in segs])
+        outs = [np.empty((s.extent().height, s.extent().width), dtype=np.uint8) for s in segs]
+        ptrs = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        p = r = None
+        if points is not None:
+            p = (C.c_int * (2 * n))(*[v for q in points for v in (q.x, q.y)])
+        if regions is not None:
+            r = (C.c_int * (4 * n))(*[v for q in regions for v in (q.top_left.x, q.top_left.y, q.bottom_right.x,
+                                                                  q.bottom_right.y)])
+        _check(api().get_segmentation_masks(handles, n, p, r, ptrs))
+        return outs
+
+    def close(self) -> None:
+        h, self._handle = self._handle, C.c_void_p()
+        if h and _api is not None:
+            _api.destroy_segmentation(h)
+
+    def __del__(self):
+        self.close()
+
+
+def segment_objects(img: ImageView, env: Environment) -> np.ndarray:
+    out = np.empty((img.extent.height, img.extent.width), dtype=np.uint8)
+    v = img._c()
+    _check(api().segment_objects(C.byref(v), out.ctypes.data, env.handle()))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# extension entry points (include/dlimgedit/dlimgedit_amd.h)
+
+STAGES = ("pre", "gemm", "layernorm", "attention_window", "attention_global", "encoder_other", "decoder", "post")
+
+
+class ext:
+    _sigs_done = False
+
+    @classmethod
+    def _l(cls):
+        lib = library()
+        if not cls._sigs_done:
+            vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+            sig = {
+                "dlimg_amd_device_count": ([], ci),
+                "dlimg_amd_model_geometry": ([vp, C.POINTER(ci)], ci),
+                "dlimg_amd_get_embedding": ([vp, vp], ci),
+                "dlimg_amd_get_logits": ([vp, C.POINTER(ci), C.POINTER(ci), vp, vp], ci),
+                "dlimg_amd_device_alloc": ([vp, C.c_size_t, C.POINTER(vp)], ci),
+                "dlimg_amd_device_free": ([vp, vp], ci),
+                "dlimg_amd_copy_to_device": ([vp, vp, vp, C.c_size_t], ci),
+                "dlimg_amd_copy_to_host": ([vp, vp, vp, C.c_size_t], ci),
+                "dlimg_amd_encode_and_mask": ([vp, C.POINTER(_ImageView), ci, C.POINTER(ci), C.POINTER(vp)], ci),
+                "dlimg_amd_encode_only": ([vp, C.POINTER(_ImageView), ci], ci),
+                "dlimg_amd_synchronize": ([vp], ci),
+                "dlimg_amd_set_profiling": ([vp, ci], ci),
+                "dlimg_amd_take_stage_stats": ([vp, vp, vp, vp], ci),
+                "dlimg_amd_test_preprocess": ([vp, ci, ci, ci, ci, vp], ci),
+                "dlimg_amd_test_postprocess": ([vp, ci, vp, ci, ci, vp], ci),
+                "dlimg_amd_test_gemm": ([ci, ci, ci, vp, vp, vp, vp, ci, ci, vp, vp], ci),
+                "dlimg_amd_test_layernorm": ([vp, vp, vp, cf, ci, ci, ci, vp, vp], ci),
+                "dlimg_amd_test_attention": ([ci, vp, vp, vp, vp, ci, ci, ci, vp], ci),
+                "dlimg_amd_bench_gemm": ([ci, ci, ci, ci, ci, C.POINTER(C.c_double)], ci),
+            }
+            for name, (args, res) in sig.items():
+                fn = getattr(lib, name)
+                fn.argtypes, fn.restype = args, res
+            cls._sigs_done = True
+        return lib
+
+    EXPORTS = ("dlimg_amd_device_count", "dlimg_amd_model_geometry", "dlimg_amd_get_embedding", "dlimg_amd_get_logits",
+               "dlimg_amd_device_alloc", "dlimg_amd_device_free", "dlimg_amd_copy_to_device", "dlimg_amd_copy_to_host",
+               "dlimg_amd_encode_and_mask", "dlimg_amd_encode_only", "dlimg_amd_synchronize", "dlimg_amd_set_profiling",
+               "dlimg_amd_take_stage_stats", "dlimg_amd_test_preprocess", "dlimg_amd_test_postprocess",
+               "dlimg_amd_test_gemm", "dlimg_amd_test_layernorm", "dlimg_amd_test_attention", "dlimg_amd_bench_gemm")
+
+    @staticmethod
+    def _ptr(a: Optional[np.ndarray]):
+        return None if a is None else a.ctypes.data
+
+    @classmethod
+    def device_count(cls) -> int:
+        return cls._l().dlimg_amd_device_count()
+
+    @classmethod
+    def model_geometry(cls, env: Environment) -> Tuple[int, int, int, int]:
+        out = (C.c_int * 4)()
+        _check(cls._l().dlimg_amd_model_geometry(env.handle(), out))
+        return tuple(out)
+
+    @classmethod
+    def get_embedding(cls, seg: Segmentation) -> np.ndarray:
+        out = np.empty((4096, 256), dtype=np.float32)
+        _check(cls._l().dlimg_amd_get_embedding(seg._handle, out.ctypes.data))
+        return out
+
+    @classmethod
+    def get_logits(cls, seg: Segmentation, point: Optional[Point] = None, region: Optional[Region] = None):
+        logits = np.empty((4, 256, 256), dtype=np.float32)
+        iou = np.empty(4, dtype=np.float32)
+        p = (C.c_int * 2)(point.x, point.y) if point is not None else None
+        r = (C.c_int * 4)(region.top_left.x, region.top_left.y, region.bottom_right.x, region.bottom_right.y) \
+            if region is not None else None
+        _check(cls._l().dlimg_amd_get_logits(seg._handle, p, r, logits.ctypes.data, iou.ctypes.data))
+        return logits, iou
+
+    # -- benchmark path
+    @classmethod
+    def device_alloc(cls, env, nbytes: int) -> int:
+        out = C.c_void_p()
+        _check(cls._l().dlimg_amd_device_alloc(env.handle(), nbytes, C.byref(out)))
+        return out.value
+
+    @classmethod
+    def device_free(cls, env, ptr: int) -> None:
+        _check(cls._l().dlimg_amd_device_free(env.handle(), ptr))
+
+    @classmethod
+    def copy_to_device(cls, env, dst: int, src: np.ndarray) -> None:
+        src = np.ascontiguousarray(src)
+        _check(cls._l().dlimg_amd_copy_to_device(env.handle(), dst, src.ctypes.data, src.nbytes))
+
+    @classmethod
+    def copy_to_host(cls, env, dst: np.ndarray, src: int) -> None:
+        _check(cls._l().dlimg_amd_copy_to_host(env.handle(), dst.ctypes.data, src, dst.nbytes))
+
+    @staticmethod
+    def device_views(ptrs, width, height, channels=Channels.rgba):
+        n = len(ptrs)
+        return (_ImageView * n)(*[_ImageView(width, height, int(channels), width * count(channels), p) for p in ptrs])
+
+    @classmethod
+    def encode_and_mask(cls, env, views, points, mask_ptrs) -> None:
+        n = len(views)
+        p = (C.c_int * (2 * n))(*[v for q in points for v in (q.x, q.y)])
+        m = (C.c_void_p * n)(*mask_ptrs)
+        _check(cls._l().dlimg_amd_encode_and_mask(env.handle(), views, n, p, m))
+
+    @classmethod
+    def encode_only(cls, env, views) -> None:
+        _check(cls._l().dlimg_amd_encode_only(env.handle(), views, len(views)))
+
+    @classmethod
+    def synchronize(cls, env) -> None:
+        _check(cls._l().dlimg_amd_synchronize(env.handle()))
+
+    @classmethod
+    def set_profiling(cls, env, on: bool) -> None:
+        _check(cls._l().dlimg_amd_set_profiling(env.handle(), int(on)))
+
+    @classmethod
+    def take_stage_stats(cls, env) -> dict:
+        n = len(STAGES)
+        ms, work, launches = (C.c_double * n)(), (C.c_double * n)(), (C.c_long * n)()
+        _check(cls._l().dlimg_amd_take_stage_stats(env.handle(), ms, work, launches))
+        return {s: {"ms": ms[i], "work": work[i], "launches": launches[i]} for i, s in enumerate(STAGES)}
+
+    # -- single-kernel hooks
+    @classmethod
+    def test_preprocess(cls, pixels: np.ndarray, channels: Channels, stride: Optional[int] = None) -> np.ndarray:
+        h, w = pixels.shape[:2]
+        if stride is None:
+            pixels = np.ascontiguousarray(pixels)
+            stride = w * count(channels)
+        out = np.empty((4096, 768), dtype=np.float16)
+        _check(cls._l().dlimg_amd_test_preprocess(pixels.ctypes.data, w, h, stride, int(channels), out.ctypes.data))
+        return out
+
+    @classmethod
+    def test_postprocess(cls, planes: np.ndarray, out_w: int, out_h: int, iou: Optional[np.ndarray] = None) -> np.ndarray:
+        planes = np.ascontiguousarray(planes, dtype=np.float32).reshape(-1, 256, 256)
+        out = np.empty((out_h, out_w), dtype=np.uint8)
+        iou = None if iou is None else np.ascontiguousarray(iou, dtype=np.float32)
+        _check(cls._l().dlimg_amd_test_postprocess(planes.ctypes.data, planes.shape[0], cls._ptr(iou), out_w, out_h,
+                                                   out.ctypes.data))
+        return out
+
+    @classmethod
+    def test_gemm(cls, A: np.ndarray, W: np.ndarray, bias=None, resid=None, act: int = 0, want_f16: bool = False):
+        A = np.ascontiguousarray(A, dtype=np.float16)
+        W = np.ascontiguousarray(W, dtype=np.float16)
+        M, K = A.shape
+        N = W.shape[0]
+        bias = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
+        resid = None if resid is None else np.ascontiguousarray(resid, dtype=np.float32)
+        out32 = np.empty((M, N), dtype=np.float32)
+        out16 = np.empty((M, N), dtype=np.float16) if want_f16 else None
+        _check(cls._l().dlimg_amd_test_gemm(M, N, K, A.ctypes.data, W.ctypes.data, cls._ptr(bias), cls._ptr(resid),
+                                            0 if resid is None else resid.shape[0], act, out32.ctypes.data,
+                                            cls._ptr(out16)))
+        return (out32, out16) if want_f16 else out32
+
+    @classmethod
+    def test_layernorm(cls, x, w, b, eps: float, act: int = 0):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        w = np.ascontiguousarray(w, dtype=np.float32)
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        rows, dim = x.shape
+        o32 = np.empty_like(x)
+        o16 = np.empty(x.shape, dtype=np.float16)
+        _check(cls._l().dlimg_amd_test_layernorm(x.ctypes.data, w.ctypes.data, b.ctypes.data, eps, rows, dim, act,
+                                                 o32.ctypes.data, o16.ctypes.data))
+        return o32, o16
+
+    @classmethod
+    def test_attention(cls, is_global: bool, qkv, qkv_bias, rel_h, rel_w, batch: int, heads: int, hd: int):
+        qkv = np.ascontiguousarray(qkv, dtype=np.float16)
+        rel_h = np.ascontiguousarray(rel_h, dtype=np.float32)
+        rel_w = np.ascontiguousarray(rel_w, dtype=np.float32)
+        qkv_bias = None if qkv_bias is None else np.ascontiguousarray(qkv_bias, dtype=np.float32)
+        out = np.empty((batch * 4096, heads * hd), dtype=np.float16)
+        _check(cls._l().dlimg_amd_test_attention(int(is_global), qkv.ctypes.data, cls._ptr(qkv_bias), rel_h.ctypes.data,
+                                                 rel_w.ctypes.data, batch, heads, hd, out.ctypes.data))
+        return out
+
+    @classmethod
+    def bench_gemm(cls, M: int, N: int, K: int, act: int = 0, iters: int = 20) -> float:
+        ms = C.c_double()
+        _check(cls._l().dlimg_amd_bench_gemm(M, N, K, act, iters, C.byref(ms)))
+        return ms.value

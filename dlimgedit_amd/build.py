@@ -1,0 +1,90 @@
+"""Builds libdlimgedit.so (HIP kernels + C++ host runtime + C-ABI) for gfx950 with hipcc.
+
+In-tree, no cmake: `python -m dlimgedit_amd.build`.  hipcc cross-compiles without a GPU, so this also
+runs in the CPU-only build container.  Objects are cached by source mtime under csrc/_obj/.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+ROOT = PKG.parent
+CSRC = PKG / "csrc"
+OBJ = CSRC / "_obj"
+LIB = PKG / "lib" / "libdlimgedit.so"
+ARCH = "gfx950"
+
+SOURCES = [
+    "kernels/gemm.hip",
+    "kernels/elementwise.hip",
+    "kernels/attention_window.hip",
+    "kernels/attention_global.hip",
+    "kernels/decoder.hip",
+    "kernels/postprocess.hip",
+    "weights.cpp",
+    "sam_model.cpp",
+    "environment.cpp",
+    "segmentation.cpp",
+    "dlimgedit.cpp",
+    "ext_api.cpp",
+]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(exe).exists():
+        raise RuntimeError("hipcc not found; the MI355X build of dlimgedit needs the ROCm toolchain")
+    return exe
+
+
+def _flags() -> list:
+    return [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DDLIMGEDIT_EXPORTS",
+            "-Wall", "-Wno-unused-function", "-Wno-unused-result", f"-I{ROOT / 'include'}", f"-I{CSRC}"]
+
+
+def _deps_mtime() -> float:
+    hdrs = list(CSRC.rglob("*.hpp")) + list((ROOT / "include").rglob("*.h"))
+    return max(p.stat().st_mtime for p in hdrs)
+
+
+def _compile(src: str, force: bool, hdr_mtime: float) -> Path:
+    s = CSRC / src
+    if not s.exists():
+        raise FileNotFoundError(s)
+    o = OBJ / (src.replace("/", "_") + ".o")
+    if not force and o.exists() and o.stat().st_mtime > max(s.stat().st_mtime, hdr_mtime):
+        return o
+    cmd = [hipcc(), *_flags(), "-x", "hip", "-c", str(s), "-o", str(o)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return o
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    OBJ.mkdir(parents=True, exist_ok=True)
+    LIB.parent.mkdir(parents=True, exist_ok=True)
+    hdr = _deps_mtime()
+    workers = min(6, os.cpu_count() or 1)
+    with ThreadPoolExecutor(workers) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force, hdr), SOURCES))
+    if force or not LIB.exists() or LIB.stat().st_mtime < max(o.stat().st_mtime for o in objs):
+        cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs),
+               "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"built {LIB} ({LIB.stat().st_size / 1e6:.1f} MB)")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,352 @@
+// Extension entry points declared in include/dlimgedit/dlimgedit_amd.h: benchmark path with
+// device-resident data, stage clocks, and single-kernel hooks for the parity tests.
+#include "environment.hpp"
+#include "segmentation.hpp"
+
+#include <dlimgedit/dlimgedit_amd.h>
+
+#include <cstring>
+#include <vector>
+
+namespace dlimg {
+
+dlimg_Result report_error(char const* what) noexcept;   // dlimgedit.cpp
+
+namespace {
+
+template <typename F> int guarded(F&& body) noexcept {
+    try {
+        body();
+        return 0;
+    } catch (std::exception const& e) {
+        report_error(e.what());
+        return 1;
+    } catch (...) {
+        report_error("Unknown error");
+        return 1;
+    }
+}
+
+EnvironmentImpl& impl(dlimg_Environment h) {
+    DLIMG_ASSERT(h != nullptr);
+    return *reinterpret_cast<EnvironmentImpl*>(h);
+}
+SegmentationImpl& impl(dlimg_Segmentation h) {
+    DLIMG_ASSERT(h != nullptr);
+    return *reinterpret_cast<SegmentationImpl*>(h);
+}
+
+template <typename T> struct Upload {
+    DeviceBuffer<T> buf;
+    Upload(T const* host, size_t n) {
+        if (host && n) {
+            buf.reserve(n);
+            HIP_CHECK(hipMemcpy(buf.get(), host, n * sizeof(T), hipMemcpyHostToDevice));
+        }
+    }
+    T* get() const { return buf.get(); }
+};
+
+template <typename T> void download(T* host, T const* dev, size_t n) {
+    if (host && n) HIP_CHECK(hipMemcpy(host, dev, n * sizeof(T), hipMemcpyDeviceToHost));
+}
+
+void require_gpu() {
+    if (!EnvironmentImpl::is_supported(dlimg_gpu)) throw Exception("No supported GPU (gfx950) found");
+}
+
+// Shared by encode_and_mask / encode_only: images already on the device.
+void encode_device_images(SamModel& model, dlimg_ImageView const* imgs, int count) {
+    for (int i = 0; i < count; ++i) {
+        check_image(imgs[i]);
+        if (std::max(imgs[i].width, imgs[i].height) != kImageSize)
+            throw Exception("device-resident images must have their longest side at 1024 pixels");
+        model.preprocess_device_image(i, count, imgs[i].pixels, imgs[i].width, imgs[i].height, imgs[i].stride,
+                                      imgs[i].channels);
+    }
+    model.encode(count);
+}
+
+}  // namespace
+}  // namespace dlimg
+
+using namespace dlimg;
+
+extern "C" {
+
+DLIMG_API int dlimg_amd_device_count(void) { return EnvironmentImpl::device_count(); }
+
+DLIMG_API int dlimg_amd_model_geometry(dlimg_Environment env, int* out) {
+    return guarded([&] {
+        SamGeometry const& g = impl(env).sam_model().geometry();
+        out[0] = g.embed_dim;
+        out[1] = g.depth;
+        out[2] = g.num_heads;
+        out[3] = g.mlp_dim;
+    });
+}
+
+DLIMG_API int dlimg_amd_get_embedding(dlimg_Segmentation seg, float* out) {
+    return guarded([&] {
+        SegmentationImpl& s = impl(seg);
+        DLIMG_ASSERT(s.embedding() != nullptr && out != nullptr);
+        std::lock_guard<std::mutex> lock(s.model().mutex());
+        HIP_CHECK(hipSetDevice(s.model().device()));
+        s.model().synchronize();
+        download(out, s.embedding(), (size_t)kTokens * kEmbedDim);
+    });
+}
+
+DLIMG_API int dlimg_amd_get_logits(dlimg_Segmentation seg, int const* point, int const* region, float* out_logits,
+                                   float* out_iou) {
+    return guarded([&] {
+        SegmentationImpl& s = impl(seg);
+        DLIMG_ASSERT(s.embedding() != nullptr);
+        Point p;
+        Region r;
+        if (point) p = Point{point[0], point[1]};
+        if (region) r = Region{Point{region[0], region[1]}, Point{region[2], region[3]}};
+        float coords[4], labels[2];
+        pack_prompt(s.geometry(), point ? &p : nullptr, !point && region ? &r : nullptr, coords, labels);
+        SamModel& m = s.model();
+        std::lock_guard<std::mutex> lock(m.mutex());
+        HIP_CHECK(hipSetDevice(m.device()));
+        float const* emb = s.embedding();
+        m.decode(&emb, coords, labels, 1);
+        m.synchronize();
+        download(out_logits, m.logits(), (size_t)4 * kLowRes * kLowRes);
+        download(out_iou, m.iou(), 4);
+    });
+}
+
+DLIMG_API int dlimg_amd_device_alloc(dlimg_Environment env, size_t bytes, void** out_ptr) {
+    return guarded([&] {
+        HIP_CHECK(hipSetDevice(impl(env).device));
+        HIP_CHECK(hipMalloc(out_ptr, bytes));
+    });
+}
+
+DLIMG_API int dlimg_amd_device_free(dlimg_Environment env, void* ptr) {
+    return guarded([&] {
+        HIP_CHECK(hipSetDevice(impl(env).device));
+        HIP_CHECK(hipFree(ptr));
+    });
+}
+
+DLIMG_API int dlimg_amd_copy_to_device(dlimg_Environment env, void* dst, void const* src, size_t bytes) {
+    return guarded([&] {
+        HIP_CHECK(hipSetDevice(impl(env).device));
+        HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    });
+}
+
+DLIMG_API int dlimg_amd_copy_to_host(dlimg_Environment env, void* dst, void const* src, size_t bytes) {
+    return guarded([&] {
+        HIP_CHECK(hipSetDevice(impl(env).device));
+        HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    });
+}
+
+DLIMG_API int dlimg_amd_encode_only(dlimg_Environment env, dlimg_ImageView const* dev_images, int count) {
+    return guarded([&] {
+        DLIMG_ASSERT(dev_images != nullptr && count > 0);
+        SamModel& m = impl(env).sam_model();
+        std::lock_guard<std::mutex> lock(m.mutex());
+        HIP_CHECK(hipSetDevice(m.device()));
+        encode_device_images(m, dev_images, count);
+    });
+}
+
+DLIMG_API int dlimg_amd_encode_and_mask(dlimg_Environment env, dlimg_ImageView const* dev_images, int count,
+                                        int const* points, uint8_t* const* dev_masks) {
+    return guarded([&] {
+        DLIMG_ASSERT(dev_images != nullptr && points != nullptr && dev_masks != nullptr && count > 0);
+        SamModel& m = impl(env).sam_model();
+        std::lock_guard<std::mutex> lock(m.mutex());
+        HIP_CHECK(hipSetDevice(m.device()));
+        encode_device_images(m, dev_images, count);
+        std::vector<float> coords((size_t)count * 4), labels((size_t)count * 2);
+        std::vector<float const*> emb(count);
+        std::vector<ResizeLongestSide> rs(count);
+        for (int i = 0; i < count; ++i) {
+            rs[i].set(Extent{dev_images[i].width, dev_images[i].height});
+            Point p{points[i * 2], points[i * 2 + 1]};
+            pack_prompt(rs[i], &p, nullptr, &coords[i * 4], &labels[i * 2]);
+            emb[i] = m.embeddings() + (size_t)i * kTokens * kEmbedDim;
+        }
+        m.decode(emb.data(), coords.data(), labels.data(), count);
+        std::vector<k::PostJob> jobs(count);
+        for (int i = 0; i < count; ++i) {
+            DLIMG_ASSERT(dev_masks[i] != nullptr);
+            jobs[i] = k::PostJob{m.logits() + (size_t)i * 4 * kLowRes * kLowRes, m.iou() + (size_t)i * 4, dev_masks[i],
+                                 rs[i].original.width, rs[i].original.height, rs[i].resized.width, rs[i].resized.height};
+        }
+        m.masks_on_device(jobs.data(), count);
+    });
+}
+
+DLIMG_API int dlimg_amd_synchronize(dlimg_Environment env) {
+    return guarded([&] {
+        SamModel& m = impl(env).sam_model();
+        std::lock_guard<std::mutex> lock(m.mutex());
+        HIP_CHECK(hipSetDevice(m.device()));
+        m.synchronize();
+    });
+}
+
+DLIMG_API int dlimg_amd_set_profiling(dlimg_Environment env, int enabled) {
+    return guarded([&] {
+        SamModel& m = impl(env).sam_model();
+        std::lock_guard<std::mutex> lock(m.mutex());
+        HIP_CHECK(hipSetDevice(m.device()));
+        m.set_profiling(enabled != 0);
+    });
+}
+
+DLIMG_API int dlimg_amd_take_stage_stats(dlimg_Environment env, double* out_ms, double* out_work, long* out_launches) {
+    static_assert(ST_COUNT == DLIMG_AMD_STAGE_COUNT, "stage table out of sync with the public header");
+    return guarded([&] {
+        SamModel& m = impl(env).sam_model();
+        std::lock_guard<std::mutex> lock(m.mutex());
+        HIP_CHECK(hipSetDevice(m.device()));
+        StageStats s = m.take_stats();
+        for (int i = 0; i < ST_COUNT; ++i) {
+            if (out_ms) out_ms[i] = s.ms[i];
+            if (out_work) out_work[i] = s.work[i];
+            if (out_launches) out_launches[i] = s.launches[i];
+        }
+    });
+}
+
+// ---- single-kernel hooks ----------------------------------------------------------------------
+
+DLIMG_API int dlimg_amd_test_preprocess(uint8_t const* pixels, int width, int height, int stride, int channels,
+                                        uint16_t* out_patches) {
+    return guarded([&] {
+        require_gpu();
+        DLIMG_ASSERT(pixels != nullptr && out_patches != nullptr && height > 0 && stride > 0);
+        Upload<uint8_t> img(pixels, (size_t)stride * height);
+        DeviceBuffer<half_t> out((size_t)kTokens * kPatchK);
+        k::preprocess(img.get(), width, height, stride, channels, out.get(), nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+        download(reinterpret_cast<half_t*>(out_patches), out.get(), (size_t)kTokens * kPatchK);
+    });
+}
+
+DLIMG_API int dlimg_amd_test_postprocess(float const* planes, int n_planes, float const* iou, int out_w, int out_h,
+                                         uint8_t* out_mask) {
+    return guarded([&] {
+        require_gpu();
+        DLIMG_ASSERT(planes != nullptr && out_mask != nullptr && n_planes >= 1 && (!iou || n_planes == 4));
+        DLIMG_ASSERT(out_w > 0 && out_h > 0);
+        Upload<float> src(planes, (size_t)n_planes * kLowRes * kLowRes);
+        Upload<float> sel(iou, 4);
+        DeviceBuffer<uint8_t> dst((size_t)out_w * out_h);
+        ResizeLongestSide rs;
+        rs.set(Extent{out_w, out_h});
+        k::PostJob job{src.get(), iou ? sel.get() : nullptr, dst.get(), out_w, out_h, rs.resized.width, rs.resized.height};
+        k::postprocess_masks(&job, 1, nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+        download(out_mask, dst.get(), (size_t)out_w * out_h);
+    });
+}
+
+DLIMG_API int dlimg_amd_test_gemm(int M, int N, int K, uint16_t const* A, uint16_t const* W, float const* bias,
+                                  float const* resid, int resid_rows, int act, float* out_f32, uint16_t* out_f16) {
+    return guarded([&] {
+        require_gpu();
+        DLIMG_ASSERT(M > 0 && N > 0 && K > 0 && A != nullptr && W != nullptr);
+        Upload<half_t> a(reinterpret_cast<half_t const*>(A), (size_t)M * K);
+        Upload<half_t> w(reinterpret_cast<half_t const*>(W), (size_t)N * K);
+        Upload<float> b(bias, N);
+        Upload<float> r(resid, resid ? (size_t)resid_rows * N : 0);
+        DeviceBuffer<float> o32(out_f32 ? (size_t)M * N : 0);
+        DeviceBuffer<half_t> o16(out_f16 ? (size_t)M * N : 0);
+        k::GemmArgs g;
+        g.A = a.get(); g.lda = K; g.W = w.get(); g.ldw = K; g.bias = bias ? b.get() : nullptr;
+        g.resid = resid ? r.get() : nullptr; g.ldr = N; g.resid_mod = resid ? resid_rows : 1;
+        g.out_f32 = out_f32 ? o32.get() : nullptr; g.ldc32 = N;
+        g.out_h = out_f16 ? o16.get() : nullptr; g.ldc16 = N;
+        g.M = M; g.N = N; g.K = K; g.act = act;
+        k::gemm(g, nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+        download(out_f32, o32.get(), out_f32 ? (size_t)M * N : 0);
+        download(reinterpret_cast<half_t*>(out_f16), o16.get(), out_f16 ? (size_t)M * N : 0);
+    });
+}
+
+DLIMG_API int dlimg_amd_test_layernorm(float const* x, float const* w, float const* b, float eps, int rows, int dim,
+                                       int act, float* out_f32, uint16_t* out_f16) {
+    return guarded([&] {
+        require_gpu();
+        DLIMG_ASSERT(rows > 0 && dim > 0 && x && w && b);
+        const size_t n = (size_t)rows * dim;
+        Upload<float> dx(x, n), dw(w, dim), db(b, dim);
+        DeviceBuffer<float> o32(out_f32 ? n : 0);
+        DeviceBuffer<half_t> o16(out_f16 ? n : 0);
+        k::layernorm(dx.get(), dw.get(), db.get(), eps, rows, dim, act, out_f32 ? o32.get() : nullptr,
+                     out_f16 ? o16.get() : nullptr, nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+        download(out_f32, o32.get(), out_f32 ? n : 0);
+        download(reinterpret_cast<half_t*>(out_f16), o16.get(), out_f16 ? n : 0);
+    });
+}
+
+DLIMG_API int dlimg_amd_test_attention(int global, uint16_t const* qkv, float const* qkv_bias, float const* rel_h,
+                                       float const* rel_w, int batch, int heads, int hd, uint16_t* out) {
+    return guarded([&] {
+        require_gpu();
+        DLIMG_ASSERT(batch > 0 && heads > 0 && qkv && rel_h && rel_w && out);
+        const int D = heads * hd;
+        const int span = global ? 64 : 14;
+        const size_t rows = (size_t)batch * kTokens;
+        Upload<half_t> dq(reinterpret_cast<half_t const*>(qkv), rows * 3 * D);
+        Upload<float> db(qkv_bias, qkv_bias ? (size_t)3 * D : 0);
+        Upload<float> dh(rel_h, (size_t)(2 * span - 1) * hd), dw(rel_w, (size_t)(2 * span - 1) * hd);
+        DeviceBuffer<half_t> o(rows * D);
+        HIP_CHECK(hipMemset(o.get(), 0, rows * D * sizeof(half_t)));
+        if (global) {
+            k::attention_global(dq.get(), dh.get(), dw.get(), o.get(), batch, heads, hd, nullptr);
+        } else {
+            DLIMG_ASSERT(qkv_bias != nullptr);
+            k::attention_window(dq.get(), db.get(), dh.get(), dw.get(), o.get(), batch, heads, hd, nullptr);
+        }
+        HIP_CHECK(hipDeviceSynchronize());
+        download(reinterpret_cast<half_t*>(out), o.get(), rows * D);
+    });
+}
+
+DLIMG_API int dlimg_amd_bench_gemm(int M, int N, int K, int act, int iters, double* out_ms) {
+    return guarded([&] {
+        require_gpu();
+        DLIMG_ASSERT(M > 0 && N > 0 && K > 0 && iters > 0 && out_ms);
+        std::vector<half_t> ha((size_t)M * K), hw((size_t)N * K);
+        uint32_t seed = 12345u;
+        auto rnd = [&] { seed = seed * 1664525u + 1013904223u; return ((seed >> 8) & 0xffff) / 32768.0f - 1.0f; };
+        for (auto& v : ha) v = (half_t)rnd();
+        for (auto& v : hw) v = (half_t)(rnd() * 0.05f);
+        Upload<half_t> a(ha.data(), ha.size()), w(hw.data(), hw.size());
+        DeviceBuffer<half_t> o((size_t)M * N);
+        k::GemmArgs g;
+        g.A = a.get(); g.lda = K; g.W = w.get(); g.ldw = K; g.out_h = o.get(); g.ldc16 = N;
+        g.M = M; g.N = N; g.K = K; g.act = act;
+        hipStream_t s;
+        HIP_CHECK(hipStreamCreate(&s));
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        for (int i = 0; i < 3; ++i) k::gemm(g, s);
+        HIP_CHECK(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; ++i) k::gemm(g, s);
+        HIP_CHECK(hipEventRecord(e1, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        *out_ms = ms / iters;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        (void)hipStreamDestroy(s);
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,283 @@
+// Global self-attention of the SAM ViT encoder (4 of the blocks attend over all 64x64 tokens),
+// flash-style: the 4096x4096 score matrix is never materialised.  In the reference this is part of
+// the encoder ONNX graph run by Session::run (/root/reference/src/segmentation.cpp:126-128).
+//
+//   S[i,j] = scale * q_i.k_j + q_i.Rh[qy_i - ky_j + 63] + q_i.Rw[qx_i - kx_j + 63]   (raw q in the bias)
+//
+// One workgroup = 128 consecutive queries (two rows of the token grid) of one (image, head);
+// 4 waves x 32 queries.  Keys are streamed in tiles of 64 = one grid row, so inside a tile ky is
+// constant and kx = 0..63: the bias is a per-query scalar (from LDS) plus a per-query 64-vector that
+// lives in registers in accumulator layout and is used as the MFMA's initial accumulator.
+// Operands are swapped (S^T = K . Q^T) so a lane owns one query: online-softmax statistics, the
+// rescale of O^T and the bias are all lane-local; P tiles feed the second MFMA straight from the
+// accumulator registers (O^T = V^T . P^T).
+// K/V tiles are register-staged one tile ahead (loads issued before the MFMAs of the current tile,
+// LDS writes after them), two LDS buffers, one barrier per tile.
+#include "device_common.hpp"
+#include "kernels.hpp"
+
+namespace dlimg {
+namespace {
+
+constexpr int GRID = 64;
+constexpr int TOKENS = 4096;
+constexpr int KT = 64;              // keys per tile
+constexpr int VT_STRIDE = 68;       // elements per row of the transposed V tile (136 B: conflict-free ds_read_b64)
+constexpr int RELH_STRIDE = 32;     // floats: relh_lds[wave][ky][query]
+constexpr int GW_STRIDE = 97;       // floats per query row of the prologue scratch (96 rel rows + 1)
+
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attention_global_kernel(const half_t* __restrict__ qkv,
+                                                                  const float* __restrict__ rel_h,
+                                                                  const float* __restrict__ rel_w,
+                                                                  half_t* __restrict__ out, int heads) {
+    constexpr int KS = HD / 16;
+    constexpr int DT = (HD + 31) / 32;
+    constexpr int K_STRIDE = HD + 8;
+    constexpr int CHUNKS = HD / 8;
+    constexpr int STAGE_ITERS = (KT * CHUNKS + 255) / 256;
+    constexpr int K_TILE = KT * K_STRIDE;               // elements
+    constexpr int VT_TILE = DT * 32 * VT_STRIDE;        // elements
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* relh_lds = reinterpret_cast<float*>(smem);                          // [4][64][32]
+    half_t* lds_k = reinterpret_cast<half_t*>(smem + 4 * 64 * RELH_STRIDE * 4);   // [2][K_TILE]
+    half_t* lds_vt = lds_k + 2 * K_TILE;                                        // [2][VT_TILE]
+    float* scratch = reinterpret_cast<float*>(lds_k);   // prologue only: [4][32][GW_STRIDE], aliases the tile buffers
+
+    const int D = heads * HD;
+    const int ld = 3 * D;
+    const int qblk = blockIdx.x % (TOKENS / 128);
+    const int head = (blockIdx.x / (TOKENS / 128)) % heads;
+    const int img = blockIdx.x / ((TOKENS / 128) * heads);
+    const half_t* base = qkv + (size_t)img * TOKENS * ld + head * HD;
+    const int tid = threadIdx.x;
+    const int lane = lane_id();
+    const int wave = wave_id();
+    const int hi = lane >> 5, l31 = lane & 31;
+
+    const int qtok = qblk * 128 + wave * 32 + l31;
+    const int qy = qblk * 2 + (wave >> 1);              // wave-uniform
+    const int qx0 = (wave & 1) * 32;
+
+    half8_t qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+        qf[ks] = *reinterpret_cast<const half8_t*>(base + (size_t)qtok * ld + ks * 16 + hi * 8);
+
+    const float inv_scale = sqrtf((float)HD);
+    const float c = rsqrtf((float)HD) * 1.44269504088896341f;
+
+    // ---- prologue: rel-pos tables via MFMA -------------------------------------------------------
+    // relh[i][ky] = q_i . rel_h[qy - ky + 63]: rows rr = 0..63 <-> rel_h[qy + rr], ky = 63 - rr
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        float16_t acc = zero16();
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const float* r = rel_h + (size_t)(qy + t * 32 + l31) * HD + ks * 16 + hi * 8;
+            half8_t rf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rf[e] = (half_t)r[e];
+            acc = mfma32(rf, qf[ks], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ky = 63 - (t * 32 + acc_row(r, hi));
+            relh_lds[(wave * 64 + ky) * RELH_STRIDE + l31] = acc[r] * inv_scale;
+        }
+    }
+    // relw[i][kx] = q_i . rel_w[qx_i - kx + 63], rows rr = 0..95 <-> rel_w[qx0 + rr] (rows past 126 are zero)
+    float* gw = scratch + wave * 32 * GW_STRIDE;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        float16_t acc = zero16();
+        const int row = qx0 + t * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            half8_t rf = zero_h8();
+            if (row < 2 * GRID - 1) {
+                const float* r = rel_w + (size_t)row * HD + ks * 16 + hi * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rf[e] = (half_t)r[e];
+            }
+            acc = mfma32(rf, qf[ks], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gw[l31 * GW_STRIDE + t * 32 + acc_row(r, hi)] = acc[r];
+    }
+    __syncthreads();
+    float16_t relw[2];          // accumulator layout: tile jt, register r <-> kx = jt*32 + acc_row(r, hi)
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kx = jt * 32 + acc_row(r, hi);
+            relw[jt][r] = gw[l31 * GW_STRIDE + l31 - kx + 63] * inv_scale;
+        }
+    __syncthreads();            // scratch is dead; tile buffers may be written
+
+    // ---- K/V tile staging ------------------------------------------------------------------------
+    half8_t kreg[STAGE_ITERS], vreg[STAGE_ITERS];
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int it = 0; it < STAGE_ITERS; ++it) {
+            const int idx = it * 256 + tid;
+            if (idx < KT * CHUNKS) {
+                const int key = idx % KT, ch = idx / KT;
+                const half_t* row = base + (size_t)(t * KT + key) * ld + ch * 8;
+                kreg[it] = *reinterpret_cast<const half8_t*>(row + D);
+                vreg[it] = *reinterpret_cast<const half8_t*>(row + 2 * D);
+            }
+        }
+    };
+    auto write_tile = [&](int buf) {
+        half_t* kd = lds_k + buf * K_TILE;
+        half_t* vd = lds_vt + buf * VT_TILE;
+#pragma unroll
+        for (int it = 0; it < STAGE_ITERS; ++it) {
+            const int idx = it * 256 + tid;
+            if (idx < KT * CHUNKS) {
+                const int key = idx % KT, ch = idx / KT;
+                *reinterpret_cast<half8_t*>(kd + key * K_STRIDE + ch * 8) = kreg[it];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vd[(ch * 8 + e) * VT_STRIDE + key] = vreg[it][e];
+            }
+        }
+    };
+
+    if (DT * 32 > HD) {         // rows of V^T beyond the head dimension stay zero in both buffers
+        for (int idx = tid; idx < 2 * VT_TILE / 2; idx += 256) reinterpret_cast<uint32_t*>(lds_vt)[idx] = 0u;
+        __syncthreads();
+    }
+    load_tile(0);
+    write_tile(0);
+    __syncthreads();
+
+    float16_t o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] = zero16();
+    float m = -INFINITY, l = 0.f;
+
+    constexpr int NT = TOKENS / KT;
+    for (int t = 0; t < NT; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < NT) load_tile(t + 1);
+
+        const half_t* kb = lds_k + buf * K_TILE;
+        const half_t* vb = lds_vt + buf * VT_TILE;
+        const float rh = relh_lds[(wave * 64 + t) * RELH_STRIDE + l31];
+
+        float16_t s[2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[jt][r] = relw[jt][r] + rh;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                half8_t kf = *reinterpret_cast<const half8_t*>(kb + (jt * 32 + l31) * K_STRIDE + ks * 16 + hi * 8);
+                s[jt] = mfma32(kf, qf[ks], s[jt]);
+            }
+        }
+
+        // online softmax (per lane = per query; the two halves hold disjoint key subsets)
+        float tm = s[0][0];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tm = fmaxf(tm, s[jt][r]);
+        tm = fmaxf(tm, swap_halves(tm));
+        const float m_new = fmaxf(m, tm);
+        const float alpha = exp2f((m - m_new) * c);
+        m = m_new;
+        float ps = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float p = exp2f((s[jt][r] - m_new) * c);
+                s[jt][r] = p;
+                ps += p;
+            }
+        l = l * alpha + ps;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+
+        // O^T += V^T . P^T   (P tile as B operand straight from the accumulator registers)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                half8_t pf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[e] = (half_t)s[jt][st * 8 + e];
+                const int key0 = jt * 32 + st * 16 + hi * 4;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const half_t* vrow = vb + (dt * 32 + l31) * VT_STRIDE + key0;
+                    half4_t v0 = *reinterpret_cast<const half4_t*>(vrow);
+                    half4_t v1 = *reinterpret_cast<const half4_t*>(vrow + 8);
+                    half8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    o[dt] = mfma32(vf, pf, o[dt]);
+                }
+            }
+        }
+
+        if (t + 1 < NT) write_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: O^T[d][i] / l_i ; lane = query, registers = d ------------------------------------
+    l += swap_halves(l);
+    const float inv_l = 1.0f / l;
+    half_t* orow = out + ((size_t)img * TOKENS + qtok) * D + head * HD;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int d0 = dt * 32 + 8 * g4 + 4 * hi;
+            if (d0 < HD) {
+                half4_t v = {(half_t)(o[dt][g4 * 4 + 0] * inv_l), (half_t)(o[dt][g4 * 4 + 1] * inv_l),
+                             (half_t)(o[dt][g4 * 4 + 2] * inv_l), (half_t)(o[dt][g4 * 4 + 3] * inv_l)};
+                *reinterpret_cast<half4_t*>(orow + d0) = v;
+            }
+        }
+    }
+}
+
+template <int HD>
+void launch_global(const half_t* qkv, const float* rel_h, const float* rel_w, half_t* out, int B, int heads,
+                   hipStream_t s) {
+    constexpr int DT = (HD + 31) / 32;
+    const size_t tiles = 2 * ((size_t)KT * (HD + 8) + (size_t)DT * 32 * VT_STRIDE) * 2;
+    const size_t scratch = 4 * 32 * GW_STRIDE * 4;
+    const size_t lds = 4 * 64 * RELH_STRIDE * 4 + (tiles > scratch ? tiles : scratch);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)attention_global_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attention_global_kernel<HD>, dim3(B * heads * (TOKENS / 128)), dim3(256), lds, s, qkv, rel_h,
+                       rel_w, out, heads);
+}
+
+}  // namespace
+
+namespace k {
+
+void attention_global(const half_t* qkv, const float* rel_h, const float* rel_w, half_t* out, int B, int heads, int hd,
+                      hipStream_t s) {
+    if (B <= 0 || heads <= 0) throw_error("attention_global: empty problem");
+    if (((uintptr_t)qkv | (uintptr_t)out) & 15) throw_error("attention_global: buffers must be 16-byte aligned");
+    switch (hd) {
+    case 64: return launch_global<64>(qkv, rel_h, rel_w, out, B, heads, s);
+    case 80: return launch_global<80>(qkv, rel_h, rel_w, out, B, heads, s);
+    default: throw_error("attention_global: head dimension must be 64 or 80");
+    }
+}
+
+}  // namespace k
+}  // namespace dlimg

@@ -1,0 +1,266 @@
+// Windowed self-attention of the SAM ViT encoder blocks (14x14 windows over the 64x64 token grid,
+// zero-padded to 70x70 -> 25 windows), with decomposed relative-position bias.
+// This arithmetic lives inside the encoder ONNX graph in the reference
+// (/root/reference/src/segmentation.cpp:126-128 runs it through Session::run); the published
+// definition is the SAM `Attention` / `window_partition` / `add_decomposed_rel_pos` trio.
+//
+// Semantics reproduced exactly (SURVEY.md §7 "window padding semantics"):
+//   * the pad tokens are zeros AFTER LayerNorm, so their q/k/v equal the qkv bias; they take part
+//     in the softmax as keys/values, un-masked; pad queries are computed nowhere (discarded);
+//   * S[i,j] = scale * q_i.k_j + q_i.Rh[ty_i - ty_j + 13] + q_i.Rw[tx_i - tx_j + 13] with the RAW q.
+//
+// One workgroup = one (image, window, head); 7 waves, each owning 32 query slots.
+// Slots are numbered ty*16 + tx (tx = 14, 15 are dummies), which makes 224 = 7*32 slots and lets
+// every MFMA accumulator register know its key's (ty, tx) at compile time.
+// Per wave:   G   = rel_pos . Q^T   (MFMA, 27 rows each for h and w)  -> per-lane bias registers
+//             S^T = K . Q^T + bias/scale   (swapped operands: a lane owns one query column)
+//             softmax over the 224 key slots entirely in registers (+ one exchange between halves)
+//             O   = P . V   with the accumulator tiles re-used directly as the A operand.
+#include "device_common.hpp"
+#include "kernels.hpp"
+
+namespace dlimg {
+namespace {
+
+constexpr int WS = 14;            // window size
+constexpr int SLOTS = 224;        // 14 rows x 16 (14 real + 2 dummy) columns
+constexpr int NW = 5;             // windows per axis (70 / 14)
+constexpr int GRID = 64;
+constexpr int VT_STRIDE = 228;    // elements per row of the transposed V image (456 B: conflict-free ds_read_b64)
+constexpr int G_STRIDE = 33;      // floats per row of the per-wave rel-pos scratch
+
+struct WinSlot { int token; bool dummy; bool pad; };
+
+// slot -> token of window (wy, wx); dummy = not a key at all; pad = zero-padded token (qkv == bias)
+DLIMG_DEVICE WinSlot win_slot(int slot, int wy, int wx) {
+    int ty = slot >> 4, tx = slot & 15;
+    int gy = wy * WS + ty, gx = wx * WS + tx;
+    WinSlot s;
+    s.dummy = tx >= WS;
+    s.pad = !s.dummy && (gy >= GRID || gx >= GRID);
+    s.token = gy * GRID + gx;
+    return s;
+}
+
+template <int HD>
+__global__ __launch_bounds__(448) void attention_window_kernel(const half_t* __restrict__ qkv,
+                                                               const float* __restrict__ qkv_bias,
+                                                               const float* __restrict__ rel_h,
+                                                               const float* __restrict__ rel_w,
+                                                               half_t* __restrict__ out, int heads) {
+    constexpr int KS = HD / 16;                 // MFMA k-steps over the head dimension
+    constexpr int DT = (HD + 31) / 32;          // 32-wide output tiles over the head dimension
+    constexpr int K_STRIDE = HD + 8;            // elements; +16 B keeps ds_read_b128 conflict-free
+    constexpr int CHUNKS = HD / 8;              // 16-byte chunks per row
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t* lds_k = reinterpret_cast<half_t*>(smem);                              // [224][K_STRIDE]
+    half_t* lds_vt = lds_k + SLOTS * K_STRIDE;                                    // [DT*32][VT_STRIDE]
+    float* lds_g = reinterpret_cast<float*>(lds_vt + DT * 32 * VT_STRIDE);        // [7 waves][32][G_STRIDE]
+
+    const int D = heads * HD;
+    const int ld = 3 * D;
+    const int head = blockIdx.x % heads;
+    const int win = (blockIdx.x / heads) % (NW * NW);
+    const int img = blockIdx.x / (heads * NW * NW);
+    const int wy = win / NW, wx = win % NW;
+    const half_t* base = qkv + (size_t)img * 4096 * ld;
+    const int tid = threadIdx.x;
+    const int lane = lane_id();
+    const int wave = wave_id();
+    const int hi = lane >> 5, l31 = lane & 31;
+
+    // ---- stage K (row-major, padded rows) and V (transposed) of the whole window --------------
+    for (int idx = tid; idx < DT * 32 * VT_STRIDE / 2; idx += 448)              // zero V^T incl. pad rows
+        reinterpret_cast<uint32_t*>(lds_vt)[idx] = 0u;
+    __syncthreads();
+    for (int idx = tid; idx < SLOTS * CHUNKS; idx += 448) {
+        // consecutive threads take consecutive slots of one chunk: V^T writes land in adjacent halves
+        const int slot = idx % SLOTS, ch = idx / SLOTS;
+        const WinSlot ws = win_slot(slot, wy, wx);
+        half8_t kv = zero_h8(), vv = zero_h8();
+        if (!ws.dummy) {
+            if (ws.pad) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    kv[e] = (half_t)qkv_bias[D + head * HD + ch * 8 + e];
+                    vv[e] = (half_t)qkv_bias[2 * D + head * HD + ch * 8 + e];
+                }
+            } else {
+                const half_t* row = base + (size_t)ws.token * ld + head * HD + ch * 8;
+                kv = *reinterpret_cast<const half8_t*>(row + D);
+                vv = *reinterpret_cast<const half8_t*>(row + 2 * D);
+            }
+        }
+        *reinterpret_cast<half8_t*>(lds_k + slot * K_STRIDE + ch * 8) = kv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) lds_vt[(ch * 8 + e) * VT_STRIDE + slot] = vv[e];
+    }
+
+    // ---- this wave's 32 queries as B-operand fragments ------------------------------------------
+    const int qslot = wave * 32 + l31;
+    const WinSlot qs = win_slot(qslot, wy, wx);
+    const bool q_real = !qs.dummy && !qs.pad;
+    half8_t qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        qf[ks] = zero_h8();
+        if (q_real)
+            qf[ks] = *reinterpret_cast<const half8_t*>(base + (size_t)qs.token * ld + head * HD + ks * 16 + hi * 8);
+    }
+
+    // ---- decomposed rel-pos: G[r][i] = rel[r] . q_i  via MFMA, gathered into per-lane registers ----
+    float* g = lds_g + wave * 32 * G_STRIDE;
+    const int ty_q = qslot >> 4, tx_q = qslot & 15;
+    float bh[WS];       // bias from the key's row, index = key ty
+    float bw[8];        // bias from the key's column, index e <-> tx = (e&3) + 8*(e>>2) + 4*hi
+    {
+        float16_t acc = zero16();
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            half8_t rf = zero_h8();
+            if (l31 < 2 * WS - 1) {
+                const float* r = rel_h + l31 * HD + ks * 16 + hi * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rf[e] = (half_t)r[e];
+            }
+            acc = mfma32(rf, qf[ks], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[l31 * G_STRIDE + acc_row(r, hi)] = acc[r];
+        __syncthreads();
+#pragma unroll
+        for (int ky = 0; ky < WS; ++ky) bh[ky] = g[l31 * G_STRIDE + ty_q + (WS - 1) - ky];
+        __syncthreads();
+        acc = zero16();
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            half8_t rf = zero_h8();
+            if (l31 < 2 * WS - 1) {
+                const float* r = rel_w + l31 * HD + ks * 16 + hi * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rf[e] = (half_t)r[e];
+            }
+            acc = mfma32(rf, qf[ks], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[l31 * G_STRIDE + acc_row(r, hi)] = acc[r];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int tx = (e & 3) + 8 * (e >> 2) + 4 * hi;
+            // dummy key columns (tx >= 14) are removed from the softmax by a -inf bias
+            bw[e] = tx < WS ? g[l31 * G_STRIDE + tx_q + (WS - 1) - tx] : -INFINITY;
+        }
+    }
+    // (the barriers above also published the K / V^T images)
+
+    const float scale = rsqrtf((float)HD);
+    const float inv_scale = sqrtf((float)HD);
+
+    // ---- S^T = K . Q^T, accumulators initialised with bias/scale -----------------------------------
+    float16_t s[7];
+#pragma unroll
+    for (int jt = 0; jt < 7; ++jt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ty = jt * 2 + (r >> 3);
+            const int e = (r & 3) + 4 * ((r >> 2) & 1);
+            s[jt][r] = (bh[ty] + bw[e]) * inv_scale;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            half8_t kf = *reinterpret_cast<const half8_t*>(lds_k + (jt * 32 + l31) * K_STRIDE + ks * 16 + hi * 8);
+            s[jt] = mfma32(kf, qf[ks], s[jt]);
+        }
+    }
+
+    // ---- softmax over the 224 key slots of this lane's query --------------------------------------
+    float m = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < 7; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, s[jt][r]);
+    m = fmaxf(m, swap_halves(m));
+    const float c = scale * 1.44269504088896341f;
+    float l = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 7; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float p = exp2f((s[jt][r] - m) * c);
+            s[jt][r] = p;
+            l += p;
+        }
+    l += swap_halves(l);
+    const float inv_l = 1.0f / l;
+
+    // ---- O = P . V : accumulator tiles become A operands (k order permuted identically on V^T) ----
+    float16_t o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] = zero16();
+#pragma unroll
+    for (int jt = 0; jt < 7; ++jt) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            half8_t pf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[e] = (half_t)(s[jt][st * 8 + e] * inv_l);
+            const int key0 = jt * 32 + st * 16 + hi * 4;        // element e <-> key0 + 8*(e>>2) + (e&3)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const half_t* vrow = lds_vt + (dt * 32 + l31) * VT_STRIDE + key0;
+                half4_t v0 = *reinterpret_cast<const half4_t*>(vrow);
+                half4_t v1 = *reinterpret_cast<const half4_t*>(vrow + 8);
+                half8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                o[dt] = mfma32(pf, vf, o[dt]);
+            }
+        }
+    }
+
+    // ---- store: register r <-> query slot wave*32 + acc_row(r, hi), lane <-> d ---------------------
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const WinSlot os = win_slot(wave * 32 + acc_row(r, hi), wy, wx);
+        if (os.dummy || os.pad) continue;
+        half_t* orow = out + ((size_t)img * 4096 + os.token) * D + head * HD;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d = dt * 32 + l31;
+            if (d < HD) orow[d] = (half_t)o[dt][r];
+        }
+    }
+}
+
+template <int HD>
+void launch_window(const half_t* qkv, const float* bias, const float* rel_h, const float* rel_w, half_t* out, int B,
+                   int heads, hipStream_t s) {
+    constexpr int DT = (HD + 31) / 32;
+    const size_t lds = (size_t)SLOTS * (HD + 8) * 2 + (size_t)DT * 32 * VT_STRIDE * 2 + 7 * 32 * G_STRIDE * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)attention_window_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attention_window_kernel<HD>, dim3(B * NW * NW * heads), dim3(448), lds, s, qkv, bias, rel_h,
+                       rel_w, out, heads);
+}
+
+}  // namespace
+
+namespace k {
+
+void attention_window(const half_t* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w, half_t* out,
+                      int B, int heads, int hd, hipStream_t s) {
+    if (B <= 0 || heads <= 0) throw_error("attention_window: empty problem");
+    if (((uintptr_t)qkv | (uintptr_t)out) & 15) throw_error("attention_window: buffers must be 16-byte aligned");
+    switch (hd) {
+    case 64: return launch_window<64>(qkv, qkv_bias, rel_h, rel_w, out, B, heads, s);
+    case 80: return launch_window<80>(qkv, qkv_bias, rel_h, rel_w, out, B, heads, s);
+    default: throw_error("attention_window: head dimension must be 64 or 80");
+    }
+}
+
+}  // namespace k
+}  // namespace dlimg

@@ -1,0 +1,95 @@
+// Host-callable launchers of the gfx950 kernels.  All pointers are device pointers unless noted;
+// every launcher validates the shapes its grid assumes and throws dlimg::Exception on mismatch
+// (a faulting kernel can take the whole node down, so nothing is launched on unchecked shapes).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dlimg {
+
+typedef _Float16 half_t;
+
+[[noreturn]] void throw_error(const char* msg);   // defined in common.cpp
+
+namespace k {
+
+enum Act { ACT_NONE = 0, ACT_GELU = 1 };
+
+// ---- GEMM ------------------------------------------------------------------------------------
+struct GemmArgs {
+    const half_t* A = nullptr;  int lda = 0;     // [M,K] row-major f16
+    const half_t* W = nullptr;  int ldw = 0;     // [N,K] row-major f16 (nn.Linear layout)
+    const float* bias = nullptr;                 // [N] or null
+    const float* resid = nullptr; int ldr = 0; int resid_mod = 1;   // added after activation: resid[m % resid_mod][n]
+    float* out_f32 = nullptr;   int ldc32 = 0;
+    half_t* out_h = nullptr;    int ldc16 = 0;
+    int M = 0, N = 0, K = 0;
+    int act = ACT_NONE;
+};
+const char* gemm_check(const GemmArgs&);
+void gemm(const GemmArgs&, hipStream_t);
+
+// ---- row LayerNorm ---------------------------------------------------------------------------
+// y = (x-mean)/sqrt(var+eps)*w+b over rows of length D (<= 1280); optional GELU; f32 and/or f16 out.
+// x and out_f32 may alias.
+void layernorm(const float* x, const float* w, const float* b, float eps, int rows, int D, int act,
+               float* out_f32, half_t* out_h, hipStream_t);
+
+// ---- pixel pre-processing (K1) ---------------------------------------------------------------
+// u8 image [h,w,C] (row stride `stride` bytes; dlimg::Channels code `channels`) -> f16 patch-major
+// matrix [4096, 768]: row = patch (py*64+px), column = c*256 + iy*16 + ix, value
+// (float(u8) - mean[c]) / std[c]; pixels outside h x w (zero padding of the graph) are 0.
+void preprocess(const uint8_t* img, int w, int h, int stride, int channels, half_t* patches, hipStream_t);
+
+// ---- elementwise -----------------------------------------------------------------------------
+// out_h[i] = f16(a[i] + (b ? b[i % b_mod] : 0)); out_f32 likewise (either may be null); n % 4 == 0
+void add_cast(const float* a, const float* b, size_t b_mod, size_t n, float* out_f32, half_t* out_h, hipStream_t);
+// 3x3 im2col over a [B,64,64,C] f16 map (zero pad 1): out [B*4096, 9*C], column = (ky*3+kx)*C + c
+void im2col3x3(const half_t* in, int B, int C, half_t* out, hipStream_t);
+// f32 -> f16 conversion of a weight tensor
+void cast_f16(const float* in, half_t* out, size_t n, hipStream_t);
+
+// ---- encoder attention -----------------------------------------------------------------------
+// qkv: [B*4096, 3*D] f16 token-major (q | k | v, head-major inside each), out: [B*4096, D] f16.
+// qkv_bias: f32 [3*D] (keys/values of zero-padded window tokens equal the bias).
+// rel_h/rel_w: f32 [2*S-1, hd] with S = 14 (windowed) or 64 (global).
+void attention_window(const half_t* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w,
+                      half_t* out, int B, int heads, int hd, hipStream_t);
+void attention_global(const half_t* qkv, const float* rel_h, const float* rel_w, half_t* out, int B,
+                      int heads, int hd, hipStream_t);
+
+// ---- mask decoder (token side is tiny: fp32 VALU kernels) ------------------------------------
+// tokens [P,7,256]: iou token, 4 mask tokens, 2 prompt tokens from (coords [P,2,2], labels [P,2])
+void prompt_tokens(const float* coords, const float* labels, const float* gauss, const float* point_embed,
+                   const float* not_a_point, const float* iou_token, const float* mask_tokens, float* tokens,
+                   int P, hipStream_t);
+// Y[r,n] = act((X[r,:] + X2[r,:]) . W[n,:] + b[n]) + R[r,n]; X2/R optional; act: 0 none, 2 relu
+void token_linear(const float* X, const float* X2, const float* W, const float* b, const float* R, float* Y,
+                  int rows, int K, int N, int relu, hipStream_t);
+// multi-head attention among the 7 tokens of each prompt: q,k,v [P,7,256] -> out [P,7,256] (8 heads)
+void token_self_attention(const float* q, const float* k, const float* v, float* out, int P, hipStream_t);
+// tokens attend to the image: q [P,7,128] f32, K,V [P,4096,ld] f16 (column offsets given) -> out [P,7,128]
+void token_to_image_attention(const float* q, const half_t* K, int ldk, const half_t* V, int ldv, float* out,
+                              int P, hipStream_t);
+// image attends to tokens: q [P,4096,ldq] f16, k,v [P,7,128] f32 -> out [P,4096,128] f16
+void image_to_token_attention(const half_t* q, int ldq, const float* k, const float* v, half_t* out, int P,
+                              hipStream_t);
+// hyper-network MLPs (4 x 256->256->256->32) and IoU head (256->256->256->4) on the output tokens
+struct HeadWeights { const float* w[5][3]; const float* b[5][3]; };
+void output_heads(const float* queries /*[P,7,256]*/, const HeadWeights& hw, float* hyper /*[P,4,32]*/,
+                  float* iou /*[P,4]*/, int P, hipStream_t);
+// low-res logits [P,4,256,256] from the upscaled embedding in quad order and the hyper vectors.
+// up: [P*65536, 32] f32, row = ((y*64+x)*4 + dy1*2+dx1)*4 + dy2*2+dx2  (pixel Y = 4y+2dy1+dy2, X likewise)
+void mask_logits(const float* up, const float* hyper, float* logits, int P, hipStream_t);
+
+// ---- mask post-processing (K16) --------------------------------------------------------------
+// For each of `count` jobs: logits plane job.src (256x256 f32, device) -> two-stage bilinear
+// (256->1024, crop to prepadded ph x pw, -> out_h x out_w), threshold > 0 -> 255/0 into job.dst (device, packed rows).
+// If job.select_iou != nullptr the plane is chosen on device as argmax over planes 1..3 of
+// select_iou[0..3] (SamOnnxModel.select_masks with 2 prompt points) starting from job.src as plane 0.
+struct PostJob { const float* src; const float* select_iou; uint8_t* dst; int out_w, out_h, pre_w, pre_h; };
+void postprocess_masks(const PostJob* jobs_host, int count, hipStream_t);
+
+}  // namespace k
+}  // namespace dlimg

@@ -1,0 +1,128 @@
+// K16  mask post-processing: low-res logits -> binary mask at the original image resolution.
+//
+// Fuses what the reference does in two places:
+//   * in the decoder ONNX graph (SamOnnxModel.mask_postprocessing, exported by
+//     /root/reference/script/export_models.py:29-43): bilinear 256->1024 (align_corners=False),
+//     crop to the pre-padding size, bilinear to (H, W);
+//   * write_mask_image (/root/reference/src/segmentation.cpp:108-116): `> 0 ? 255 : 0`;
+//   * and, in single-mask mode, SamOnnxModel.select_masks (argmax of iou + (n_pts-2.5)*[1000,0,0,0]).
+// Neither 4 MiB fp32 intermediate is materialised: each output pixel evaluates the two stages
+// analytically (up to 4 stage-1 samples of 4 taps each).
+//
+// Every multiply/add is an explicitly rounded fp32 operation (__fmul_rn/__fadd_rn, no fma
+// contraction) in the order of oracle/sam_oracle.py:bilinear_resize, so the thresholded mask is
+// bit-identical to the oracle's for identical logits.
+#include "device_common.hpp"
+#include "kernels.hpp"
+
+namespace dlimg {
+namespace {
+
+constexpr int LOW = 256;
+constexpr int FULL = 1024;
+constexpr int MAX_JOBS = 16;
+
+struct JobPack { k::PostJob j[MAX_JOBS]; };
+
+struct Tap { int i0, i1; float w0, w1; };
+
+// half-pixel bilinear source coordinates, align_corners=False (oracle: _lin_coeffs)
+DLIMG_DEVICE Tap make_tap(int dst, float scale, int in_size) {
+    float src = __fsub_rn(__fmul_rn(scale, __fadd_rn((float)dst, 0.5f)), 0.5f);
+    src = fmaxf(src, 0.f);
+    Tap t;
+    t.i0 = min((int)src, in_size - 1);
+    t.i1 = min(t.i0 + 1, in_size - 1);
+    float l1 = __fsub_rn(src, (float)t.i0);
+    l1 = fminf(fmaxf(l1, 0.f), 1.f);
+    t.w1 = l1;
+    t.w0 = __fsub_rn(1.0f, l1);
+    return t;
+}
+
+DLIMG_DEVICE float lerp2(float a00, float a01, float a10, float a11, const Tap& ty, const Tap& tx) {
+    const float top = __fadd_rn(__fmul_rn(a00, tx.w0), __fmul_rn(a01, tx.w1));
+    const float bot = __fadd_rn(__fmul_rn(a10, tx.w0), __fmul_rn(a11, tx.w1));
+    return __fadd_rn(__fmul_rn(ty.w0, top), __fmul_rn(ty.w1, bot));
+}
+
+// value of the 1024x1024 upsampled plane at (Y, X)
+DLIMG_DEVICE float stage1(const float* __restrict__ low, int Y, int X) {
+    const Tap ty = make_tap(Y, 0.25f, LOW), tx = make_tap(X, 0.25f, LOW);
+    const float* r0 = low + ty.i0 * LOW;
+    const float* r1 = low + ty.i1 * LOW;
+    return lerp2(r0[tx.i0], r0[tx.i1], r1[tx.i0], r1[tx.i1], ty, tx);
+}
+
+__global__ __launch_bounds__(256) void postprocess_kernel(JobPack pack) {
+    const k::PostJob job = pack.j[blockIdx.y];
+    const float* low = job.src;
+    if (job.select_iou) {
+        // SamOnnxModel.select_masks with num_points = 2: score = iou + (2 - 2.5) * [1000, 0, 0, 0]
+        float best = __fadd_rn(job.select_iou[0], __fmul_rn(-0.5f, 1000.0f));
+        int bi = 0;
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+            if (job.select_iou[i] > best) { best = job.select_iou[i]; bi = i; }
+        low += (size_t)bi * LOW * LOW;
+    }
+    const int W = job.out_w, H = job.out_h;
+    const int groups_per_row = (W + 3) >> 2;
+    const bool identity2 = (job.pre_w == W && job.pre_h == H);
+    const float sy = (float)job.pre_h / (float)H, sx = (float)job.pre_w / (float)W;
+    const long total = (long)H * groups_per_row;
+    for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long)gridDim.x * 256) {
+        const int oy = (int)(g / groups_per_row);
+        const int ox0 = (int)(g % groups_per_row) * 4;
+        uint32_t packed = 0;
+        Tap t2y;
+        if (!identity2) t2y = make_tap(oy, sy, job.pre_h);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ox = ox0 + i;
+            if (ox >= W) break;
+            float v;
+            if (identity2) {
+                v = stage1(low, oy, ox);
+            } else {
+                const Tap t2x = make_tap(ox, sx, job.pre_w);
+                v = lerp2(stage1(low, t2y.i0, t2x.i0), stage1(low, t2y.i0, t2x.i1), stage1(low, t2y.i1, t2x.i0),
+                          stage1(low, t2y.i1, t2x.i1), t2y, t2x);
+            }
+            if (v > 0.f) packed |= 0xffu << (8 * i);
+        }
+        uint8_t* dst = job.dst + (size_t)oy * W + ox0;
+        if (ox0 + 4 <= W && (((uintptr_t)dst) & 3) == 0) {
+            *reinterpret_cast<uint32_t*>(dst) = packed;
+        } else {
+            for (int i = 0; i < 4 && ox0 + i < W; ++i) dst[i] = (uint8_t)(packed >> (8 * i));
+        }
+    }
+}
+
+}  // namespace
+
+namespace k {
+
+void postprocess_masks(const PostJob* jobs, int count, hipStream_t s) {
+    for (int base = 0; base < count; base += MAX_JOBS) {
+        const int n = count - base < MAX_JOBS ? count - base : MAX_JOBS;
+        JobPack pack{};
+        long max_groups = 1;
+        for (int i = 0; i < n; ++i) {
+            const PostJob& j = jobs[base + i];
+            if (j.out_w <= 0 || j.out_h <= 0 || j.pre_w <= 0 || j.pre_h <= 0 || j.pre_w > FULL || j.pre_h > FULL)
+                throw_error("postprocess_masks: invalid extent");
+            if (!j.src || !j.dst) throw_error("postprocess_masks: null buffer");
+            pack.j[i] = j;
+            long g = (long)j.out_h * ((j.out_w + 3) / 4);
+            if (g > max_groups) max_groups = g;
+        }
+        long blocks = (max_groups + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(postprocess_kernel, dim3((unsigned)blocks, n), dim3(256), 0, s, pack);
+    }
+}
+
+}  // namespace k
+}  // namespace dlimg

@@ -1,0 +1,573 @@
+#include "sam_model.hpp"
+
+#include <cmath>
+#include <cstring>
+
+namespace dlimg {
+
+namespace {
+
+constexpr float kLnEps = 1e-6f;
+
+struct Loader {
+    WeightFile const& file;
+    hipStream_t stream;
+    DeviceBuffer<float> staging;    // fp32 staging for device-side f16 conversion
+
+    void f32(std::string const& name, std::vector<int64_t> const& dims, DeviceBuffer<float>& dst) {
+        HostTensor const& t = file.get(name, dims);
+        dst.reserve(t.numel());
+        HIP_CHECK(hipMemcpy(dst.get(), t.data, t.numel() * 4, hipMemcpyHostToDevice));
+    }
+    void f32_host(std::vector<float> const& v, DeviceBuffer<float>& dst) {
+        dst.reserve(v.size());
+        HIP_CHECK(hipMemcpy(dst.get(), v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    }
+    void f16_host(float const* src, size_t n, DeviceBuffer<half_t>& dst) {
+        staging.reserve(n);
+        dst.reserve(n);
+        HIP_CHECK(hipMemcpy(staging.get(), src, n * 4, hipMemcpyHostToDevice));
+        k::cast_f16(staging.get(), dst.get(), n, stream);
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    void linear_h(std::string const& prefix, int out, int in, bool bias, LinearH& l) {
+        HostTensor const& w = file.get(prefix + ".w", {out, in});
+        f16_host(w.data, w.numel(), l.w);
+        l.out = out;
+        l.in = in;
+        l.has_bias = bias;
+        if (bias) f32(prefix + ".b", {out}, l.b);
+    }
+    void linear_f(std::string const& prefix, int out, int in, LinearF& l) {
+        f32(prefix + ".w", {out, in}, l.w);
+        f32(prefix + ".b", {out}, l.b);
+        l.out = out;
+        l.in = in;
+    }
+    void norm(std::string const& prefix, int dim, NormW& n) {
+        f32(prefix + ".w", {dim}, n.w);
+        f32(prefix + ".b", {dim}, n.b);
+    }
+    void attention(std::string const& prefix, int dim, int inner, TokenAttention& a) {
+        linear_f(prefix + ".q", inner, dim, a.q);
+        linear_f(prefix + ".k", inner, dim, a.k);
+        linear_f(prefix + ".v", inner, dim, a.v);
+        linear_f(prefix + ".o", dim, inner, a.o);
+    }
+    // rows of `a` followed by rows of `b` -> one f16 GEMM weight with concatenated bias
+    void fused_h(std::string const& pa, std::string const& pb, int out_each, int in, LinearH& l) {
+        HostTensor const& wa = file.get(pa + ".w", {out_each, in});
+        HostTensor const& wb = file.get(pb + ".w", {out_each, in});
+        HostTensor const& ba = file.get(pa + ".b", {out_each});
+        HostTensor const& bb = file.get(pb + ".b", {out_each});
+        std::vector<float> w(2 * (size_t)out_each * in), b(2 * (size_t)out_each);
+        std::memcpy(w.data(), wa.data, wa.numel() * 4);
+        std::memcpy(w.data() + wa.numel(), wb.data, wb.numel() * 4);
+        std::memcpy(b.data(), ba.data, ba.numel() * 4);
+        std::memcpy(b.data() + out_each, bb.data, bb.numel() * 4);
+        f16_host(w.data(), w.size(), l.w);
+        f32_host(b, l.b);
+        l.out = 2 * out_each;
+        l.in = in;
+        l.has_bias = true;
+    }
+    // ConvTranspose2d(k=2, s=2) weight [ci, co, 2, 2] -> GEMM weight [n = (dy*2+dx)*co_n + co][k = ci]
+    void conv_transpose_h(std::string const& prefix, int ci_n, int co_n, LinearH& l) {
+        HostTensor const& w = file.get(prefix + ".w", {ci_n, co_n, 2, 2});
+        HostTensor const& b = file.get(prefix + ".b", {co_n});
+        std::vector<float> g((size_t)4 * co_n * ci_n), gb((size_t)4 * co_n);
+        for (int s = 0; s < 4; ++s)
+            for (int co = 0; co < co_n; ++co) {
+                gb[(size_t)s * co_n + co] = b.data[co];
+                for (int ci = 0; ci < ci_n; ++ci)
+                    g[((size_t)s * co_n + co) * ci_n + ci] = w.data[((size_t)ci * co_n + co) * 4 + s];
+            }
+        f16_host(g.data(), g.size(), l.w);
+        f32_host(gb, l.b);
+        l.out = 4 * co_n;
+        l.in = ci_n;
+        l.has_bias = true;
+    }
+};
+
+}  // namespace
+
+SamModel::SamModel(std::string const& weight_path, int device) : device_(device) {
+    WeightFile file(weight_path);
+    geom_ = file.geometry();
+    const int D = geom_.embed_dim, hd = geom_.head_dim();
+    if (D % 64 || geom_.mlp_dim % 64) throw Exception("SAM encoder width must be a multiple of 64");
+    if (D != hd * geom_.num_heads || (hd != 64 && hd != 80))
+        throw Exception("SAM encoder head dimension must be 64 or 80");
+
+    HIP_CHECK(hipSetDevice(device_));
+    HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&upload_done_, hipEventDisableTiming));
+    for (auto& e : prompt_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    Loader ld{file, stream_, {}};
+
+    ld.linear_h("enc.patch", D, kPatchK, true, patch_);
+    ld.f32("enc.pos", {kTokens, D}, pos_embed_);
+    layers_.resize(geom_.depth);
+    for (int i = 0; i < geom_.depth; ++i) {
+        EncoderLayer& L = layers_[i];
+        const std::string p = "enc.L" + std::to_string(i);
+        L.global = geom_.is_global(i);
+        const int span = L.global ? 64 : 14;
+        ld.norm(p + ".ln1", D, L.ln1);
+        ld.linear_h(p + ".qkv", 3 * D, D, true, L.qkv);
+        ld.f32(p + ".rel_h", {2 * span - 1, hd}, L.rel_h);
+        ld.f32(p + ".rel_w", {2 * span - 1, hd}, L.rel_w);
+        ld.linear_h(p + ".proj", D, D, true, L.proj);
+        ld.norm(p + ".ln2", D, L.ln2);
+        ld.linear_h(p + ".fc1", geom_.mlp_dim, D, true, L.fc1);
+        ld.linear_h(p + ".fc2", D, geom_.mlp_dim, true, L.fc2);
+    }
+    ld.linear_h("enc.neck.conv1", kEmbedDim, D, false, neck1_);
+    ld.norm("enc.neck.ln1", kEmbedDim, neck_ln1_);
+    {   // 3x3 conv [co, ci, ky, kx] -> [co][(ky*3+kx)*256 + ci], matching im2col3x3's column order
+        HostTensor const& w = file.get("enc.neck.conv2.w", {kEmbedDim, kEmbedDim, 3, 3});
+        std::vector<float> g(w.numel());
+        for (int co = 0; co < kEmbedDim; ++co)
+            for (int ci = 0; ci < kEmbedDim; ++ci)
+                for (int t = 0; t < 9; ++t)
+                    g[((size_t)co * 9 + t) * kEmbedDim + ci] = w.data[((size_t)co * kEmbedDim + ci) * 9 + t];
+        ld.f16_host(g.data(), g.size(), neck2_.w);
+        neck2_.out = kEmbedDim;
+        neck2_.in = 9 * kEmbedDim;
+    }
+    ld.norm("enc.neck.ln2", kEmbedDim, neck_ln2_);
+
+    ld.f32("pe.gauss", {2, 128}, pe_gauss_);
+    ld.f32("pe.point", {4, 256}, pe_point_);
+    ld.f32("pe.not_a_point", {256}, pe_not_a_point_);
+    ld.f32("pe.no_mask", {256}, pe_no_mask_);
+    {   // dense positional encoding of the 64x64 grid (PositionEmbeddingRandom.forward), constant
+        HostTensor const& g = file.get("pe.gauss", {2, 128});
+        std::vector<float> pe((size_t)kTokens * 256);
+        for (int y = 0; y < 64; ++y)
+            for (int x = 0; x < 64; ++x) {
+                const float cx = 2.0f * ((x + 0.5f) / 64.0f) - 1.0f, cy = 2.0f * ((y + 0.5f) / 64.0f) - 1.0f;
+                float* row = pe.data() + ((size_t)y * 64 + x) * 256;
+                for (int kf = 0; kf < 128; ++kf) {
+                    const float v = 6.283185307179586f * (cx * g.data[kf] + cy * g.data[128 + kf]);
+                    row[kf] = std::sin(v);
+                    row[128 + kf] = std::cos(v);
+                }
+            }
+        ld.f32_host(pe, image_pe_);
+    }
+    ld.f32("dec.iou_token", {256}, iou_token_);
+    ld.f32("dec.mask_tokens", {4, 256}, mask_tokens_);
+    for (int i = 0; i < 2; ++i) {
+        DecoderLayer& L = dec_[i];
+        const std::string p = "dec.L" + std::to_string(i);
+        ld.attention(p + ".self", 256, 256, L.self_attn);
+        ld.norm(p + ".ln1", 256, L.ln1);
+        ld.norm(p + ".ln2", 256, L.ln2);
+        ld.norm(p + ".ln3", 256, L.ln3);
+        ld.norm(p + ".ln4", 256, L.ln4);
+        ld.linear_f(p + ".t2i.q", 128, 256, L.t2i_q);
+        ld.linear_f(p + ".t2i.o", 256, 128, L.t2i_o);
+        ld.fused_h(p + ".t2i.k", p + ".i2t.q", 128, 256, L.img_kq);
+        ld.linear_h(p + ".t2i.v", 128, 256, true, L.img_v);
+        ld.linear_f(p + ".mlp.fc1", 2048, 256, L.mlp1);
+        ld.linear_f(p + ".mlp.fc2", 256, 2048, L.mlp2);
+        ld.linear_f(p + ".i2t.k", 128, 256, L.i2t_k);
+        ld.linear_f(p + ".i2t.v", 128, 256, L.i2t_v);
+        ld.linear_h(p + ".i2t.o", 256, 128, true, L.i2t_o);
+    }
+    ld.linear_f("dec.final.q", 128, 256, final_q_);
+    ld.linear_f("dec.final.o", 256, 128, final_o_);
+    ld.linear_h("dec.final.k", 128, 256, true, final_k_);
+    ld.linear_h("dec.final.v", 128, 256, true, final_v_);
+    ld.norm("dec.ln_final", 256, ln_final_);
+    ld.conv_transpose_h("dec.up1", 256, 64, up1_);
+    ld.norm("dec.up_ln", 64, up_ln_);
+    ld.conv_transpose_h("dec.up2", 64, 32, up2_);
+    for (int m = 0; m < 5; ++m) {
+        const std::string p = m < 4 ? "dec.hyper" + std::to_string(m) : std::string("dec.iou");
+        const int last = m < 4 ? 32 : 4;
+        ld.linear_f(p + ".0", 256, 256, heads_[m][0]);
+        ld.linear_f(p + ".1", 256, 256, heads_[m][1]);
+        ld.linear_f(p + ".2", last, 256, heads_[m][2]);
+    }
+    HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+SamModel::~SamModel() {
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    for (auto& p : pending_) {
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    for (auto e : event_pool_) (void)hipEventDestroy(e);
+    if (upload_done_) (void)hipEventDestroy(upload_done_);
+    for (auto e : prompt_done_)
+        if (e) (void)hipEventDestroy(e);
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+// ---------------------------------------------------------------------------------------------
+// profiling
+
+void SamModel::set_profiling(bool on) {
+    flush_events();
+    profiling_ = on;
+}
+
+void SamModel::flush_events() {
+    if (pending_.empty()) return;
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    for (auto& p : pending_) {
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, p.a, p.b));
+        stats_.ms[p.st] += ms;
+        stats_.work[p.st] += p.work;
+        stats_.launches[p.st] += 1;
+        event_pool_.push_back(p.a);
+        event_pool_.push_back(p.b);
+    }
+    pending_.clear();
+}
+
+StageStats SamModel::take_stats() {
+    flush_events();
+    StageStats s = stats_;
+    stats_ = StageStats{};
+    return s;
+}
+
+template <typename F> void SamModel::timed(Stage st, double work, F&& launch) {
+    if (!profiling_) {
+        launch();
+        return;
+    }
+    auto take = [&]() {
+        hipEvent_t e;
+        if (!event_pool_.empty()) {
+            e = event_pool_.back();
+            event_pool_.pop_back();
+        } else {
+            HIP_CHECK(hipEventCreate(&e));
+        }
+        return e;
+    };
+    Pending p{take(), take(), st, work};
+    HIP_CHECK(hipEventRecord(p.a, stream_));
+    launch();
+    HIP_CHECK(hipEventRecord(p.b, stream_));
+    pending_.push_back(p);
+    if (pending_.size() > 8192) flush_events();
+}
+
+void SamModel::gemm(k::GemmArgs const& a) {
+    timed(ST_GEMM, 2.0 * a.M * a.N * a.K, [&] { k::gemm(a, stream_); });
+}
+
+void SamModel::synchronize() { HIP_CHECK(hipStreamSynchronize(stream_)); }
+
+// ---------------------------------------------------------------------------------------------
+// encoder
+
+void SamModel::reserve_encoder(int batch) {
+    if (batch <= enc_batch_) return;
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    const size_t M = (size_t)batch * kTokens;
+    const size_t D = geom_.embed_dim;
+    const size_t wide = std::max<size_t>(geom_.mlp_dim, 9 * kEmbedDim);
+    img_dev_.reserve((size_t)batch * kImageSize * kImageSize * 4);
+    patches_.reserve(M * kPatchK);
+    x_.reserve(M * D);
+    xn_.reserve(M * D);
+    qkv_.reserve(M * 3 * D);
+    att_.reserve(M * std::max<size_t>(D, kEmbedDim));
+    hid_.reserve(M * wide);
+    neck_f32_.reserve(M * kEmbedDim);
+    emb_.reserve(M * kEmbedDim);
+    enc_batch_ = batch;
+}
+
+void SamModel::preprocess_device_image(int slot, int batch, uint8_t const* dev_pixels, int w, int h, int stride,
+                                       int channels) {
+    DLIMG_ASSERT(slot >= 0 && slot < batch);
+    reserve_encoder(batch);
+    const int bytes = channels > 4 ? 4 : channels;
+    timed(ST_PRE, (double)w * h * bytes + (double)kTokens * kPatchK * 2, [&] {
+        k::preprocess(dev_pixels, w, h, stride, channels, patches_.get() + (size_t)slot * kTokens * kPatchK, stream_);
+    });
+}
+
+void SamModel::upload_image(int slot, int batch, uint8_t const* pixels, int w, int h, int stride, int channels) {
+    DLIMG_ASSERT(slot >= 0 && slot < batch);
+    DLIMG_ASSERT(w > 0 && h > 0 && w <= kImageSize && h <= kImageSize);
+    reserve_encoder(batch);
+    const int bytes = channels > 4 ? 4 : channels;
+    const size_t row = (size_t)w * bytes;
+    const size_t slot_bytes = (size_t)kImageSize * kImageSize * 4;
+    img_pinned_.reserve((size_t)batch * slot_bytes);
+    uint8_t* pin = static_cast<uint8_t*>(img_pinned_.get()) + slot * slot_bytes;
+    // Rows are packed on the way (the reference's create_image_tensor assumes packed rows when no
+    // resize happens, segmentation.cpp:81-106; honouring the stride is identical for packed views).
+    if (slot == 0) HIP_CHECK(hipEventSynchronize(upload_done_));     // previous batch's copies have left the staging area
+    for (int y = 0; y < h; ++y) std::memcpy(pin + y * row, pixels + (size_t)y * stride, row);
+    uint8_t* dev = img_dev_.get() + slot * slot_bytes;
+    HIP_CHECK(hipMemcpyAsync(dev, pin, row * h, hipMemcpyHostToDevice, stream_));
+    if (slot == batch - 1) HIP_CHECK(hipEventRecord(upload_done_, stream_));
+    preprocess_device_image(slot, batch, dev, w, h, (int)row, channels);
+}
+
+void SamModel::upload_and_resize_image(int, int, uint8_t const*, int, int, int, int, int, int) {
+    throw Exception("Images whose longest side is not 1024 pixels need the device resampler, which is not built yet");
+}
+
+void SamModel::encode(int batch) {
+    DLIMG_ASSERT(batch > 0 && batch <= enc_batch_);
+    const int D = geom_.embed_dim, H = geom_.num_heads, hd = geom_.head_dim(), mlp = geom_.mlp_dim;
+    const int M = batch * kTokens;
+
+    k::GemmArgs g;
+    g.A = patches_.get(); g.lda = kPatchK; g.W = patch_.w.get(); g.ldw = kPatchK; g.bias = patch_.b.get();
+    g.resid = pos_embed_.get(); g.ldr = D; g.resid_mod = kTokens;
+    g.out_f32 = x_.get(); g.ldc32 = D; g.M = M; g.N = D; g.K = kPatchK;
+    gemm(g);
+
+    const double ln_bytes = (double)M * D * 6;
+    for (EncoderLayer const& L : layers_) {
+        timed(ST_LAYERNORM, ln_bytes, [&] {
+            k::layernorm(x_.get(), L.ln1.w.get(), L.ln1.b.get(), kLnEps, M, D, k::ACT_NONE, nullptr, xn_.get(), stream_);
+        });
+        g = k::GemmArgs{};
+        g.A = xn_.get(); g.lda = D; g.W = L.qkv.w.get(); g.ldw = D; g.bias = L.qkv.b.get();
+        g.out_h = qkv_.get(); g.ldc16 = 3 * D; g.M = M; g.N = 3 * D; g.K = D;
+        gemm(g);
+        if (L.global) {
+            const double fl = (double)batch * (4.0 * kTokens * (double)kTokens * D + 4.0 * kTokens * 64.0 * hd * H);
+            timed(ST_ATTN_GLOBAL, fl, [&] {
+                k::attention_global(qkv_.get(), L.rel_h.get(), L.rel_w.get(), att_.get(), batch, H, hd, stream_);
+            });
+        } else {
+            const double fl = (double)batch * 25.0 * (4.0 * 196.0 * 196.0 * D + 4.0 * 196.0 * 14.0 * hd * H);
+            timed(ST_ATTN_WINDOW, fl, [&] {
+                k::attention_window(qkv_.get(), L.qkv.b.get(), L.rel_h.get(), L.rel_w.get(), att_.get(), batch, H, hd,
+                                    stream_);
+            });
+        }
+        g = k::GemmArgs{};
+        g.A = att_.get(); g.lda = D; g.W = L.proj.w.get(); g.ldw = D; g.bias = L.proj.b.get();
+        g.resid = x_.get(); g.ldr = D; g.resid_mod = M; g.out_f32 = x_.get(); g.ldc32 = D; g.M = M; g.N = D; g.K = D;
+        gemm(g);
+        timed(ST_LAYERNORM, ln_bytes, [&] {
+            k::layernorm(x_.get(), L.ln2.w.get(), L.ln2.b.get(), kLnEps, M, D, k::ACT_NONE, nullptr, xn_.get(), stream_);
+        });
+        g = k::GemmArgs{};
+        g.A = xn_.get(); g.lda = D; g.W = L.fc1.w.get(); g.ldw = D; g.bias = L.fc1.b.get(); g.act = k::ACT_GELU;
+        g.out_h = hid_.get(); g.ldc16 = mlp; g.M = M; g.N = mlp; g.K = D;
+        gemm(g);
+        g = k::GemmArgs{};
+        g.A = hid_.get(); g.lda = mlp; g.W = L.fc2.w.get(); g.ldw = mlp; g.bias = L.fc2.b.get();
+        g.resid = x_.get(); g.ldr = D; g.resid_mod = M; g.out_f32 = x_.get(); g.ldc32 = D; g.M = M; g.N = D; g.K = mlp;
+        gemm(g);
+    }
+
+    // neck: 1x1 conv -> LayerNorm2d -> 3x3 conv (pad 1) -> LayerNorm2d, all channel-last
+    timed(ST_ENC_OTHER, (double)M * D * 6, [&] {
+        k::add_cast(x_.get(), nullptr, 0, (size_t)M * D, nullptr, xn_.get(), stream_);
+    });
+    g = k::GemmArgs{};
+    g.A = xn_.get(); g.lda = D; g.W = neck1_.w.get(); g.ldw = D;
+    g.out_f32 = neck_f32_.get(); g.ldc32 = kEmbedDim; g.M = M; g.N = kEmbedDim; g.K = D;
+    gemm(g);
+    timed(ST_LAYERNORM, (double)M * kEmbedDim * 6, [&] {
+        k::layernorm(neck_f32_.get(), neck_ln1_.w.get(), neck_ln1_.b.get(), kLnEps, M, kEmbedDim, k::ACT_NONE, nullptr,
+                     att_.get(), stream_);
+    });
+    timed(ST_ENC_OTHER, (double)M * kEmbedDim * 2 * 10, [&] {
+        k::im2col3x3(att_.get(), batch, kEmbedDim, hid_.get(), stream_);
+    });
+    g = k::GemmArgs{};
+    g.A = hid_.get(); g.lda = 9 * kEmbedDim; g.W = neck2_.w.get(); g.ldw = 9 * kEmbedDim;
+    g.out_f32 = neck_f32_.get(); g.ldc32 = kEmbedDim; g.M = M; g.N = kEmbedDim; g.K = 9 * kEmbedDim;
+    gemm(g);
+    timed(ST_LAYERNORM, (double)M * kEmbedDim * 8, [&] {
+        k::layernorm(neck_f32_.get(), neck_ln2_.w.get(), neck_ln2_.b.get(), kLnEps, M, kEmbedDim, k::ACT_NONE, emb_.get(),
+                     nullptr, stream_);
+    });
+}
+
+// ---------------------------------------------------------------------------------------------
+// prompt encoder + mask decoder
+
+void SamModel::reserve_decoder(int count) {
+    if (count <= dec_count_) return;
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    const size_t P = count, M = P * kTokens;
+    keys_.reserve(M * 256);
+    keys_h_.reserve(M * 256);
+    kp_h_.reserve(M * 256);
+    kq_h_.reserve(M * 256);
+    v_h_.reserve(M * 128);
+    att_img_h_.reserve(M * 128);
+    up1_f32_.reserve(M * 256);
+    up1_h_.reserve(M * 256);
+    up_.reserve(M * 16 * 32);
+    logits_.reserve(P * 4 * kLowRes * kLowRes);
+    iou_.reserve(P * 4);
+    hyper_.reserve(P * 4 * 32);
+    coords_.reserve(P * 4);
+    labels_.reserve(P * 2);
+    const size_t T = P * kDecTokens;
+    tokens_.reserve(T * 256);
+    queries_.reserve(T * 256);
+    tq_.reserve(T * 256);
+    tk_.reserve(T * 256);
+    tv_.reserve(T * 256);
+    tatt_.reserve(T * 256);
+    tmlp_.reserve(T * 2048);
+    prompt_pinned_.reserve(kPromptRing * P * 6 * sizeof(float));
+    dec_count_ = count;
+}
+
+void SamModel::decode(float const* const* emb, float const* coords, float const* labels, int count) {
+    DLIMG_ASSERT(count > 0);
+    reserve_decoder(count);
+    const int P = count, M = P * kTokens, T = P * kDecTokens;
+    hipStream_t s = stream_;
+
+    auto body = [&] {
+        // prompt -> device (through pinned memory so the copy is stream-ordered)
+        const unsigned ring = prompt_seq_++ % kPromptRing;
+        HIP_CHECK(hipEventSynchronize(prompt_done_[ring]));     // the copy issued kPromptRing decodes ago has run
+        float* pin = static_cast<float*>(prompt_pinned_.get()) + (size_t)ring * dec_count_ * 6;
+        std::memcpy(pin, coords, (size_t)P * 4 * sizeof(float));
+        std::memcpy(pin + (size_t)P * 4, labels, (size_t)P * 2 * sizeof(float));
+        HIP_CHECK(hipMemcpyAsync(coords_.get(), pin, (size_t)P * 4 * sizeof(float), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(labels_.get(), pin + (size_t)P * 4, (size_t)P * 2 * sizeof(float),
+                                 hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipEventRecord(prompt_done_[ring], s));
+        k::prompt_tokens(coords_.get(), labels_.get(), pe_gauss_.get(), pe_point_.get(), pe_not_a_point_.get(),
+                         iou_token_.get(), mask_tokens_.get(), tokens_.get(), P, s);
+        HIP_CHECK(hipMemcpyAsync(queries_.get(), tokens_.get(), (size_t)T * 256 * sizeof(float),
+                                 hipMemcpyDeviceToDevice, s));
+        // src = image_embedding + no_mask_embed (has_mask_input == 0, segmentation.cpp:43-45)
+        for (int p = 0; p < P; ++p)
+            k::add_cast(emb[p], pe_no_mask_.get(), 256, (size_t)kTokens * 256, keys_.get() + (size_t)p * kTokens * 256,
+                        keys_h_.get() + (size_t)p * kTokens * 256, s);
+
+        float* q = queries_.get();
+        float const* qpe = tokens_.get();
+        auto lin = [&](float const* X, float const* X2, LinearF const& l, float const* R, float* Y, int relu) {
+            k::token_linear(X, X2, l.w.get(), l.b.get(), R, Y, T, l.in, l.out, relu, s);
+        };
+        auto ln_tokens = [&](NormW const& n, float eps) {
+            k::layernorm(q, n.w.get(), n.b.get(), eps, T, 256, k::ACT_NONE, q, nullptr, s);
+        };
+        auto img_gemm = [&](half_t const* A, int K, LinearH const& l, half_t* out_h, int ldc) {
+            k::GemmArgs g;
+            g.A = A; g.lda = K; g.W = l.w.get(); g.ldw = K; g.bias = l.b.get();
+            g.out_h = out_h; g.ldc16 = ldc; g.M = M; g.N = l.out; g.K = K;
+            k::gemm(g, s);
+        };
+        // tokens attend to the image: K = kq_h[:, :128] (or final K), V = v_h
+        auto token_to_image = [&](LinearF const& wq, LinearF const& wo, half_t const* K, int ldk) {
+            lin(q, qpe, wq, nullptr, tq_.get(), 0);
+            k::token_to_image_attention(tq_.get(), K, ldk, v_h_.get(), 128, tatt_.get(), P, s);
+            lin(tatt_.get(), nullptr, wo, q, q, 0);
+        };
+
+        for (int i = 0; i < 2; ++i) {
+            DecoderLayer const& L = dec_[i];
+            // (1) self attention of the tokens; the first layer has no PE and no residual
+            float const* pe = i == 0 ? nullptr : qpe;
+            lin(q, pe, L.self_attn.q, nullptr, tq_.get(), 0);
+            lin(q, pe, L.self_attn.k, nullptr, tk_.get(), 0);
+            lin(q, nullptr, L.self_attn.v, nullptr, tv_.get(), 0);
+            k::token_self_attention(tq_.get(), tk_.get(), tv_.get(), tatt_.get(), P, s);
+            lin(tatt_.get(), nullptr, L.self_attn.o, i == 0 ? nullptr : q, q, 0);
+            ln_tokens(L.ln1, kLnEps);
+            // (2) tokens -> image
+            k::add_cast(keys_.get(), image_pe_.get(), (size_t)kTokens * 256, (size_t)M * 256, nullptr, kp_h_.get(), s);
+            img_gemm(kp_h_.get(), 256, L.img_kq, kq_h_.get(), 256);
+            img_gemm(keys_h_.get(), 256, L.img_v, v_h_.get(), 128);
+            token_to_image(L.t2i_q, L.t2i_o, kq_h_.get(), 256);
+            ln_tokens(L.ln2, kLnEps);
+            // (3) token MLP
+            lin(q, nullptr, L.mlp1, nullptr, tmlp_.get(), 1);
+            lin(tmlp_.get(), nullptr, L.mlp2, q, q, 0);
+            ln_tokens(L.ln3, kLnEps);
+            // (4) image -> tokens
+            lin(q, qpe, L.i2t_k, nullptr, tk_.get(), 0);
+            lin(q, nullptr, L.i2t_v, nullptr, tv_.get(), 0);
+            k::image_to_token_attention(kq_h_.get() + 128, 256, tk_.get(), tv_.get(), att_img_h_.get(), P, s);
+            k::GemmArgs g;
+            g.A = att_img_h_.get(); g.lda = 128; g.W = L.i2t_o.w.get(); g.ldw = 128; g.bias = L.i2t_o.b.get();
+            g.resid = keys_.get(); g.ldr = 256; g.resid_mod = M; g.out_f32 = keys_.get(); g.ldc32 = 256;
+            g.M = M; g.N = 256; g.K = 128;
+            k::gemm(g, s);
+            k::layernorm(keys_.get(), L.ln4.w.get(), L.ln4.b.get(), kLnEps, M, 256, k::ACT_NONE, keys_.get(),
+                         keys_h_.get(), s);
+        }
+        // final token -> image attention
+        k::add_cast(keys_.get(), image_pe_.get(), (size_t)kTokens * 256, (size_t)M * 256, nullptr, kp_h_.get(), s);
+        img_gemm(kp_h_.get(), 256, final_k_, kq_h_.get(), 128);
+        img_gemm(keys_h_.get(), 256, final_v_, v_h_.get(), 128);
+        token_to_image(final_q_, final_o_, kq_h_.get(), 128);
+        ln_tokens(ln_final_, 1e-5f);
+
+        // upscaling: ConvT(256->64) -> LN2d -> GELU -> ConvT(64->32) -> GELU, sub-pixels kept in quad order
+        k::GemmArgs g;
+        g.A = keys_h_.get(); g.lda = 256; g.W = up1_.w.get(); g.ldw = 256; g.bias = up1_.b.get();
+        g.out_f32 = up1_f32_.get(); g.ldc32 = 256; g.M = M; g.N = 256; g.K = 256;
+        k::gemm(g, s);
+        k::layernorm(up1_f32_.get(), up_ln_.w.get(), up_ln_.b.get(), kLnEps, M * 4, 64, k::ACT_GELU, nullptr,
+                     up1_h_.get(), s);
+        g = k::GemmArgs{};
+        g.A = up1_h_.get(); g.lda = 64; g.W = up2_.w.get(); g.ldw = 64; g.bias = up2_.b.get(); g.act = k::ACT_GELU;
+        g.out_f32 = up_.get(); g.ldc32 = 128; g.M = M * 4; g.N = 128; g.K = 64;
+        k::gemm(g, s);
+
+        k::HeadWeights hw;
+        for (int m = 0; m < 5; ++m)
+            for (int j = 0; j < 3; ++j) {
+                hw.w[m][j] = heads_[m][j].w.get();
+                hw.b[m][j] = heads_[m][j].b.get();
+            }
+        k::output_heads(q, hw, hyper_.get(), iou_.get(), P, s);
+        k::mask_logits(up_.get(), hyper_.get(), logits_.get(), P, s);
+    };
+    timed(ST_DECODER, 3.62e9 * P, body);
+}
+
+void SamModel::masks_on_device(k::PostJob const* jobs, int count) {
+    if (count <= 0) return;
+    double bytes = 0;
+    for (int i = 0; i < count; ++i) bytes += (double)kLowRes * kLowRes * 4 + (double)jobs[i].out_w * jobs[i].out_h;
+    timed(ST_POST, bytes, [&] { k::postprocess_masks(jobs, count, stream_); });
+}
+
+void SamModel::masks_to_host(k::PostJob const* jobs, int count) {
+    if (count <= 0) return;
+    size_t total = 0;
+    for (int i = 0; i < count; ++i) total += ((size_t)jobs[i].out_w * jobs[i].out_h + 255) / 256 * 256;
+    mask_dev_.reserve(total);
+    mask_pinned_.reserve(total);
+    std::vector<k::PostJob> dev_jobs(jobs, jobs + count);
+    size_t off = 0;
+    double bytes = 0;
+    for (int i = 0; i < count; ++i) {
+        dev_jobs[i].dst = mask_dev_.get() + off;
+        off += ((size_t)jobs[i].out_w * jobs[i].out_h + 255) / 256 * 256;
+        bytes += (double)kLowRes * kLowRes * 4 + (double)jobs[i].out_w * jobs[i].out_h;
+    }
+    timed(ST_POST, bytes, [&] { k::postprocess_masks(dev_jobs.data(), count, stream_); });
+    HIP_CHECK(hipMemcpyAsync(mask_pinned_.get(), mask_dev_.get(), total, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    off = 0;
+    for (int i = 0; i < count; ++i) {
+        const size_t n = (size_t)jobs[i].out_w * jobs[i].out_h;
+        std::memcpy(jobs[i].dst, static_cast<uint8_t*>(mask_pinned_.get()) + off, n);
+        off += (n + 255) / 256 * 256;
+    }
+}
+
+}  // namespace dlimg

@@ -1,0 +1,169 @@
+// SamModel: device-resident weights + the HIP executor for the Segment-Anything path.
+// Takes the place of the reference's SegmentAnythingModel, i.e. of its three onnxruntime Sessions
+// (/root/reference/src/segmentation.hpp:17-32, /root/reference/src/session.cpp:57-136):
+//   encode()  == image_embedder.run(...)            (segmentation.cpp:126-128)
+//   decode()  == single/multi_mask_decoder()(...)   (segmentation.cpp:154-158)
+// Tensors stay in HBM between the two; nothing round-trips through host memory as it does in the
+// reference (environment.cpp:142 binds every Ort::Value to CPU memory).
+#pragma once
+
+#include "common.hpp"
+#include "kernels/kernels.hpp"
+#include "weights.hpp"
+
+#include <array>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace dlimg {
+
+constexpr int kTokens = 4096;       // 64 x 64 embedding grid
+constexpr int kEmbedDim = 256;      // channels of the image embedding
+constexpr int kPatchK = 768;        // 3 * 16 * 16
+constexpr int kImageSize = 1024;    // /root/reference/src/segmentation.cpp:17
+constexpr int kDecTokens = 7;
+constexpr int kLowRes = 256;
+
+struct LinearH {                    // f16 weight for MFMA GEMMs, fp32 bias
+    DeviceBuffer<half_t> w;
+    DeviceBuffer<float> b;
+    int out = 0, in = 0;
+    bool has_bias = false;
+};
+struct LinearF {                    // fp32 weight for the token-side kernels
+    DeviceBuffer<float> w, b;
+    int out = 0, in = 0;
+};
+struct NormW { DeviceBuffer<float> w, b; };
+
+struct EncoderLayer {
+    bool global = false;
+    NormW ln1, ln2;
+    LinearH qkv, proj, fc1, fc2;
+    DeviceBuffer<float> rel_h, rel_w;
+};
+
+struct TokenAttention { LinearF q, k, v, o; };
+
+struct DecoderLayer {
+    TokenAttention self_attn;
+    NormW ln1, ln2, ln3, ln4;
+    LinearF t2i_q, t2i_o;            // token side of token->image attention
+    LinearH img_kq;                  // [t2i.k ; i2t.q] fused: both consume (keys + pos)
+    LinearH img_v;                   // t2i.v on keys
+    LinearF mlp1, mlp2;
+    LinearF i2t_k, i2t_v;            // token side of image->token attention
+    LinearH i2t_o;                   // image side output projection (128 -> 256)
+};
+
+// Stage clock for roofline accounting (HIP events on the executor's own stream).
+enum Stage { ST_PRE = 0, ST_GEMM, ST_LAYERNORM, ST_ATTN_WINDOW, ST_ATTN_GLOBAL, ST_ENC_OTHER, ST_DECODER, ST_POST, ST_COUNT };
+
+struct StageStats {
+    double ms[ST_COUNT] = {0};
+    double work[ST_COUNT] = {0};     // algorithmic FLOPs (MFMA stages) or bytes (HBM stages)
+    long launches[ST_COUNT] = {0};
+};
+
+class SamModel {
+  public:
+    SamModel(std::string const& weight_path, int device);
+    ~SamModel();
+    SamModel(SamModel const&) = delete;
+    SamModel& operator=(SamModel const&) = delete;
+
+    SamGeometry const& geometry() const { return geom_; }
+    hipStream_t stream() const { return stream_; }
+    std::mutex& mutex() { return mutex_; }
+    int device() const { return device_; }
+
+    // All methods below require mutex() to be held by the caller.
+
+    // Host image (already at its encoder resolution: longest side 1024) -> slot `slot` of the patch
+    // matrix.  Copies through pinned staging and runs the pre-processing kernel.
+    void upload_image(int slot, int batch, uint8_t const* pixels, int w, int h, int stride, int channels);
+    // Host image whose longest side is not 1024: uploaded at its own size and resampled on the device to
+    // rw x rh (reference: dlimg::resize through stb, /root/reference/src/image.cpp:37-51).
+    void upload_and_resize_image(int slot, int batch, uint8_t const* pixels, int w, int h, int stride, int channels,
+                                 int rw, int rh);
+    // Device-resident image variant (used by the batch benchmark so PCIe is outside the timed region).
+    void preprocess_device_image(int slot, int batch, uint8_t const* dev_pixels, int w, int h, int stride, int channels);
+    // Runs the encoder on `batch` uploaded images; embeddings [batch][4096][256] fp32 in embeddings().
+    void encode(int batch);
+    float const* embeddings() const { return emb_.get(); }
+
+    // Decoder for `count` prompts. emb[i]: device embedding of prompt i's image; coords [count][2][2],
+    // labels [count][2] host arrays. Results stay on device: logits() [count][4][256][256], iou() [count][4].
+    void decode(float const* const* emb, float const* coords, float const* labels, int count);
+    float const* logits() const { return logits_.get(); }
+    float const* iou() const { return iou_.get(); }
+
+    // Post-process to host masks. jobs[i].dst must be a HOST pointer of out_w*out_h bytes; the kernel
+    // writes a device staging buffer which is then copied out.
+    void masks_to_host(k::PostJob const* jobs, int count);
+    // Same kernel, but jobs[i].dst are DEVICE pointers and nothing is copied or waited for.
+    void masks_on_device(k::PostJob const* jobs, int count);
+
+    void synchronize();
+
+    void set_profiling(bool on);
+    StageStats take_stats();
+
+  private:
+    void reserve_encoder(int batch);
+    void reserve_decoder(int count);
+    void gemm(k::GemmArgs const& a);
+    template <typename F> void timed(Stage st, double work, F&& launch);
+    void flush_events();
+
+    int device_ = 0;
+    hipStream_t stream_ = nullptr;
+    std::mutex mutex_;
+    SamGeometry geom_;
+
+    // ---- weights
+    LinearH patch_;                       // [D, 768] + bias
+    DeviceBuffer<float> pos_embed_;       // [4096, D]
+    std::vector<EncoderLayer> layers_;
+    LinearH neck1_, neck2_;               // 1x1 conv [256, D]; 3x3 conv as [256, 9*256] (tap-major columns)
+    NormW neck_ln1_, neck_ln2_;
+    DeviceBuffer<float> pe_gauss_, pe_point_, pe_not_a_point_, pe_no_mask_;
+    DeviceBuffer<float> image_pe_;        // [4096, 256] dense positional encoding (constant)
+    DeviceBuffer<float> iou_token_, mask_tokens_;
+    std::array<DecoderLayer, 2> dec_;
+    LinearF final_q_, final_o_;
+    LinearH final_k_, final_v_;
+    NormW ln_final_;
+    LinearH up1_, up2_;                   // transposed-conv weights as GEMM operands (sub-pixel-major rows)
+    NormW up_ln_;
+    std::array<std::array<LinearF, 3>, 5> heads_;   // 4 hyper MLPs + IoU head
+
+    // ---- encoder workspace (sized for enc_batch_ images)
+    int enc_batch_ = 0;
+    DeviceBuffer<uint8_t> img_dev_;
+    PinnedBuffer img_pinned_;
+    hipEvent_t upload_done_ = nullptr;    // guards re-use of img_pinned_ by the next upload
+    DeviceBuffer<half_t> patches_, xn_, qkv_, att_, hid_;
+    DeviceBuffer<float> x_, neck_f32_, emb_;
+
+    // ---- decoder workspace (sized for dec_count_ prompts)
+    int dec_count_ = 0;
+    DeviceBuffer<float> keys_, up1_f32_, up_, logits_, iou_, hyper_;
+    DeviceBuffer<half_t> keys_h_, kp_h_, kq_h_, v_h_, att_img_h_, up1_h_;
+    DeviceBuffer<float> coords_, labels_, tokens_, queries_, tq_, tk_, tv_, tatt_, tmlp_;
+    DeviceBuffer<uint8_t> mask_dev_;
+    PinnedBuffer mask_pinned_, prompt_pinned_;
+    static constexpr int kPromptRing = 8;           // pinned prompt staging slots, re-used round robin
+    hipEvent_t prompt_done_[kPromptRing] = {};
+    unsigned prompt_seq_ = 0;
+
+    // ---- profiling
+    bool profiling_ = false;
+    struct Pending { hipEvent_t a, b; Stage st; double work; };
+    std::vector<Pending> pending_;
+    std::vector<hipEvent_t> event_pool_;
+    StageStats stats_;
+};
+
+}  // namespace dlimg

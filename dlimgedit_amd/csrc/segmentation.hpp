@@ -1,0 +1,70 @@
+// SegmentationImpl: per-image state of the Segment-Anything path.
+// Counterpart of /root/reference/src/segmentation.{hpp,cpp} (SegmentationImpl, ResizeLongestSide):
+// same life cycle (process once, query many masks), but the embedding lives in HBM.
+#pragma once
+
+#include "common.hpp"
+#include "environment.hpp"
+
+#include <dlimgedit/dlimgedit.h>
+
+namespace dlimg {
+
+struct Extent { int width = 0, height = 0; };
+struct Point { int x = 0, y = 0; };
+struct Region { Point top_left, bottom_right; };
+
+int channel_bytes(int channels);          // 4 for bgra/argb (reference: dlimgedit.impl.hpp:15)
+int scale_coord(int coord, float scale);  // reference: segmentation.cpp:26
+
+// Longest-side-to-1024 geometry (reference: segmentation.cpp:58-74).  The pixel resampling itself is
+// a device kernel here; this struct only keeps the numbers needed later for prompts and masks.
+struct ResizeLongestSide {
+    Extent original;
+    Extent resized;
+    float scale = 1.f;
+
+    explicit ResizeLongestSide(int max_side = kImageSize) : max_side_(max_side) {}
+    void set(Extent image);
+    Point transform(Point p) const { return Point{scale_coord(p.x, scale), scale_coord(p.y, scale)}; }
+
+  private:
+    int max_side_;
+};
+
+// Packs one prompt the way SegmentationImpl::compute_mask does (reference: segmentation.cpp:135-152).
+void pack_prompt(ResizeLongestSide const& rs, Point const* point, Region const* region, float coords[4],
+                 float labels[2]);
+
+class SegmentationImpl {
+  public:
+    explicit SegmentationImpl(EnvironmentImpl& env);
+
+    void process(dlimg_ImageView const& image);
+    // Batched variant: segs[i] receives the embedding of images[i].
+    static void process_batch(EnvironmentImpl& env, SegmentationImpl* const* segs, dlimg_ImageView const* images,
+                              int count);
+
+    void compute_mask(Point const* point, Region const* region, uint8_t* const out_masks[3],
+                      float out_accuracy[3]) const;
+    static void compute_mask_batch(SegmentationImpl const* const* segs, int count, int const* points,
+                                   int const* regions, uint8_t* const* out_masks);
+
+    Extent extent() const { return image_size_.original; }
+    ResizeLongestSide const& geometry() const { return image_size_; }
+    float const* embedding() const { return embedding_.get(); }
+    SamModel& model() const { return model_; }
+    void set_geometry(Extent e) { image_size_.set(e); }
+    float* embedding_storage();
+
+  private:
+    EnvironmentImpl& env_;
+    SamModel& model_;
+    ResizeLongestSide image_size_;
+    DeviceBuffer<float> embedding_;     // [4096][256] fp32, resident
+};
+
+// Validates an image view the way the entry points need it; throws on nonsense.
+void check_image(dlimg_ImageView const& image);
+
+}  // namespace dlimg

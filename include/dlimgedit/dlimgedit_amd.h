@@ -1,0 +1,85 @@
+/* dlimgedit_amd.h -- extension entry points of the MI355X build (plain C, exported next to
+ * dlimg_init from the same shared library).  None of these exist in the reference; they serve
+ *   (1) the throughput benchmark: device-resident inputs/outputs, asynchronous steps, stage clocks;
+ *   (2) the parity tests: intermediate results (embedding, mask logits) and single-kernel hooks so
+ *       every HIP kernel can be compared with the CPU oracle in isolation.
+ * All functions return 0 on success and non-zero on failure with the message available through
+ * dlimg_init()->last_error() unless stated otherwise.  f16 tensors cross the boundary as uint16_t
+ * bit patterns (IEEE binary16).
+ */
+#ifndef DLIMGEDIT_AMD_H_
+#define DLIMGEDIT_AMD_H_
+
+#include "dlimgedit.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Number of usable HIP devices (0 if the runtime cannot be initialised).  Never fails. */
+DLIMG_API int dlimg_amd_device_count(void);
+
+/* ---- model facts ---------------------------------------------------------------------------- */
+/* out[0..3] = embed_dim, depth, num_heads, mlp_dim of the SAM encoder loaded by `env` (loads it). */
+DLIMG_API int dlimg_amd_model_geometry(dlimg_Environment env, int* out);
+
+/* ---- intermediates for parity tests (Segmentation::process / compute_mask internals) -------- */
+/* Copies the cached image embedding, token-major [4096][256] fp32 (reference layout 1x256x64x64 is
+ * its transpose), replacing what the reference keeps in SegmentationImpl::image_embedding_
+ * (reference: src/segmentation.hpp:61). */
+DLIMG_API int dlimg_amd_get_embedding(dlimg_Segmentation seg, float* out);
+/* Runs prompt encoder + mask decoder for one prompt and returns the decoder's raw outputs:
+ * out_logits [4][256][256] (low_res_masks), out_iou [4] (iou_predictions). */
+DLIMG_API int dlimg_amd_get_logits(dlimg_Segmentation seg, int const* point, int const* region, float* out_logits,
+                                   float* out_iou);
+
+/* ---- benchmark path: everything device-resident, stream-ordered, no host synchronisation ----- */
+/* Device memory helpers (hipMalloc/hipFree/hipMemcpy on the environment's device). */
+DLIMG_API int dlimg_amd_device_alloc(dlimg_Environment env, size_t bytes, void** out_ptr);
+DLIMG_API int dlimg_amd_device_free(dlimg_Environment env, void* ptr);
+DLIMG_API int dlimg_amd_copy_to_device(dlimg_Environment env, void* dst_dev, void const* src_host, size_t bytes);
+DLIMG_API int dlimg_amd_copy_to_host(dlimg_Environment env, void* dst_host, void const* src_dev, size_t bytes);
+/* One pass of the hot path over `count` images already in HBM: pre-process, encode (one batched
+ * pass), decode one point prompt per image (single-mask mode) and write the 0/255 masks to
+ * dev_masks[i] (width*height bytes each, device memory).  Views carry DEVICE pixel pointers.
+ * points: count x {x,y}.  Returns after enqueueing; call dlimg_amd_synchronize to wait. */
+DLIMG_API int dlimg_amd_encode_and_mask(dlimg_Environment env, dlimg_ImageView const* dev_images, int count,
+                                        int const* points, uint8_t* const* dev_masks);
+/* Encode only / decode only variants of the above, for per-stage rates. */
+DLIMG_API int dlimg_amd_encode_only(dlimg_Environment env, dlimg_ImageView const* dev_images, int count);
+DLIMG_API int dlimg_amd_synchronize(dlimg_Environment env);
+
+/* ---- stage clocks (HIP events on the executor's stream) -------------------------------------- */
+#define DLIMG_AMD_STAGE_COUNT 8
+/* stage ids: 0 pre, 1 gemm (all MFMA GEMMs of the encoder), 2 layernorm, 3 attention_window,
+ * 4 attention_global, 5 encoder_other, 6 decoder (whole prompt+mask decoder), 7 post */
+DLIMG_API int dlimg_amd_set_profiling(dlimg_Environment env, int enabled);
+/* Accumulated since the previous call: milliseconds, algorithmic work (FLOPs for stages 1,3,4,6;
+ * bytes for the others) and launch counts; arrays of DLIMG_AMD_STAGE_COUNT. Resets the counters. */
+DLIMG_API int dlimg_amd_take_stage_stats(dlimg_Environment env, double* out_ms, double* out_work, long* out_launches);
+
+/* ---- single-kernel hooks (host buffers in and out; device memory handled inside) ------------- */
+/* K1: pixels -> patch matrix [4096][768] f16. */
+DLIMG_API int dlimg_amd_test_preprocess(uint8_t const* pixels, int width, int height, int stride, int channels,
+                                        uint16_t* out_patches);
+/* K16: planes [n_planes][256][256] fp32; iou (4 floats) non-null selects the plane as the single-mask
+ * decoder does, otherwise plane 0 is used.  out_mask: out_w*out_h bytes. */
+DLIMG_API int dlimg_amd_test_postprocess(float const* planes, int n_planes, float const* iou, int out_w, int out_h,
+                                         uint8_t* out_mask);
+/* C = epilogue(A[M,K] . W[N,K]^T): bias[N], resid[resid_rows][N] (row m % resid_rows), act 0/1(GELU). */
+DLIMG_API int dlimg_amd_test_gemm(int M, int N, int K, uint16_t const* A, uint16_t const* W, float const* bias,
+                                  float const* resid, int resid_rows, int act, float* out_f32, uint16_t* out_f16);
+DLIMG_API int dlimg_amd_test_layernorm(float const* x, float const* w, float const* b, float eps, int rows, int dim,
+                                       int act, float* out_f32, uint16_t* out_f16);
+/* Encoder attention on qkv [B*4096][3*heads*hd] f16 -> out [B*4096][heads*hd] f16.
+ * global != 0: rel tables are [127][hd]; else windowed 14x14 with [27][hd] tables and qkv_bias [3*D]. */
+DLIMG_API int dlimg_amd_test_attention(int global, uint16_t const* qkv, float const* qkv_bias, float const* rel_h,
+                                       float const* rel_w, int batch, int heads, int hd, uint16_t* out);
+/* Times `iters` launches of the GEMM on device-resident random operands; returns average ms per launch. */
+DLIMG_API int dlimg_amd_bench_gemm(int M, int N, int K, int act, int iters, double* out_ms);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* DLIMGEDIT_AMD_H_ */

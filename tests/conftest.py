@@ -1,0 +1,58 @@
+"""Shared fixtures.  `-m "not gpu"` runs on the CPU-only build box; `-m gpu` needs one MI355X."""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def synthetic_image(seed: int, width: int = 1024, height: int = 1024, channels: int = 4) -> np.ndarray:
+    """SURVEY.md §8(d) synthetic input: low-frequency sinusoids + noise, alpha 255."""
+    rng = np.random.default_rng(1000 + seed)
+    yy, xx = np.mgrid[0:height, 0:width].astype(np.float32)
+    img = np.zeros((height, width, channels), np.uint8)
+    for c in range(min(3, channels)):
+        f = np.full((height, width), 128.0, np.float32)
+        for _ in range(8):
+            fx, fy = rng.uniform(0.002, 0.02, 2)
+            ph = rng.uniform(0, 6.28)
+            f += 14.0 * np.sin(xx * fx + yy * fy + ph).astype(np.float32)
+        f += rng.uniform(-8, 8, (height, width)).astype(np.float32)
+        img[:, :, c] = np.clip(f, 0, 255).astype(np.uint8)
+    if channels == 4:
+        img[:, :, 3] = 255
+    return img
+
+
+@pytest.fixture(scope="session")
+def model_dirs(tmp_path_factory):
+    """variant -> (model directory with seeded synthetic weights, params dict, config); built lazily."""
+    from dlimgedit_amd import weights as W
+    from dlimgedit_amd.sam_config import get_config
+    cache = {}
+
+    def get(variant: str, seed: int = 7):
+        key = (variant, seed)
+        if key not in cache:
+            cfg = get_config(variant)
+            d = tmp_path_factory.mktemp(f"models_{variant}_{seed}")
+            params = W.write_synthetic_model_dir(d, cfg, seed)
+            cache[key] = (str(d), params, cfg)
+        return cache[key]
+
+    return get
+
+
+def iou(a: np.ndarray, b: np.ndarray) -> float:
+    a, b = a > 0, b > 0
+    union = np.logical_or(a, b).sum()
+    return 1.0 if union == 0 else float(np.logical_and(a, b).sum()) / float(union)

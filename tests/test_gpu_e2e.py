@@ -1,0 +1,161 @@
+"""End-to-end parity of the drop-in path (Segmentation.process / compute_mask through the C-ABI
+table) against the CPU oracle on the same seeded weights, inputs and prompts."""
+import numpy as np
+import pytest
+
+from conftest import iou, synthetic_image
+
+pytestmark = pytest.mark.gpu
+
+# Tolerances (fp32 oracle vs f16-operand MFMA path, fp32 accumulate / softmax / LayerNorm):
+EMB_TOL = 0.05        # max-abs error of the image embedding (values are LayerNorm'ed, |x| ~ 4)
+LOGIT_TOL = 0.15      # max-abs error of the low-res mask logits (std ~ 1.3)
+IOU_BAR = 0.98        # BASELINE.json: mask IoU vs CPU reference
+
+
+@pytest.fixture(scope="module")
+def api():
+    from dlimgedit_amd import api
+    return api
+
+
+@pytest.fixture(scope="module")
+def session(api, model_dirs):
+    """(env, params, cfg, image, segmentation, oracle segmentation) for the reduced variant."""
+    from oracle import sam_oracle as O
+    mdir, params, cfg = model_dirs("vit_test")
+    env = api.Environment(api.Options(api.Backend.gpu, mdir))
+    img = synthetic_image(0)
+    seg = api.Segmentation.process(api.ImageView(img, api.Channels.rgba), env)
+    ora = O.OracleSegmentation(params, cfg).process(img, O.CH_RGBA)
+    return env, params, cfg, img, seg, ora
+
+
+def test_backend_gate(api):
+    assert api.Environment.is_supported(api.Backend.gpu)
+    assert not api.Environment.is_supported(api.Backend.cpu)
+
+
+def test_model_geometry(api, session):
+    env, _, cfg, *_ = session
+    assert api.ext.model_geometry(env) == (cfg.embed_dim, cfg.depth, cfg.num_heads, cfg.mlp_dim)
+
+
+def test_extent(api, session):
+    seg = session[4]
+    assert seg.extent() == api.Extent(1024, 1024)
+
+
+def test_embedding_parity(api, session):
+    *_, seg, ora = session
+    emb = api.ext.get_embedding(seg)
+    err = np.abs(emb - ora.embedding).max()
+    assert err < EMB_TOL, err
+
+
+@pytest.mark.parametrize("prompt", ["point", "region"])
+def test_logits_parity(api, session, prompt):
+    *_, seg, ora = session
+    if prompt == "point":
+        got, got_iou = api.ext.get_logits(seg, point=api.Point(512, 512))
+        want, want_iou = ora.logits(point=(512, 512))
+    else:
+        r = api.Region(api.Point(256, 256), api.Point(768, 768))
+        got, got_iou = api.ext.get_logits(seg, region=r)
+        want, want_iou = ora.logits(region=(256, 256, 768, 768))
+    assert np.abs(got - want).max() < LOGIT_TOL, np.abs(got - want).max()
+    assert np.abs(got_iou - want_iou).max() < 0.05
+
+
+def test_point_mask_iou(api, session):
+    *_, seg, ora = session
+    got = seg.compute_mask(api.Point(512, 512))
+    want = ora.compute_mask(point=(512, 512))
+    assert got.shape == (1024, 1024) and set(np.unique(got)) <= {0, 255}
+    assert iou(got, want) >= IOU_BAR, iou(got, want)
+
+
+def test_region_mask_iou(api, session):
+    *_, seg, ora = session
+    got = seg.compute_mask(api.Region(api.Point(256, 256), api.Point(768, 768)))
+    want = ora.compute_mask(region=(256, 256, 768, 768))
+    assert iou(got, want) >= IOU_BAR, iou(got, want)
+
+
+def test_multi_mask_mode(api, session):
+    """compute_masks: decoder outputs 1..3 with their predicted IoU (reference segmentation.cpp:167-172)."""
+    *_, seg, ora = session
+    got = seg.compute_masks(api.Point(300, 700))
+    want_masks, want_acc = ora.compute_masks((300, 700))
+    for g, wm, wa in zip(got, want_masks, want_acc):
+        assert iou(g.image, wm) >= IOU_BAR
+        assert abs(g.accuracy - wa) < 0.05
+
+
+def test_mask_is_bit_exact_given_logits(api, session):
+    """Post stage in isolation: feed the GPU's own logits to the oracle's post-processing."""
+    from oracle import sam_oracle as O
+    *_, seg, _ = session
+    logits, iou_pred = api.ext.get_logits(seg, point=api.Point(512, 512))
+    best = O.select_single(iou_pred, 2)
+    want = O.write_mask_image(O.postprocess_logits(logits[best], (1024, 1024))[None, None], 0, (1024, 1024))
+    got = seg.compute_mask(api.Point(512, 512))
+    assert np.array_equal(got, want)
+
+
+def test_repeated_queries_are_deterministic(api, session):
+    *_, seg, _ = session
+    a = seg.compute_mask(api.Point(100, 900))
+    b = seg.compute_mask(api.Point(100, 900))
+    assert np.array_equal(a, b)
+
+
+def test_batch_entry_points(api, session):
+    """process_images_for_segmentation / get_segmentation_masks equal the one-at-a-time calls."""
+    env, *_ = session
+    imgs = [synthetic_image(i) for i in (1, 2, 3)]
+    views = [api.ImageView(i, api.Channels.rgba) for i in imgs]
+    segs = api.Segmentation.process_batch(views, env)
+    assert len(segs) == 3
+    single = [api.Segmentation.process(v, env) for v in views]
+    pts = [api.Point(512, 512), api.Point(200, 300), api.Point(900, 100)]
+    batch_masks = api.Segmentation.compute_mask_batch(segs, points=pts)
+    for sb, ss, p, mb in zip(segs, single, pts, batch_masks):
+        assert np.array_equal(api.ext.get_embedding(sb), api.ext.get_embedding(ss))
+        assert np.array_equal(mb, ss.compute_mask(p))
+
+
+def test_channel_orders_end_to_end(api, session):
+    """bgra / argb inputs that describe the same picture give the same embedding."""
+    env, _, _, img, seg, _ = session
+    ref = api.ext.get_embedding(seg)
+    bgra = np.ascontiguousarray(img[:, :, [2, 1, 0, 3]])
+    argb = np.ascontiguousarray(img[:, :, [3, 0, 1, 2]])
+    for arr, ch in ((bgra, api.Channels.bgra), (argb, api.Channels.argb)):
+        s = api.Segmentation.process(api.ImageView(arr, ch), env)
+        assert np.array_equal(api.ext.get_embedding(s), ref)
+
+
+def test_head_dim_80_variant(api, model_dirs):
+    """ViT-H's head size (80) through the whole path on the reduced variant."""
+    from oracle import sam_oracle as O
+    mdir, params, cfg = model_dirs("vit_test80")
+    env = api.Environment(api.Options(api.Backend.gpu, mdir))
+    img = synthetic_image(4)
+    seg = api.Segmentation.process(api.ImageView(img, api.Channels.rgba), env)
+    ora = O.OracleSegmentation(params, cfg).process(img, O.CH_RGBA)
+    assert np.abs(api.ext.get_embedding(seg) - ora.embedding).max() < EMB_TOL
+    assert iou(seg.compute_mask(api.Point(512, 512)), ora.compute_mask(point=(512, 512))) >= IOU_BAR
+
+
+def test_error_paths(api, session, tmp_path):
+    env, *_ = session
+    with pytest.raises(api.Error, match="does not exist"):
+        api.Environment(api.Options(api.Backend.gpu, str(tmp_path / "nope")))
+    with pytest.raises(api.Error, match="CPU backend"):
+        api.Environment(api.Options(api.Backend.cpu, str(tmp_path)))
+    empty = api.Environment(api.Options(api.Backend.gpu, str(tmp_path)))
+    with pytest.raises(api.Error, match="Could not find model 'segmentation/sam_vit_b.dlw'"):
+        api.Segmentation.process(api.ImageView(synthetic_image(0), api.Channels.rgba), empty)
+    with pytest.raises(api.Error, match="not part of the MI355X build"):
+        api.segment_objects(api.ImageView(synthetic_image(0), api.Channels.rgba), env)

@@ -1,0 +1,245 @@
+"""Kernel-level parity: every HIP kernel against the CPU oracle on seeded inputs, through the C-ABI
+test hooks of include/dlimgedit/dlimgedit_amd.h.  Bit-exact for the byte/threshold kernels;
+stated tolerances for f16-operand MFMA kernels (fp32 accumulate)."""
+import numpy as np
+import pytest
+
+from conftest import synthetic_image
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ext():
+    from dlimgedit_amd import api
+    assert api.ext.device_count() >= 1, "no HIP device visible"
+    assert api.Environment.is_supported(api.Backend.gpu), "GPU backend must be supported on the GPU box"
+    return api.ext
+
+
+def _oracle():
+    from oracle import sam_oracle as O
+    return O
+
+
+# --------------------------------------------------------------------------------------------- K1
+
+@pytest.mark.parametrize("channels,nbytes", [(4, 4), (5, 4), (6, 4), (3, 3), (1, 1)])
+def test_preprocess_bit_exact(ext, channels, nbytes):
+    """create_image_tensor KAT channel orders (reference test_segmentation.cpp:59-83) at full size:
+    HIP output must equal f16(oracle fp32) bit for bit."""
+    from dlimgedit_amd import api
+    O = _oracle()
+    img = synthetic_image(3, channels=4)
+    if nbytes == 3:
+        img = np.ascontiguousarray(img[:, :, :3])
+    elif nbytes == 1:
+        img = np.ascontiguousarray(img[:, :, :1])
+    got = ext.test_preprocess(img, api.Channels(channels))
+    want = O.patchify(O.preprocess(O.create_image_tensor(img, channels))).astype(np.float16)
+    assert got.shape == want.shape
+    assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
+
+
+@pytest.mark.parametrize("w,h", [(1024, 683), (683, 1024), (1024, 1), (37, 1024)])
+def test_preprocess_padding_and_ragged(ext, w, h):
+    """Non-square inputs: bottom/right region is zero in normalised space (graph-internal padding)."""
+    from dlimgedit_amd import api
+    O = _oracle()
+    img = synthetic_image(5, width=w, height=h, channels=4)
+    got = ext.test_preprocess(img, api.Channels.rgba)
+    want = O.patchify(O.preprocess(O.create_image_tensor(img, 4))).astype(np.float16)
+    assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
+
+
+def test_preprocess_honours_stride(ext):
+    """A 1024-wide view into a wider buffer: rows are taken `stride` bytes apart."""
+    from dlimgedit_amd import api
+    O = _oracle()
+    full = synthetic_image(9, width=1100, height=1024, channels=4)
+    out = np.empty((4096, 768), dtype=np.float16)
+    rc = api.ext._l().dlimg_amd_test_preprocess(full.ctypes.data, 1024, 1024, 1100 * 4, 4, out.ctypes.data)
+    assert rc == 0
+    want = O.patchify(O.preprocess(O.create_image_tensor(np.ascontiguousarray(full[:, :1024]), 4))).astype(np.float16)
+    assert np.array_equal(out.view(np.uint16), want.view(np.uint16))
+
+
+# -------------------------------------------------------------------------------------------- K16
+
+def _planes(seed, n=4):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:256, 0:256].astype(np.float32)
+    out = []
+    for i in range(n):
+        f = np.sin(xx * rng.uniform(0.02, 0.2) + rng.uniform(0, 6)) * np.cos(yy * rng.uniform(0.02, 0.2))
+        out.append((f * 3 + rng.normal(0, 0.3, (256, 256))).astype(np.float32))
+    return np.stack(out)
+
+
+@pytest.mark.parametrize("w,h", [(1024, 1024), (1800, 1200), (512, 512), (640, 960), (1024, 768), (91, 37), (5, 3)])
+def test_postprocess_bit_exact(ext, w, h):
+    """Two-stage bilinear + crop + threshold equals the oracle's masks bit for bit."""
+    O = _oracle()
+    planes = _planes(w * 7 + h, 1)
+    got = ext.test_postprocess(planes, w, h)
+    want = O.write_mask_image(O.postprocess_logits(planes[0], (h, w))[None, None], 0, (w, h))
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
+    assert set(np.unique(got)) <= {0, 255}
+
+
+def test_postprocess_write_mask_kat(ext):
+    """reference test_segmentation.cpp:85-99: strict > 0 (0.0 stays 0)."""
+    planes = np.zeros((1, 256, 256), np.float32)
+    planes[0, :, :128] = 0.2
+    planes[0, :, 128:] = -3.1
+    planes[0, 0, 0] = 0.0
+    got = ext.test_postprocess(planes, 1024, 1024)
+    O = _oracle()
+    want = O.write_mask_image(O.postprocess_logits(planes[0], (1024, 1024))[None, None], 0, (1024, 1024))
+    assert np.array_equal(got, want)
+    assert got[500, 100] == 255 and got[500, 900] == 0
+
+
+@pytest.mark.parametrize("iou,expect", [([0.9, 0.1, 0.5, 0.3], 2), ([0.2, 0.7, 0.7, 0.1], 1), ([600.0, 0.1, 0.2, 0.3], 0),
+                                        ([0.0, -1.0, -2.0, -0.5], 3)])
+def test_postprocess_single_mask_selection(ext, iou, expect):
+    """SamOnnxModel.select_masks with two prompt tokens: token 0 is penalised by 500."""
+    O = _oracle()
+    planes = _planes(11, 4)
+    iou = np.array(iou, np.float32)
+    assert O.select_single(iou, 2) == expect
+    got = ext.test_postprocess(planes, 1024, 1024, iou=iou)
+    want = O.write_mask_image(O.postprocess_logits(planes[expect], (1024, 1024))[None, None], 0, (1024, 1024))
+    assert np.array_equal(got, want)
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+
+def _gemm_ref(A, W, bias, resid, act):
+    O = _oracle()
+    y = A.astype(np.float32) @ W.astype(np.float32).T
+    if bias is not None:
+        y = y + bias
+    if act:
+        y = O.gelu(y)
+    if resid is not None:
+        y = y + np.tile(resid, (A.shape[0] // resid.shape[0], 1))
+    return y
+
+
+@pytest.mark.parametrize("M,N,K,act,with_bias,resid_rows", [
+    (128, 128, 64, 0, False, 0),        # single tile, single k-step
+    (256, 192, 256, 0, True, 0),        # 64x64 tiles (N not a multiple of 128)
+    (4096, 768, 768, 0, True, 4096),    # proj / patch-embed shape: 128x64 tiles, residual
+    (4096, 2304, 768, 0, True, 0),      # qkv: 128x128 tiles
+    (4096, 3072, 768, 1, True, 0),      # fc1 + GELU
+    (4096, 768, 3072, 0, True, 4096),   # fc2
+    (8192, 768, 768, 0, True, 4096),    # batch 2 with positional residual wrapping every 4096 rows
+    (4096, 256, 2304, 0, False, 0),     # neck 3x3 as GEMM
+    (16384, 128, 64, 1, True, 0),       # decoder upscaling stage 2
+    (4096, 320, 320, 0, True, 0),       # head_dim-80 test width
+])
+def test_gemm_parity(ext, M, N, K, act, with_bias, resid_rows):
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float16)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float16)
+    bias = rng.standard_normal(N).astype(np.float32) if with_bias else None
+    resid = rng.standard_normal((resid_rows, N)).astype(np.float32) if resid_rows else None
+    out32, out16 = ext.test_gemm(A, W, bias, resid, act, want_f16=True)
+    ref = _gemm_ref(A, W, bias, resid, act)
+    # fp32 accumulation of exact f16 products: only summation order differs from the fp32 BLAS
+    assert np.abs(out32 - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max())
+    assert np.array_equal(out16, out32.astype(np.float16))
+
+
+def test_gemm_identity_layout(ext):
+    """A = I against an asymmetric W catches a transposed or permuted C write."""
+    K = 128
+    A = np.zeros((128, K), np.float16)
+    A[np.arange(128), np.arange(128)] = 1
+    W = (np.arange(192 * K).reshape(192, K) % 251).astype(np.float16)
+    out = ext.test_gemm(A, W)
+    assert np.array_equal(out, W.astype(np.float32).T[:128])
+
+
+def test_gemm_rejects_bad_shapes(ext):
+    from dlimgedit_amd import api
+    A = np.zeros((100, 64), np.float16)
+    W = np.zeros((64, 64), np.float16)
+    with pytest.raises(api.Error, match="multiples of 64"):
+        ext.test_gemm(A, W)
+
+
+# -------------------------------------------------------------------------------------- LayerNorm
+
+@pytest.mark.parametrize("rows,dim,act", [(4096, 768, 0), (4096, 1280, 0), (4096, 256, 0), (16384, 64, 1), (7, 256, 0),
+                                          (4096, 128, 0), (4096, 320, 0)])
+def test_layernorm_parity(ext, rows, dim, act):
+    O = _oracle()
+    rng = np.random.default_rng(rows + dim)
+    x = (rng.standard_normal((rows, dim)) * 3 + 1).astype(np.float32)
+    w = (1 + 0.1 * rng.standard_normal(dim)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(dim)).astype(np.float32)
+    o32, o16 = ext.test_layernorm(x, w, b, 1e-6, act)
+    ref = O.layer_norm(x, w, b, 1e-6)
+    if act:
+        ref = O.gelu(ref)
+    assert np.abs(o32 - ref).max() < 2e-5
+    assert np.array_equal(o16, o32.astype(np.float16))
+
+
+# -------------------------------------------------------------------------------------- attention
+
+def _qkv(seed, heads, hd, batch=1):
+    rng = np.random.default_rng(seed)
+    D = heads * hd
+    qkv = rng.standard_normal((batch * 4096, 3 * D)).astype(np.float16)
+    bias = (0.5 * rng.standard_normal(3 * D)).astype(np.float32)
+    return qkv, bias
+
+
+@pytest.mark.parametrize("heads,hd", [(2, 64), (2, 80)])
+def test_attention_window_parity(ext, heads, hd):
+    """Windowed attention incl. zero-padded tokens as un-masked keys and decomposed rel-pos bias."""
+    O = _oracle()
+    qkv, bias = _qkv(1, heads, hd)
+    rng = np.random.default_rng(2)
+    rel_h = (0.2 * rng.standard_normal((27, hd))).astype(np.float32)
+    rel_w = (0.2 * rng.standard_normal((27, hd))).astype(np.float32)
+    got = ext.test_attention(False, qkv, bias, rel_h, rel_w, 1, heads, hd).astype(np.float32)
+    # the kernel sees the bias rounded to f16 for pad tokens, as the GEMM epilogue would have stored it
+    ref = O.windowed_attention_from_qkv(qkv.astype(np.float32), bias.astype(np.float16).astype(np.float32),
+                                        rel_h.astype(np.float16).astype(np.float32),
+                                        rel_w.astype(np.float16).astype(np.float32), heads)
+    err = np.abs(got - ref).max()
+    assert err < 6e-3, err          # P and V are f16 operands of the second MFMA; output rounded to f16
+
+
+@pytest.mark.parametrize("heads,hd,batch", [(2, 64, 1), (2, 80, 1), (1, 64, 2)])
+def test_attention_global_parity(ext, heads, hd, batch):
+    """Flash-style global attention with on-the-fly rel-pos bias against the explicit 4096x4096 softmax."""
+    O = _oracle()
+    qkv, _ = _qkv(3, heads, hd, batch)
+    rng = np.random.default_rng(4)
+    rel_h = (0.2 * rng.standard_normal((127, hd))).astype(np.float32)
+    rel_w = (0.2 * rng.standard_normal((127, hd))).astype(np.float32)
+    got = ext.test_attention(True, qkv, None, rel_h, rel_w, batch, heads, hd).astype(np.float32)
+    ref = O.attention_from_qkv(qkv.astype(np.float32).reshape(batch, 4096, -1),
+                               rel_h.astype(np.float16).astype(np.float32),
+                               rel_w.astype(np.float16).astype(np.float32), heads, 64).reshape(batch * 4096, -1)
+    err = np.abs(got - ref).max()
+    assert err < 6e-3, err
+
+
+def test_attention_global_online_softmax_rescale(ext):
+    """Force the running-max rescale branch: one key row far above the rest, late in the stream."""
+    O = _oracle()
+    heads, hd = 1, 64
+    qkv, _ = _qkv(8, heads, hd)
+    qkv = (qkv.astype(np.float32) * 0.3).astype(np.float16)
+    qkv[3000, hd:2 * hd] = (qkv[5, 0:hd].astype(np.float32) * 40).astype(np.float16)   # k_3000 aligned with q_5
+    rel = np.zeros((127, hd), np.float32)
+    got = ext.test_attention(True, qkv, None, rel, rel, 1, heads, hd).astype(np.float32)
+    ref = O.attention_from_qkv(qkv.astype(np.float32)[None], rel, rel, heads, 64)[0]
+    assert np.abs(got - ref).max() < 6e-3
