@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the Segment-Anything hot path (BASELINE.json metric:
+images/sec encode+mask @1024x1024).
+
+  python bench.py --gpus N --steps K --warmup W [--model vit_b] [--batch B]
+
+One process per GPU (N > 1: launched by torch.distributed.run, RCCL only for the barrier and the
+max-over-ranks of the elapsed time: images are independent, there is no data-path collective).
+A step = one pass of the hot path over `batch` synthetic 1024x1024 RGBA images that are already
+resident in HBM: pre-process -> ViT encoder -> prompt encoder + mask decoder (one point prompt per
+image, single-mask mode) -> bilinear upsample + threshold, masks left in HBM.  At N = 1 the default
+workload is BASELINE.json configs[1] (ViT-B, batch 1, one point prompt).
+
+Besides the contract fields the JSON line carries
+  roofline      dominant kernel (the f16 MFMA GEMM of the encoder): algorithmic FLOPs / HIP-event time
+  cpu_baseline  the CPU oracle (oracle/sam_oracle.py, a port: the reference's onnxruntime path cannot
+                be built here) timed on this host on one image of the same workload
+  mask_iou      IoU of the HIP mask against the oracle's mask for that image
+  stages        per-stage HIP-event breakdown of one profiled repeat of the timed steps
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+MFMA_F16_PEAK_TFLOPS = 2500.0      # MI355X dense f16/bf16 (MI355X_MICROARCH.md, spec)
+HBM_PEAK_GBS = 8000.0
+
+
+def synthetic_image(seed: int, size: int = 1024) -> np.ndarray:
+    rng = np.random.default_rng(1000 + seed)
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32)
+    img = np.zeros((size, size, 4), np.uint8)
+    for c in range(3):
+        f = np.full((size, size), 128.0, np.float32)
+        for _ in range(8):
+            fx, fy = rng.uniform(0.002, 0.02, 2)
+            f += 14.0 * np.sin(xx * fx + yy * fy + rng.uniform(0, 6.28)).astype(np.float32)
+        f += rng.uniform(-8, 8, (size, size)).astype(np.float32)
+        img[:, :, c] = np.clip(f, 0, 255).astype(np.uint8)
+    img[:, :, 3] = 255
+    return img
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="vit_b")
+    ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model-dir", default=None, help="existing model directory (default: seeded synthetic weights)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    os.environ["DLIMGEDIT_DEVICE"] = str(local_rank)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device is visible")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from dlimgedit_amd import api, weights as W
+    from dlimgedit_amd.sam_config import get_config
+
+    cfg = get_config(args.model)
+    # ---- model directory: rank 0 of the node writes seeded synthetic weights, the others wait
+    model_dir = args.model_dir
+    params = None
+    if model_dir is None:
+        model_dir = os.path.join(tempfile.gettempdir(), f"dlimgedit_bench_{args.model}_{args.seed}_{os.getuid()}")
+        target = Path(model_dir) / "segmentation" / W.weight_file_name(cfg)
+        if local_rank == 0 and not target.exists():
+            params = W.synthetic_weights(cfg, args.seed)
+            tmp = target.with_suffix(".tmp")
+            W.save_weights(tmp, cfg, params)
+            os.replace(tmp, target)
+    if world > 1:
+        dist.barrier()
+    os.environ["DLIMGEDIT_SAM_MODEL"] = args.model
+
+    env = api.Environment(api.Options(api.Backend.gpu, model_dir))
+    ext = api.ext
+    B = args.batch
+    # ---- inputs resident in HBM before the timed region
+    imgs = [synthetic_image(rank * B + i) for i in range(B)]
+    img_ptrs, mask_ptrs = [], []
+    for im in imgs:
+        p = ext.device_alloc(env, im.nbytes)
+        ext.copy_to_device(env, p, im)
+        img_ptrs.append(p)
+        mask_ptrs.append(ext.device_alloc(env, 1024 * 1024))
+    views = ext.device_views(img_ptrs, 1024, 1024)
+    points = [api.Point(512, 512)] * B
+
+    def step():
+        ext.encode_and_mask(env, views, points, mask_ptrs)
+
+    def sync_all():
+        ext.synchronize(env)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ext.synchronize(env)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+
+    result = None
+    if rank == 0:
+        images = world * B * args.steps
+        result = {
+            "metric": "images/sec encode+mask @1024x1024",
+            "value": images / elapsed,
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16",
+            "data": "synthetic",
+            "config": {"workload": f"SAM {args.model} encoder + 1 point prompt, {B} image(s)/GPU/step, 1024x1024 RGBA, "
+                                   "inputs and masks resident in HBM", "images_per_gpu_per_step": B,
+                       "weights": "seeded synthetic" if args.model_dir is None else "from --model-dir"},
+        }
+
+    # ---- profiled repeat of the same steps: HIP events around every launch on the executor's stream
+    if rank == 0:
+        ext.set_profiling(env, True)
+        ext.take_stage_stats(env)
+        for _ in range(args.steps):
+            step()
+        ext.synchronize(env)
+        st = ext.take_stage_stats(env)
+        ext.set_profiling(env, False)
+        g = st["gemm"]
+        achieved = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        result["roofline"] = {
+            "kernel": "gemm_f16_kernel (all encoder/decoder MFMA GEMM launches)",
+            "bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": None,
+            "launches": g["launches"], "avg_launch_us": 1e3 * g["ms"] / max(1, g["launches"]),
+            "flops_per_launch": g["work"] / max(1, g["launches"]),
+        }
+        stages = {}
+        for name, s in st.items():
+            if s["launches"] == 0:
+                continue
+            per_step_ms = s["ms"] / args.steps
+            e = {"ms_per_step": per_step_ms, "launches_per_step": s["launches"] / args.steps}
+            if name in ("gemm", "attention_window", "attention_global", "decoder"):
+                e["tflops"] = s["work"] / (s["ms"] * 1e-3) / 1e12
+            else:
+                e["gbs"] = s["work"] / (s["ms"] * 1e-3) / 1e9
+                e["frac_hbm_peak"] = e["gbs"] / HBM_PEAK_GBS
+            stages[name] = e
+        result["stages"] = stages
+        enc_ms = sum(v["ms_per_step"] for k, v in stages.items() if k not in ("decoder", "post", "pre"))
+        result["encoder"] = {"gflop_per_image": cfg.encoder_flops() / 1e9, "event_ms_per_step": enc_ms,
+                             "tflops": B * cfg.encoder_flops() / (enc_ms * 1e-3) / 1e12 if enc_ms > 0 else 0.0,
+                             "mfma_frac": B * cfg.encoder_flops() / (enc_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS
+                             if enc_ms > 0 else 0.0}
+
+    # ---- CPU baseline (oracle port) + mask IoU, rank 0, N = 1 only
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import sam_oracle as O
+        if params is None:
+            params = W.load_weights(Path(model_dir) / "segmentation" / W.weight_file_name(cfg))[1] \
+                if args.model_dir else W.synthetic_weights(cfg, args.seed)
+        gpu_mask = np.empty((1024, 1024), np.uint8)
+        ext.copy_to_host(env, gpu_mask, mask_ptrs[0])
+        threads = os.cpu_count() or 1
+        t0 = time.perf_counter()
+        ora = O.OracleSegmentation(params, cfg).process(imgs[0], O.CH_RGBA)
+        t_enc = time.perf_counter() - t0
+        cpu_mask = ora.compute_mask(point=(512, 512))
+        t_all = time.perf_counter() - t0
+        inter = np.logical_and(gpu_mask > 0, cpu_mask > 0).sum()
+        union = np.logical_or(gpu_mask > 0, cpu_mask > 0).sum()
+        result["cpu_baseline"] = {"value": 1.0 / t_all, "unit": "images/s", "cores": threads, "kind": "port",
+                                  "sample": f"1 image of the same workload ({args.model} encode {t_enc:.1f} s + 1 point "
+                                            f"mask {t_all - t_enc:.2f} s), numpy fp32 oracle, BLAS threads = host cores"}
+        result["mask_iou"] = float(inter) / float(union) if union else 1.0
+        result["mask_foreground_frac"] = float((cpu_mask > 0).mean())
+
+    if rank == 0:
+        print(json.dumps(result))
+    for p in img_ptrs + mask_ptrs:
+        ext.device_free(env, p)
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
