@@ -11,8 +11,10 @@
 // Operands are swapped (S^T = K . Q^T) so a lane owns one query: online-softmax statistics, the
 // rescale of O^T and the bias are all lane-local; P tiles feed the second MFMA straight from the
 // accumulator registers (O^T = V^T . P^T).
-// K/V tiles are register-staged one tile ahead (loads issued before the MFMAs of the current tile,
-// LDS writes after them), two LDS buffers, one barrier per tile.
+// K/V tiles are register-staged one tile ahead (coalesced 16-byte loads issued before the MFMAs of the
+// current tile, ds_write_b128 after them), two LDS buffers, one barrier per tile.  V stays row-major
+// in LDS; the transposed MFMA operand comes from ds_read_b64_tr_b16 (hardware transpose read) on
+// 192-byte rows, which tiles the 64 banks exactly (4 key rows x 64 B per half-wave: conflict-free).
 #include "device_common.hpp"
 #include "kernels.hpp"
 
@@ -22,8 +24,10 @@ namespace {
 constexpr int GRID = 64;
 constexpr int TOKENS = 4096;
 constexpr int KT = 64;              // keys per tile
-constexpr int VT_STRIDE = 68;       // elements per row of the transposed V tile (136 B: conflict-free ds_read_b64)
+constexpr int V_STRIDE = 96;        // elements per key row of the V tile (192 B: conflict-free ds_read_b64_tr_b16)
 constexpr int RELH_STRIDE = 32;     // floats: relh_lds[wave][ky][query]
+typedef short short4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) short4_t lds_short4_t;
 constexpr int GW_STRIDE = 97;       // floats per query row of the prologue scratch (96 rel rows + 1)
 
 template <int HD>
@@ -37,12 +41,13 @@ __global__ __launch_bounds__(256, 2) void attention_global_kernel(const half_t* 
     constexpr int CHUNKS = HD / 8;
     constexpr int STAGE_ITERS = (KT * CHUNKS + 255) / 256;
     constexpr int K_TILE = KT * K_STRIDE;               // elements
-    constexpr int VT_TILE = DT * 32 * VT_STRIDE;        // elements
+    constexpr int V_TILE = KT * V_STRIDE;               // elements
+    static_assert(DT * 32 <= V_STRIDE, "head dimension tiles must fit the padded V row");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* relh_lds = reinterpret_cast<float*>(smem);                          // [4][64][32]
     half_t* lds_k = reinterpret_cast<half_t*>(smem + 4 * 64 * RELH_STRIDE * 4);   // [2][K_TILE]
-    half_t* lds_vt = lds_k + 2 * K_TILE;                                        // [2][VT_TILE]
+    half_t* lds_v = lds_k + 2 * K_TILE;                                         // [2][V_TILE] row-major [key][V_STRIDE]
     float* scratch = reinterpret_cast<float*>(lds_k);   // prologue only: [4][32][GW_STRIDE], aliases the tile buffers
 
     const int D = heads * HD;
@@ -118,13 +123,14 @@ __global__ __launch_bounds__(256, 2) void attention_global_kernel(const half_t* 
     __syncthreads();            // scratch is dead; tile buffers may be written
 
     // ---- K/V tile staging ------------------------------------------------------------------------
+    // consecutive lanes take consecutive 16-byte chunks of a key row: every global line is used whole
     half8_t kreg[STAGE_ITERS], vreg[STAGE_ITERS];
     auto load_tile = [&](int t) {
 #pragma unroll
         for (int it = 0; it < STAGE_ITERS; ++it) {
             const int idx = it * 256 + tid;
             if (idx < KT * CHUNKS) {
-                const int key = idx % KT, ch = idx / KT;
+                const int key = idx / CHUNKS, ch = idx % CHUNKS;
                 const half_t* row = base + (size_t)(t * KT + key) * ld + ch * 8;
                 kreg[it] = *reinterpret_cast<const half8_t*>(row + D);
                 vreg[it] = *reinterpret_cast<const half8_t*>(row + 2 * D);
@@ -133,26 +139,30 @@ __global__ __launch_bounds__(256, 2) void attention_global_kernel(const half_t* 
     };
     auto write_tile = [&](int buf) {
         half_t* kd = lds_k + buf * K_TILE;
-        half_t* vd = lds_vt + buf * VT_TILE;
+        half_t* vd = lds_v + buf * V_TILE;
 #pragma unroll
         for (int it = 0; it < STAGE_ITERS; ++it) {
             const int idx = it * 256 + tid;
             if (idx < KT * CHUNKS) {
-                const int key = idx % KT, ch = idx / KT;
+                const int key = idx / CHUNKS, ch = idx % CHUNKS;
                 *reinterpret_cast<half8_t*>(kd + key * K_STRIDE + ch * 8) = kreg[it];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) vd[(ch * 8 + e) * VT_STRIDE + key] = vreg[it][e];
+                *reinterpret_cast<half8_t*>(vd + key * V_STRIDE + ch * 8) = vreg[it];
             }
         }
     };
 
-    if (DT * 32 > HD) {         // rows of V^T beyond the head dimension stay zero in both buffers
-        for (int idx = tid; idx < 2 * VT_TILE / 2; idx += 256) reinterpret_cast<uint32_t*>(lds_vt)[idx] = 0u;
+    if (DT * 32 > HD) {         // columns of V beyond the head dimension stay zero in both buffers
+        for (int idx = tid; idx < 2 * V_TILE / 2; idx += 256) reinterpret_cast<uint32_t*>(lds_v)[idx] = 0u;
         __syncthreads();
     }
     load_tile(0);
     write_tile(0);
     __syncthreads();
+
+    // transposed-read addressing (cdna_hip_programming.md T10): in each 16-lane group, lane 4q+p points
+    // at row q, columns 4p..4p+3 of a 4-key x 16-column block and receives column (lane&15) of the 4 keys.
+    // Group g = lane>>4: columns 16*(g&1).., keys of half g>>1  ==  this lane's (l31, hi) operand slot.
+    const int tr_off = ((hi * 4 + ((lane & 15) >> 2)) * V_STRIDE) + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
 
     float16_t o[DT];
 #pragma unroll
@@ -165,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void attention_global_kernel(const half_t* 
         if (t + 1 < NT) load_tile(t + 1);
 
         const half_t* kb = lds_k + buf * K_TILE;
-        const half_t* vb = lds_vt + buf * VT_TILE;
+        const half_t* vb = lds_v + buf * V_TILE + tr_off;
         const float rh = relh_lds[(wave * 64 + t) * RELH_STRIDE + l31];
 
         float16_t s[2];
@@ -188,22 +198,24 @@ __global__ __launch_bounds__(256, 2) void attention_global_kernel(const half_t* 
             for (int r = 0; r < 16; ++r) tm = fmaxf(tm, s[jt][r]);
         tm = fmaxf(tm, swap_halves(tm));
         const float m_new = fmaxf(m, tm);
-        const float alpha = exp2f((m - m_new) * c);
+        const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c);
         m = m_new;
         float ps = 0.f;
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float p = exp2f((s[jt][r] - m_new) * c);
+                float p = __builtin_amdgcn_exp2f((s[jt][r] - m_new) * c);
                 s[jt][r] = p;
                 ps += p;
             }
         l = l * alpha + ps;
+        if (!__all(alpha == 1.0f)) {            // the running max moved for some query of this wave
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+            for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
 
         // O^T += V^T . P^T   (P tile as B operand straight from the accumulator registers)
 #pragma unroll
@@ -213,13 +225,14 @@ __global__ __launch_bounds__(256, 2) void attention_global_kernel(const half_t* 
                 half8_t pf;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pf[e] = (half_t)s[jt][st * 8 + e];
-                const int key0 = jt * 32 + st * 16 + hi * 4;
+                const int key0 = jt * 32 + st * 16;         // element e <-> key0 + 4*hi + 8*(e>>2) + (e&3)
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    const half_t* vrow = vb + (dt * 32 + l31) * VT_STRIDE + key0;
-                    half4_t v0 = *reinterpret_cast<const half4_t*>(vrow);
-                    half4_t v1 = *reinterpret_cast<const half4_t*>(vrow + 8);
-                    half8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    const half_t* vp = vb + key0 * V_STRIDE + dt * 32;
+                    const short4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_t*)vp);
+                    const short4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_t*)(vp + 8 * V_STRIDE));
+                    const half4_t h0 = __builtin_bit_cast(half4_t, v0), h1 = __builtin_bit_cast(half4_t, v1);
+                    half8_t vf = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
                     o[dt] = mfma32(vf, pf, o[dt]);
                 }
             }
@@ -250,8 +263,7 @@ __global__ __launch_bounds__(256, 2) void attention_global_kernel(const half_t* 
 template <int HD>
 void launch_global(const half_t* qkv, const float* rel_h, const float* rel_w, half_t* out, int B, int heads,
                    hipStream_t s) {
-    constexpr int DT = (HD + 31) / 32;
-    const size_t tiles = 2 * ((size_t)KT * (HD + 8) + (size_t)DT * 32 * VT_STRIDE) * 2;
+    const size_t tiles = 2 * ((size_t)KT * (HD + 8) + (size_t)KT * V_STRIDE) * 2;
     const size_t scratch = 4 * 32 * GW_STRIDE * 4;
     const size_t lds = 4 * 64 * RELH_STRIDE * 4 + (tiles > scratch ? tiles : scratch);
     static bool attr_set = false;

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void prompt_tokens_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------
-// Y[r,n] = act((X[r,:]+X2[r,:]) . W[n,:] + b[n]) + R[r,n]; one wave per output column.
+// Y[r,n] = act((X[r,:]+X2[r,:]) . W[n,:] + b[n]) + R[r,n]; one wave per output column, 16-byte loads.
 constexpr int RCHUNK = 8;
 __global__ __launch_bounds__(256) void token_linear_kernel(const float* __restrict__ X, const float* __restrict__ X2,
                                                            const float* __restrict__ W, const float* __restrict__ b,
@@ -56,19 +56,20 @@ __global__ __launch_bounds__(256) void token_linear_kernel(const float* __restri
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
     const int lane = lane_id();
-    const float* wr = W + (size_t)n * K;
+    const float4_t* wr = reinterpret_cast<const float4_t*>(W + (size_t)n * K);
+    const int K4 = K >> 2;
     for (int r0 = 0; r0 < rows; r0 += RCHUNK) {
         float acc[RCHUNK];
 #pragma unroll
         for (int r = 0; r < RCHUNK; ++r) acc[r] = 0.f;
-        for (int kk = lane; kk < K; kk += 64) {
-            const float w = wr[kk];
+        for (int k4 = lane; k4 < K4; k4 += 64) {
+            const float4_t w = wr[k4];
 #pragma unroll
             for (int r = 0; r < RCHUNK; ++r) {
                 if (r0 + r < rows) {
-                    float x = X[(size_t)(r0 + r) * K + kk];
-                    if (X2) x += X2[(size_t)(r0 + r) * K + kk];
-                    acc[r] = fmaf(x, w, acc[r]);
+                    float4_t x = reinterpret_cast<const float4_t*>(X + (size_t)(r0 + r) * K)[k4];
+                    if (X2) x += reinterpret_cast<const float4_t*>(X2 + (size_t)(r0 + r) * K)[k4];
+                    acc[r] = fmaf(x[0], w[0], fmaf(x[1], w[1], fmaf(x[2], w[2], fmaf(x[3], w[3], acc[r]))));
                 }
             }
         }
@@ -124,59 +125,74 @@ __global__ __launch_bounds__(256) void token_self_attention_kernel(const float* 
 
 // ---------------------------------------------------------------------------------------------
 // Tokens attend to the 4096 image positions (8 heads x 16).  One workgroup per (prompt, head);
-// thread = (query t, key lane kl of 32); per-thread online softmax, then a 32-lane combine.
+// every thread streams 16 keys for all 7 queries with an online softmax, then the 256 partial
+// (max, sum, output) triples are merged: butterfly inside each wave, LDS across the 4 waves.
 __global__ __launch_bounds__(256) void token_to_image_kernel(const float* __restrict__ q, const half_t* __restrict__ K,
                                                              int ldk, const half_t* __restrict__ V, int ldv,
                                                              float* __restrict__ out) {
+    __shared__ float sq[TOK * 16];
+    __shared__ float part[4][TOK][18];
     const int p = blockIdx.x / HEADS, h = blockIdx.x % HEADS;
-    const int t = threadIdx.x >> 5, kl = threadIdx.x & 31;
-    const bool active = t < TOK;
-    const int tq = active ? t : 0;
-    float qv[16];
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    if (tid < TOK * 16) sq[tid] = q[((size_t)p * TOK + tid / 16) * INNER + h * 16 + (tid & 15)] * 0.25f;   // 16^-0.5
+    __syncthreads();
+    float m[TOK], l[TOK], o[TOK][16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) qv[e] = q[((size_t)p * TOK + tq) * INNER + h * 16 + e] * 0.25f;   // 16^-0.5
-    float m = -INFINITY, l = 0.f, o[16];
+    for (int t = 0; t < TOK; ++t) {
+        m[t] = -INFINITY;
+        l[t] = 0.f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) o[e] = 0.f;
+        for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
+    }
     const half_t* kb = K + (size_t)p * NTOK_IMG * ldk + h * 16;
     const half_t* vb = V + (size_t)p * NTOK_IMG * ldv + h * 16;
-    for (int j = kl; j < NTOK_IMG; j += 32) {
-        half8_t k0 = *reinterpret_cast<const half8_t*>(kb + (size_t)j * ldk);
-        half8_t k1 = *reinterpret_cast<const half8_t*>(kb + (size_t)j * ldk + 8);
-        float s = 0.f;
+    for (int j = tid; j < NTOK_IMG; j += 256) {
+        const half8_t k0 = *reinterpret_cast<const half8_t*>(kb + (size_t)j * ldk);
+        const half8_t k1 = *reinterpret_cast<const half8_t*>(kb + (size_t)j * ldk + 8);
+        const half8_t v0 = *reinterpret_cast<const half8_t*>(vb + (size_t)j * ldv);
+        const half8_t v1 = *reinterpret_cast<const half8_t*>(vb + (size_t)j * ldv + 8);
+        float kf[16], vf[16];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s = fmaf(qv[e], (float)k0[e], s);
+        for (int e = 0; e < 8; ++e) { kf[e] = (float)k0[e]; kf[8 + e] = (float)k1[e]; vf[e] = (float)v0[e]; vf[8 + e] = (float)v1[e]; }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s = fmaf(qv[8 + e], (float)k1[e], s);
-        const float mn = fmaxf(m, s);
-        const float a = expf(m - mn), pj = expf(s - mn);
-        half8_t v0 = *reinterpret_cast<const half8_t*>(vb + (size_t)j * ldv);
-        half8_t v1 = *reinterpret_cast<const half8_t*>(vb + (size_t)j * ldv + 8);
-        l = l * a + pj;
+        for (int t = 0; t < TOK; ++t) {
+            float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = fmaf(pj, (float)v0[e], o[e] * a);
+            for (int e = 0; e < 16; ++e) s = fmaf(sq[t * 16 + e], kf[e], s);
+            const float mn = fmaxf(m[t], s);
+            const float a = __expf(m[t] - mn), pj = __expf(s - mn);
+            l[t] = l[t] * a + pj;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[8 + e] = fmaf(pj, (float)v1[e], o[8 + e] * a);
-        m = mn;
+            for (int e = 0; e < 16; ++e) o[t][e] = fmaf(pj, vf[e], o[t][e] * a);
+            m[t] = mn;
+        }
     }
-    // combine the 32 key lanes of this query (lanes of one 32-lane half)
-    float M = m;
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
-    const float w = expf(m - M);
-    l *= w;
+    for (int t = 0; t < TOK; ++t) {
+        const float M = wave_max(m[t]);
+        const float w = __expf(m[t] - M);
+        const float ls = wave_sum(l[t] * w);
+        if (lane == 0) { part[wave][t][0] = M; part[wave][t][1] = ls; }
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) l += __shfl_xor(l, off, 64);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        float x = o[e] * w;
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
-        o[e] = x;
+        for (int e = 0; e < 16; ++e) {
+            const float x = wave_sum(o[t][e] * w);
+            if (lane == 0) part[wave][t][2 + e] = x;
+        }
     }
-    if (active && kl == 0) {
+    __syncthreads();
+    if (tid < TOK * 16) {
+        const int t = tid / 16, e = tid & 15;
+        float M = part[0][t][0];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) out[((size_t)p * TOK + t) * INNER + h * 16 + e] = o[e] / l;
+        for (int w = 1; w < 4; ++w) M = fmaxf(M, part[w][t][0]);
+        float ls = 0.f, os = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float f = __expf(part[w][t][0] - M);
+            ls += part[w][t][1] * f;
+            os += part[w][t][2 + e] * f;
+        }
+        out[((size_t)p * TOK + t) * INNER + h * 16 + e] = os / ls;
     }
 }
 
@@ -230,34 +246,38 @@ __global__ __launch_bounds__(256) void image_to_token_kernel(const half_t* __res
 
 // ---------------------------------------------------------------------------------------------
 // Hyper-network MLPs + IoU head.  grid (P, 5): y = 0..3 mask token MLPs (-> 32), y = 4 IoU head (-> 4).
-DLIMG_DEVICE void mlp_layer(const float* x, const float* W, const float* b, float* y, int K, int N, bool relu, int wave,
-                            int lane) {
-    for (int n = wave; n < N; n += 4) {
-        float a = 0.f;
-        for (int kk = lane; kk < K; kk += 64) a = fmaf(x[kk], W[(size_t)n * K + kk], a);
-        a = wave_sum(a);
-        if (lane == 0) {
-            a += b[n];
-            y[n] = relu ? fmaxf(a, 0.f) : a;
-        }
+// One thread per output neuron, weight rows read with 16-byte loads, activations broadcast from LDS.
+DLIMG_DEVICE float neuron(const float* x /*LDS*/, const float* __restrict__ wrow, float bias) {
+    const float4_t* w4 = reinterpret_cast<const float4_t*>(wrow);
+    const float4_t* x4 = reinterpret_cast<const float4_t*>(x);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 8
+    for (int k4 = 0; k4 < DIM / 4; ++k4) {
+        const float4_t w = w4[k4], v = x4[k4];
+        a0 = fmaf(v[0], w[0], a0);
+        a1 = fmaf(v[1], w[1], a1);
+        a2 = fmaf(v[2], w[2], a2);
+        a3 = fmaf(v[3], w[3], a3);
     }
+    return (a0 + a1) + (a2 + a3) + bias;
 }
 
 __global__ __launch_bounds__(256) void output_heads_kernel(const float* __restrict__ queries, k::HeadWeights hw,
                                                            float* __restrict__ hyper, float* __restrict__ iou) {
-    __shared__ float x0[DIM], x1[DIM], x2[DIM];
-    const int p = blockIdx.x, mi = blockIdx.y;
+    __shared__ __attribute__((aligned(16))) float x0[DIM], x1[DIM], x2[DIM];
+    const int p = blockIdx.x, mi = blockIdx.y, n = threadIdx.x;
     const int tok = mi < 4 ? 1 + mi : 0;
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
-    x0[threadIdx.x] = queries[((size_t)p * TOK + tok) * DIM + threadIdx.x];
+    x0[n] = queries[((size_t)p * TOK + tok) * DIM + n];
     __syncthreads();
-    mlp_layer(x0, hw.w[mi][0], hw.b[mi][0], x1, DIM, DIM, true, wave, lane);
+    x1[n] = fmaxf(neuron(x0, hw.w[mi][0] + (size_t)n * DIM, hw.b[mi][0][n]), 0.f);
     __syncthreads();
-    mlp_layer(x1, hw.w[mi][1], hw.b[mi][1], x2, DIM, DIM, true, wave, lane);
+    x2[n] = fmaxf(neuron(x1, hw.w[mi][1] + (size_t)n * DIM, hw.b[mi][1][n]), 0.f);
     __syncthreads();
     const int nout = mi < 4 ? 32 : 4;
-    float* dst = mi < 4 ? hyper + ((size_t)p * 4 + mi) * 32 : iou + (size_t)p * 4;
-    mlp_layer(x2, hw.w[mi][2], hw.b[mi][2], dst, DIM, nout, false, wave, lane);
+    if (n < nout) {
+        float* dst = mi < 4 ? hyper + ((size_t)p * 4 + mi) * 32 : iou + (size_t)p * 4;
+        dst[n] = neuron(x2, hw.w[mi][2] + (size_t)n * DIM, hw.b[mi][2][n]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -303,7 +323,7 @@ void prompt_tokens(const float* coords, const float* labels, const float* gauss,
 void token_linear(const float* X, const float* X2, const float* W, const float* b, const float* R, float* Y, int rows,
                   int K, int N, int relu, hipStream_t s) {
     if (rows <= 0 || N <= 0) return;
-    if (K <= 0) throw_error("token_linear: K must be positive");
+    if (K <= 0 || K % 4) throw_error("token_linear: K must be a positive multiple of 4");
     hipLaunchKernelGGL(token_linear_kernel, dim3((N + 3) / 4), dim3(256), 0, s, X, X2, W, b, R, Y, rows, K, N, relu);
 }
 

@@ -130,6 +130,55 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// Same, rows whose length is a multiple of 256: 16-byte loads/stores (the encoder widths 768/1024/1280
+// and the 256-channel neck / decoder rows).
+constexpr int LN_MAX_VEC = 5;         // D <= 1280
+template <int ACT>
+__global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ b, float eps, int rows, int D,
+                                                            float* out_f32, half_t* out_h) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = lane_id();
+    const int nv = D >> 8;
+    const float4_t* xr = reinterpret_cast<const float4_t*>(x + (size_t)row * D);
+    float4_t v[LN_MAX_VEC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_VEC; ++i) {
+        v[i] = float4_t{0.f, 0.f, 0.f, 0.f};
+        if (i < nv) v[i] = xr[i * 64 + lane];
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_VEC; ++i) {
+        if (i < nv) {
+            v[i] -= mean;
+            q += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAX_VEC; ++i) {
+        if (i < nv) {
+            const int c4 = i * 64 + lane;
+            const float4_t ww = reinterpret_cast<const float4_t*>(w)[c4], bb = reinterpret_cast<const float4_t*>(b)[c4];
+            float4_t y = v[i] * rstd * ww + bb;
+            if (ACT == k::ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = gelu_erf(y[e]);
+            }
+            if (out_f32) reinterpret_cast<float4_t*>(out_f32 + (size_t)row * D)[c4] = y;
+            if (out_h) {
+                half4_t h = {(half_t)y[0], (half_t)y[1], (half_t)y[2], (half_t)y[3]};
+                reinterpret_cast<half4_t*>(out_h + (size_t)row * D)[c4] = h;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void add_cast_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                        size_t b_mod, size_t n4, float* out_f32, half_t* out_h) {
@@ -194,6 +243,14 @@ void layernorm(const float* x, const float* w, const float* b, float eps, int ro
     if (rows <= 0) return;
     if (D <= 0 || D > LN_MAX_PER_LANE * 64) throw_error("layernorm: row length must be in 1..1280");
     dim3 grid((rows + 3) / 4);
+    const bool aligned = !(((uintptr_t)x | (uintptr_t)w | (uintptr_t)b | (uintptr_t)out_f32) & 15) && !((uintptr_t)out_h & 7);
+    if (D % 256 == 0 && aligned) {
+        if (act == ACT_GELU)
+            hipLaunchKernelGGL(layernorm_vec_kernel<ACT_GELU>, grid, dim3(256), 0, s, x, w, b, eps, rows, D, out_f32, out_h);
+        else
+            hipLaunchKernelGGL(layernorm_vec_kernel<ACT_NONE>, grid, dim3(256), 0, s, x, w, b, eps, rows, D, out_f32, out_h);
+        return;
+    }
     if (act == ACT_GELU)
         hipLaunchKernelGGL(layernorm_kernel<ACT_GELU>, grid, dim3(256), 0, s, x, w, b, eps, rows, D, out_f32, out_h);
     else

@@ -5,18 +5,24 @@
 // neck convolutions (1x1 and im2col'ed 3x3), and the image-side projections of the mask decoder.
 //
 // Both operands are K-contiguous (activations row-major, weights in nn.Linear [out,in] layout), so
-// an MFMA fragment is one 16-byte LDS read.  Structure per workgroup (4 waves, 2x2):
-//   * BM x BN output tile, BK = 64; each wave owns a (BM/2) x (BN/2) sub-tile of 32x32 MFMA tiles
+// an MFMA fragment is one 16-byte LDS read.  Structure per workgroup (4 waves, WGM x WGN):
+//   * BM x BN output tile, BK = 64; each wave owns a (BM/WGM) x (BN/WGN) sub-tile of 32x32 MFMA tiles
 //   * operand tiles go HBM -> LDS with global_load_lds (16 B/lane, no VGPR round trip), two LDS
 //     buffers, tile k+1 in flight while tile k feeds the MFMAs, one barrier per K-tile
 //   * LDS image is lane-linear (a DMA wave-instruction writes 8 rows x 128 B); the bank-conflict
 //     swizzle chunk ^= (row>>1)&7 is applied on the per-lane SOURCE address and again on the read
 //     (cdna_hip_programming.md rule 21), making every ds_read_b128 group conflict-free
+//   * MFMA operands are swapped (weights as A, activations as B) so a lane's accumulator registers
+//     hold 4 CONSECUTIVE output columns of one row: the tile goes to LDS with ds_write_b128
+//     (XOR-swizzled, conflict-free) and comes back row-wise, so bias / residual / outputs are
+//     all 16-byte, fully coalesced global accesses
 //   * XCD-aware workgroup remap so the tiles of one XCD share A panels in its L2
 // Epilogue (all optional, fp32): + bias[n], GELU(erf), + residual[m % resid_mod][n], store f32
 // and/or f16.
 #include "device_common.hpp"
 #include "kernels.hpp"
+
+#include <cstdlib>
 
 namespace dlimg {
 namespace {
@@ -30,6 +36,7 @@ DLIMG_DEVICE int swz(int row) { return (row >> 1) & 7; }
 template <int ROWS>
 DLIMG_DEVICE void stage_tile(const half_t* __restrict__ src, int ld, int r0, int k0, char* lds, int wave, int lane) {
     constexpr int PIECES = ROWS / 8;            // one wave-instruction moves 8 rows x 128 B
+    static_assert(PIECES % 4 == 0, "tile rows must be a multiple of 32");
 #pragma unroll
     for (int q = 0; q < PIECES / 4; ++q) {
         const int p = q * 4 + wave;
@@ -44,17 +51,36 @@ DLIMG_DEVICE half8_t read_frag(const char* lds, int row, int chunk) {
     return *reinterpret_cast<const half8_t*>(lds + row * ROW_BYTES + ((chunk ^ swz(row)) << 4));
 }
 
-template <int BM, int BN, int ACT>
+// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7):
+// a third of the instructions of erff(), which matters because fc1's epilogue is as long as its
+// K loop at batch 1.
+DLIMG_DEVICE float gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p *= t;
+    const float e = 1.0f - p * __expf(-z * z);
+    return 0.5f * x * (1.0f + copysignf(e, x));
+}
+
+template <int BM, int BN, int WGM, int WGN, int ACT>
 __global__ __launch_bounds__(256) void gemm_f16_kernel(k::GemmArgs a) {
-    constexpr int WM = BM / 2, WN = BN / 2;     // wave tile
-    constexpr int TM = WM / 32, TN = WN / 32;   // 32x32 MFMA tiles per wave
+    static_assert(WGM * WGN == 4, "four waves per workgroup");
+    constexpr int WM = BM / WGM, WN = BN / WGN;     // wave tile
+    constexpr int TM = WM / 32, TN = WN / 32;       // 32x32 MFMA tiles per wave
     constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;  // buffer b: A tile at b*STAGE_BYTES, B tile behind it
+    constexpr int CHUNKS = WN / 4;                  // 16-byte column chunks per row of the wave's output tile
+    constexpr int OUT_BYTES = WM * WN * 4;          // per-wave fp32 staging of the output tile
+    static_assert(4 * OUT_BYTES <= 2 * STAGE_BYTES, "output staging must fit in the operand buffers");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;   // buffer b: A tile at b*STAGE_BYTES, B tile behind it
 
     const int lane = lane_id();
     const int wave = wave_id();
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WGN, wc = wave % WGN;
     const int hi = lane >> 5, l31 = lane & 31;
 
     const int ntn = a.N / BN;
@@ -90,41 +116,63 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(k::GemmArgs a) {
             for (int i = 0; i < TM; ++i) fa[i] = read_frag(la, wr * WM + i * 32 + l31, ks * 2 + hi);
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[j] = read_frag(lb, wc * WN + j * 32 + l31, ks * 2 + hi);
+            // swapped roles: D[row = n][col = m]; lane <-> m, registers <-> 4-groups of consecutive n
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(fa[i], fb[j], acc[i][j]);
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(fb[j], fa[i], acc[i][j]);
         }
     }
 
-    // epilogue
+    // ---- epilogue: accumulators -> LDS (row-major wave tile, chunk ^= row&7) -> coalesced rows ----
+    __syncthreads();                             // operand buffers are dead for every wave
+    char* stage = smem + wave * OUT_BYTES;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wc * WN + j * 32 + l31;
-        const float bias = a.bias ? a.bias[n] : 0.f;
+    for (int i = 0; i < TM; ++i) {
+        const int row = i * 32 + l31;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wr * WM + i * 32 + acc_row(r, hi);
-                float v = acc[i][j][r] + bias;
-                if (ACT == k::ACT_GELU) v = gelu_erf(v);
-                if (a.resid) v += a.resid[(size_t)(m % a.resid_mod) * a.ldr + n];
-                if (a.out_f32) a.out_f32[(size_t)m * a.ldc32 + n] = v;
-                if (a.out_h) a.out_h[(size_t)m * a.ldc16 + n] = (half_t)v;
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int chunk = j * 8 + g4 * 2 + hi;          // columns 4*chunk .. 4*chunk+3
+                float4_t v = {acc[i][j][g4 * 4 + 0], acc[i][j][g4 * 4 + 1], acc[i][j][g4 * 4 + 2],
+                              acc[i][j][g4 * 4 + 3]};
+                *reinterpret_cast<float4_t*>(stage + (row * CHUNKS + (chunk ^ (row & 7))) * 16) = v;
             }
+    }
+    // each wave reads back only what it wrote itself: wave-local ordering is enough
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    constexpr int ITEMS = WM * CHUNKS;
+    static_assert(ITEMS % 64 == 0, "wave tile must split evenly over 64 lanes");
+#pragma unroll 4
+    for (int it = 0; it < ITEMS / 64; ++it) {
+        const int idx = it * 64 + lane;
+        const int row = idx / CHUNKS, chunk = idx % CHUNKS;
+        float4_t v = *reinterpret_cast<const float4_t*>(stage + (row * CHUNKS + (chunk ^ (row & 7))) * 16);
+        const int m = m0 + wr * WM + row;
+        const int n = n0 + wc * WN + chunk * 4;
+        if (a.bias) v += *reinterpret_cast<const float4_t*>(a.bias + n);
+        if (ACT == k::ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
+        }
+        if (a.resid) v += *reinterpret_cast<const float4_t*>(a.resid + (size_t)(m % a.resid_mod) * a.ldr + n);
+        if (a.out_f32) *reinterpret_cast<float4_t*>(a.out_f32 + (size_t)m * a.ldc32 + n) = v;
+        if (a.out_h) {
+            half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            *reinterpret_cast<half4_t*>(a.out_h + (size_t)m * a.ldc16 + n) = h;
         }
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int WGM, int WGN>
 void launch(const k::GemmArgs& a, hipStream_t s) {
     const int grid = (a.M / BM) * (a.N / BN);
     const size_t lds = 2 * (BM + BN) * ROW_BYTES;
     if (a.act == k::ACT_GELU)
-        hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, k::ACT_GELU>), dim3(grid), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WGM, WGN, k::ACT_GELU>), dim3(grid), dim3(256), lds, s, a);
     else
-        hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, k::ACT_NONE>), dim3(grid), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WGM, WGN, k::ACT_NONE>), dim3(grid), dim3(256), lds, s, a);
 }
 
 }  // namespace
@@ -139,17 +187,40 @@ const char* gemm_check(const GemmArgs& a) {
     if (((uintptr_t)a.A | (uintptr_t)a.W) & 15) return "gemm: operands must be 16-byte aligned";
     if (a.resid && a.resid_mod <= 0) return "gemm: resid_mod must be positive";
     if (!a.out_f32 && !a.out_h) return "gemm: no output";
+    if ((a.bias && ((uintptr_t)a.bias & 15)) || (a.resid && (((uintptr_t)a.resid & 15) || a.ldr % 4)) ||
+        (a.out_f32 && (((uintptr_t)a.out_f32 & 15) || a.ldc32 % 4)) ||
+        (a.out_h && (((uintptr_t)a.out_h & 7) || a.ldc16 % 4)))
+        return "gemm: bias/residual/output rows must be 16-byte (f16 output: 8-byte) aligned";
     return nullptr;
 }
 
-// Tile choice: the largest tile that still yields at least one workgroup per CU (256), else the
-// smallest tile, so a batch-1 encoder GEMM (M = 4096) covers the chip.
+// Tile choice for the 256 CUs of an MI355X.  0: 128x128 (2x2 waves), 1: 128x96 (4x1), 2: 128x64 (2x2),
+// 3: 64x64 (2x2).  Prefer the largest tile that still gives every CU at least one workgroup; 128x96
+// makes N = 768 (ViT-B proj/fc2 at batch 1: M = 4096) exactly 256 workgroups.
+int gemm_pick_tile(const GemmArgs& a) {
+    static const int forced = [] {
+        const char* e = std::getenv("DLIMGEDIT_GEMM_TILE");      // tuning aid, not a user knob
+        return e ? std::atoi(e) : -1;
+    }();
+    auto tiles = [&](int bm, int bn) { return (a.M % bm || a.N % bn) ? 0 : (a.M / bm) * (a.N / bn); };
+    const int t[4] = {tiles(128, 128), tiles(128, 96), tiles(128, 64), tiles(64, 64)};
+    if (forced >= 0 && forced < 4 && t[forced] > 0) return forced;
+    if (t[0] >= 512) return 0;
+    if (t[1] >= 256) return 1;
+    if (t[0] >= 256) return 0;
+    if (t[2] >= 256) return 2;
+    if (t[3] > 0) return 3;
+    return t[2] > 0 ? 2 : (t[1] > 0 ? 1 : 0);
+}
+
 void gemm(const GemmArgs& a, hipStream_t s) {
     if (const char* err = gemm_check(a)) throw_error(err);
-    auto tiles = [&](int bm, int bn) { return (a.M % bm || a.N % bn) ? 0 : (a.M / bm) * (a.N / bn); };
-    if (tiles(128, 128) >= 256) return launch<128, 128>(a, s);
-    if (tiles(128, 64) >= 256) return launch<128, 64>(a, s);
-    return launch<64, 64>(a, s);
+    switch (gemm_pick_tile(a)) {
+    case 0: return launch<128, 128, 2, 2>(a, s);
+    case 1: return launch<128, 96, 4, 1>(a, s);
+    case 2: return launch<128, 64, 2, 2>(a, s);
+    default: return launch<64, 64, 2, 2>(a, s);
+    }
 }
 
 }  // namespace k
