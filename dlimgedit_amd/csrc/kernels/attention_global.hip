@@ -28,7 +28,7 @@ constexpr int V_STRIDE = 96;        // elements per key row of the V tile (192 B
 constexpr int RELH_STRIDE = 32;     // floats: relh_lds[wave][ky][query]
 typedef short short4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) short4_t lds_short4_t;
-constexpr int GW_STRIDE = 97;       // floats per query row of the prologue scratch (96 rel rows + 1)
+constexpr int GW_STRIDE = 33;       // floats per query row of the prologue scratch (32 rel rows + 1)
 
 template <int HD>
 __global__ __launch_bounds__(256, 2) void attention_global_kernel(const half_t* __restrict__ qkv,
@@ -92,8 +92,10 @@ __global__ __launch_bounds__(256, 2) void attention_global_kernel(const half_t* 
             relh_lds[(wave * 64 + ky) * RELH_STRIDE + l31] = acc[r] * inv_scale;
         }
     }
-    // relw[i][kx] = q_i . rel_w[qx_i - kx + 63], rows rr = 0..95 <-> rel_w[qx0 + rr] (rows past 126 are zero)
+    // relw[i][kx] = q_i . rel_w[qx_i - kx + 63], rows rr = 0..95 <-> rel_w[qx0 + rr] (rows past 126 are zero),
+    // produced 32 rows at a time through a small per-wave scratch so the kernel keeps 2 workgroups per CU
     float* gw = scratch + wave * 32 * GW_STRIDE;
+    float16_t relw[2];          // accumulator layout: tile jt, register r <-> kx = jt*32 + acc_row(r, hi)
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         float16_t acc = zero16();
@@ -108,18 +110,18 @@ __global__ __launch_bounds__(256, 2) void attention_global_kernel(const half_t* 
             }
             acc = mfma32(rf, qf[ks], acc);
         }
+        __syncthreads();        // previous chunk fully consumed
 #pragma unroll
-        for (int r = 0; r < 16; ++r) gw[l31 * GW_STRIDE + t * 32 + acc_row(r, hi)] = acc[r];
+        for (int r = 0; r < 16; ++r) gw[l31 * GW_STRIDE + acc_row(r, hi)] = acc[r];
+        __syncthreads();
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = l31 - (jt * 32 + acc_row(r, hi)) + 63 - t * 32;      // row inside this chunk?
+                if (rr >= 0 && rr < 32) relw[jt][r] = gw[l31 * GW_STRIDE + rr] * inv_scale;
+            }
     }
-    __syncthreads();
-    float16_t relw[2];          // accumulator layout: tile jt, register r <-> kx = jt*32 + acc_row(r, hi)
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int kx = jt * 32 + acc_row(r, hi);
-            relw[jt][r] = gw[l31 * GW_STRIDE + l31 - kx + 63] * inv_scale;
-        }
     __syncthreads();            // scratch is dead; tile buffers may be written
 
     // ---- K/V tile staging ------------------------------------------------------------------------

@@ -15,7 +15,9 @@
 // Per wave:   G   = rel_pos . Q^T   (MFMA, 27 rows each for h and w)  -> per-lane bias registers
 //             S^T = K . Q^T + bias/scale   (swapped operands: a lane owns one query column)
 //             softmax over the 224 key slots entirely in registers (+ one exchange between halves)
-//             O   = P . V   with the accumulator tiles re-used directly as the A operand.
+//             O   = P . V   with the accumulator tiles re-used directly as the A operand and V read
+//                           through ds_read_b64_tr_b16 from its row-major LDS image.
+// LDS: the rel-pos scratch of the prologue aliases the K/V images (75 KB total -> 2 workgroups per CU).
 #include "device_common.hpp"
 #include "kernels.hpp"
 
@@ -26,8 +28,10 @@ constexpr int WS = 14;            // window size
 constexpr int SLOTS = 224;        // 14 rows x 16 (14 real + 2 dummy) columns
 constexpr int NW = 5;             // windows per axis (70 / 14)
 constexpr int GRID = 64;
-constexpr int VT_STRIDE = 228;    // elements per row of the transposed V image (456 B: conflict-free ds_read_b64)
+constexpr int V_STRIDE = 96;      // elements per key row of the V image (192 B: conflict-free ds_read_b64_tr_b16)
 constexpr int G_STRIDE = 33;      // floats per row of the per-wave rel-pos scratch
+typedef short short4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) short4_t lds_short4_t;
 
 struct WinSlot { int token; bool dummy; bool pad; };
 
@@ -52,11 +56,12 @@ __global__ __launch_bounds__(448) void attention_window_kernel(const half_t* __r
     constexpr int DT = (HD + 31) / 32;          // 32-wide output tiles over the head dimension
     constexpr int K_STRIDE = HD + 8;            // elements; +16 B keeps ds_read_b128 conflict-free
     constexpr int CHUNKS = HD / 8;              // 16-byte chunks per row
+    static_assert(DT * 32 <= V_STRIDE, "head dimension tiles must fit the padded V row");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* lds_k = reinterpret_cast<half_t*>(smem);                              // [224][K_STRIDE]
-    half_t* lds_vt = lds_k + SLOTS * K_STRIDE;                                    // [DT*32][VT_STRIDE]
-    float* lds_g = reinterpret_cast<float*>(lds_vt + DT * 32 * VT_STRIDE);        // [7 waves][32][G_STRIDE]
+    half_t* lds_v = lds_k + SLOTS * K_STRIDE;                                     // [224][V_STRIDE]
+    float* lds_g = reinterpret_cast<float*>(smem);          // prologue only: [7 waves][32][G_STRIDE]
 
     const int D = heads * HD;
     const int ld = 3 * D;
@@ -69,33 +74,6 @@ __global__ __launch_bounds__(448) void attention_window_kernel(const half_t* __r
     const int lane = lane_id();
     const int wave = wave_id();
     const int hi = lane >> 5, l31 = lane & 31;
-
-    // ---- stage K (row-major, padded rows) and V (transposed) of the whole window --------------
-    for (int idx = tid; idx < DT * 32 * VT_STRIDE / 2; idx += 448)              // zero V^T incl. pad rows
-        reinterpret_cast<uint32_t*>(lds_vt)[idx] = 0u;
-    __syncthreads();
-    for (int idx = tid; idx < SLOTS * CHUNKS; idx += 448) {
-        // consecutive threads take consecutive slots of one chunk: V^T writes land in adjacent halves
-        const int slot = idx % SLOTS, ch = idx / SLOTS;
-        const WinSlot ws = win_slot(slot, wy, wx);
-        half8_t kv = zero_h8(), vv = zero_h8();
-        if (!ws.dummy) {
-            if (ws.pad) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    kv[e] = (half_t)qkv_bias[D + head * HD + ch * 8 + e];
-                    vv[e] = (half_t)qkv_bias[2 * D + head * HD + ch * 8 + e];
-                }
-            } else {
-                const half_t* row = base + (size_t)ws.token * ld + head * HD + ch * 8;
-                kv = *reinterpret_cast<const half8_t*>(row + D);
-                vv = *reinterpret_cast<const half8_t*>(row + 2 * D);
-            }
-        }
-        *reinterpret_cast<half8_t*>(lds_k + slot * K_STRIDE + ch * 8) = kv;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) lds_vt[(ch * 8 + e) * VT_STRIDE + slot] = vv[e];
-    }
 
     // ---- this wave's 32 queries as B-operand fragments ------------------------------------------
     const int qslot = wave * 32 + l31;
@@ -152,8 +130,37 @@ __global__ __launch_bounds__(448) void attention_window_kernel(const half_t* __r
             // dummy key columns (tx >= 14) are removed from the softmax by a -inf bias
             bw[e] = tx < WS ? g[l31 * G_STRIDE + tx_q + (WS - 1) - tx] : -INFINITY;
         }
+        __syncthreads();        // scratch is dead; K / V images may be written over it
     }
-    // (the barriers above also published the K / V^T images)
+
+    // ---- stage K and V (both row-major, padded rows) of the whole window -------------------------
+    // consecutive threads take consecutive 16-byte chunks of one slot: whole global lines per request
+    for (int idx = tid; idx < SLOTS * CHUNKS; idx += 448) {
+        const int slot = idx / CHUNKS, ch = idx % CHUNKS;
+        const WinSlot ws = win_slot(slot, wy, wx);
+        half8_t kv = zero_h8(), vv = zero_h8();
+        if (!ws.dummy) {
+            if (ws.pad) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    kv[e] = (half_t)qkv_bias[D + head * HD + ch * 8 + e];
+                    vv[e] = (half_t)qkv_bias[2 * D + head * HD + ch * 8 + e];
+                }
+            } else {
+                const half_t* row = base + (size_t)ws.token * ld + head * HD + ch * 8;
+                kv = *reinterpret_cast<const half8_t*>(row + D);
+                vv = *reinterpret_cast<const half8_t*>(row + 2 * D);
+            }
+        }
+        *reinterpret_cast<half8_t*>(lds_k + slot * K_STRIDE + ch * 8) = kv;
+        *reinterpret_cast<half8_t*>(lds_v + slot * V_STRIDE + ch * 8) = vv;
+    }
+    if (DT * 32 > HD) {         // V columns beyond the head dimension must not hold NaN patterns
+        constexpr int PADC = (DT * 32 - HD) / 8;
+        for (int idx = tid; idx < SLOTS * PADC; idx += 448)
+            *reinterpret_cast<half8_t*>(lds_v + (idx / PADC) * V_STRIDE + HD + (idx % PADC) * 8) = zero_h8();
+    }
+    __syncthreads();
 
     const float scale = rsqrtf((float)HD);
     const float inv_scale = sqrtf((float)HD);
@@ -188,14 +195,16 @@ __global__ __launch_bounds__(448) void attention_window_kernel(const half_t* __r
     for (int jt = 0; jt < 7; ++jt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float p = exp2f((s[jt][r] - m) * c);
+            float p = __builtin_amdgcn_exp2f((s[jt][r] - m) * c);
             s[jt][r] = p;
             l += p;
         }
     l += swap_halves(l);
     const float inv_l = 1.0f / l;
 
-    // ---- O = P . V : accumulator tiles become A operands (k order permuted identically on V^T) ----
+    // ---- O = P . V : accumulator tiles become A operands; V^T fragments by hardware transpose read ----
+    // in each 16-lane group, lane 4q+p points at key row q, columns 4p..4p+3 of a 4-key x 16-column block
+    const half_t* vb = lds_v + ((hi * 4 + ((lane & 15) >> 2)) * V_STRIDE) + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
     float16_t o[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) o[dt] = zero16();
@@ -206,13 +215,14 @@ __global__ __launch_bounds__(448) void attention_window_kernel(const half_t* __r
             half8_t pf;
 #pragma unroll
             for (int e = 0; e < 8; ++e) pf[e] = (half_t)(s[jt][st * 8 + e] * inv_l);
-            const int key0 = jt * 32 + st * 16 + hi * 4;        // element e <-> key0 + 8*(e>>2) + (e&3)
+            const int key0 = jt * 32 + st * 16;         // element e <-> key0 + 4*hi + 8*(e>>2) + (e&3)
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const half_t* vrow = lds_vt + (dt * 32 + l31) * VT_STRIDE + key0;
-                half4_t v0 = *reinterpret_cast<const half4_t*>(vrow);
-                half4_t v1 = *reinterpret_cast<const half4_t*>(vrow + 8);
-                half8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                const half_t* vp = vb + key0 * V_STRIDE + dt * 32;
+                const short4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_t*)vp);
+                const short4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_t*)(vp + 8 * V_STRIDE));
+                const half4_t h0 = __builtin_bit_cast(half4_t, v0), h1 = __builtin_bit_cast(half4_t, v1);
+                half8_t vf = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
                 o[dt] = mfma32(pf, vf, o[dt]);
             }
         }
@@ -235,8 +245,9 @@ __global__ __launch_bounds__(448) void attention_window_kernel(const half_t* __r
 template <int HD>
 void launch_window(const half_t* qkv, const float* bias, const float* rel_h, const float* rel_w, half_t* out, int B,
                    int heads, hipStream_t s) {
-    constexpr int DT = (HD + 31) / 32;
-    const size_t lds = (size_t)SLOTS * (HD + 8) * 2 + (size_t)DT * 32 * VT_STRIDE * 2 + 7 * 32 * G_STRIDE * 4;
+    const size_t images = (size_t)SLOTS * (HD + 8) * 2 + (size_t)SLOTS * V_STRIDE * 2;
+    const size_t scratch = 7 * 32 * G_STRIDE * 4;
+    const size_t lds = images > scratch ? images : scratch;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)attention_window_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize,
