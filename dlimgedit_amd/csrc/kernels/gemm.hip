@@ -7,8 +7,9 @@
 // Both operands are K-contiguous (activations row-major, weights in nn.Linear [out,in] layout), so
 // an MFMA fragment is one 16-byte LDS read.  Structure per workgroup (4 waves, WGM x WGN):
 //   * BM x BN output tile, BK = 64; each wave owns a (BM/WGM) x (BN/WGN) sub-tile of 32x32 MFMA tiles
-//   * operand tiles go HBM -> LDS with global_load_lds (16 B/lane, no VGPR round trip), two LDS
-//     buffers, tile k+1 in flight while tile k feeds the MFMAs, one barrier per K-tile
+//   * operand tiles go HBM -> LDS with global_load_lds (16 B/lane, no VGPR round trip) through a ring
+//     of 2-4 LDS stages: up to 3 K-tiles in flight behind a counted s_waitcnt vmcnt(N) and ONE raw
+//     s_barrier per K-tile (never vmcnt(0) in the steady state)
 //   * LDS image is lane-linear (a DMA wave-instruction writes 8 rows x 128 B); the bank-conflict
 //     swizzle chunk ^= (row>>1)&7 is applied on the per-lane SOURCE address and again on the read
 //     (cdna_hip_programming.md rule 21), making every ds_read_b128 group conflict-free
@@ -66,16 +67,25 @@ DLIMG_DEVICE float gelu_fast(float x) {
     return 0.5f * x * (1.0f + copysignf(e, x));
 }
 
-template <int BM, int BN, int WGM, int WGN, int ACT>
+// vmcnt(N): wait until at most N of this wave's DMA copies are still in flight
+template <int N> DLIMG_DEVICE void wait_dma() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// ABL (tuning builds only): 0 = real kernel, 1 = no MFMA / fragment reads (operand streaming alone),
+// 2 = no operand streaming after the first tile (MFMA + LDS reads alone).  Outputs are wrong for ABL != 0.
+template <int BM, int BN, int WGM, int WGN, int NSTAGE, int ACT, int ABL = 0>
 __global__ __launch_bounds__(256) void gemm_f16_kernel(k::GemmArgs a) {
     static_assert(WGM * WGN == 4, "four waves per workgroup");
+    static_assert(NSTAGE >= 2 && NSTAGE <= 4, "2..4 LDS stages");
     constexpr int WM = BM / WGM, WN = BN / WGN;     // wave tile
     constexpr int TM = WM / 32, TN = WN / 32;       // 32x32 MFMA tiles per wave
     constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
-    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;  // buffer b: A tile at b*STAGE_BYTES, B tile behind it
-    constexpr int CHUNKS = WN / 4;                  // 16-byte column chunks per row of the wave's output tile
-    constexpr int OUT_BYTES = WM * WN * 4;          // per-wave fp32 staging of the output tile
-    static_assert(4 * OUT_BYTES <= 2 * STAGE_BYTES, "output staging must fit in the operand buffers");
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;  // stage b: A tile at b*STAGE_BYTES, B tile behind it
+    constexpr int LOADS = (BM + BN) / 32;           // DMA wave-instructions per wave per K-tile
+    // epilogue staging: JG column tiles (JG*32 columns) of the wave tile at a time
+    constexpr int JG = (TN % 3 == 0) ? 3 : ((TN % 2 == 0) ? 2 : 1);
+    constexpr int CHUNKS = JG * 8;                  // 16-byte column chunks per staged row
+    constexpr int OUT_BYTES = WM * CHUNKS * 16;     // per-wave fp32 staging
+    static_assert(4 * OUT_BYTES <= NSTAGE * STAGE_BYTES, "output staging must fit in the operand buffers");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = lane_id();
@@ -95,19 +105,26 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(k::GemmArgs a) {
         for (int j = 0; j < TN; ++j) acc[i][j] = zero16();
 
     const int nk = a.K / BK;
-    stage_tile<BM>(a.A, a.lda, m0, 0, smem, wave, lane);
-    stage_tile<BN>(a.W, a.ldw, n0, 0, smem + A_BYTES, wave, lane);
+    auto stage = [&](int kt) {
+        char* dst = smem + (kt % NSTAGE) * STAGE_BYTES;
+        stage_tile<BM>(a.A, a.lda, m0, kt * BK, dst, wave, lane);
+        stage_tile<BN>(a.W, a.ldw, n0, kt * BK, dst + A_BYTES, wave, lane);
+    };
+    // prologue: NSTAGE-1 tiles in flight
+#pragma unroll
+    for (int t = 0; t < NSTAGE - 1; ++t)
+        if (t < nk) stage(t);
 
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                         // tile kt landed; everyone is done with buf cur^1
-        if (kt + 1 < nk) {
-            char* nxt = smem + (cur ^ 1) * STAGE_BYTES;
-            stage_tile<BM>(a.A, a.lda, m0, (kt + 1) * BK, nxt, wave, lane);
-            stage_tile<BN>(a.W, a.ldw, n0, (kt + 1) * BK, nxt + A_BYTES, wave, lane);
-        }
-        const char* la = smem + cur * STAGE_BYTES;
+        // tile kt has landed once at most `later` newer tiles of this wave are still in flight
+        const int later = min(NSTAGE - 2, nk - 1 - kt);
+        if (later >= 2) wait_dma<2 * LOADS>();
+        else if (later == 1) wait_dma<LOADS>();
+        else wait_dma<0>();
+        __builtin_amdgcn_s_barrier();            // ... for every wave; and everyone is done reading stage (kt-1)%NSTAGE
+        if (kt + NSTAGE - 1 < nk && ABL != 2) stage(kt + NSTAGE - 1);
+        if (ABL == 1) continue;
+        const char* la = smem + (kt % NSTAGE) * STAGE_BYTES;
         const char* lb = la + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
@@ -124,55 +141,72 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(k::GemmArgs a) {
         }
     }
 
-    // ---- epilogue: accumulators -> LDS (row-major wave tile, chunk ^= row&7) -> coalesced rows ----
+    // ---- epilogue: accumulators -> LDS (row-major slab, chunk ^= row&7) -> coalesced rows -----------
     __syncthreads();                             // operand buffers are dead for every wave
-    char* stage = smem + wave * OUT_BYTES;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row = i * 32 + l31;
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int chunk = j * 8 + g4 * 2 + hi;          // columns 4*chunk .. 4*chunk+3
-                float4_t v = {acc[i][j][g4 * 4 + 0], acc[i][j][g4 * 4 + 1], acc[i][j][g4 * 4 + 2],
-                              acc[i][j][g4 * 4 + 3]};
-                *reinterpret_cast<float4_t*>(stage + (row * CHUNKS + (chunk ^ (row & 7))) * 16) = v;
-            }
-    }
-    // each wave reads back only what it wrote itself: wave-local ordering is enough
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    char* slab = smem + wave * OUT_BYTES;
     constexpr int ITEMS = WM * CHUNKS;
-    static_assert(ITEMS % 64 == 0, "wave tile must split evenly over 64 lanes");
-#pragma unroll 4
-    for (int it = 0; it < ITEMS / 64; ++it) {
-        const int idx = it * 64 + lane;
-        const int row = idx / CHUNKS, chunk = idx % CHUNKS;
-        float4_t v = *reinterpret_cast<const float4_t*>(stage + (row * CHUNKS + (chunk ^ (row & 7))) * 16);
-        const int m = m0 + wr * WM + row;
-        const int n = n0 + wc * WN + chunk * 4;
-        if (a.bias) v += *reinterpret_cast<const float4_t*>(a.bias + n);
-        if (ACT == k::ACT_GELU) {
+    static_assert(ITEMS % 64 == 0, "staged slab must split evenly over 64 lanes");
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
+    for (int jg = 0; jg < TN / JG; ++jg) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = i * 32 + l31;
+#pragma unroll
+            for (int jj = 0; jj < JG; ++jj)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int chunk = jj * 8 + g4 * 2 + hi;         // columns 4*chunk .. 4*chunk+3 of the slab
+                    const float16_t& t = acc[i][jg * JG + jj];
+                    float4_t v = {t[g4 * 4 + 0], t[g4 * 4 + 1], t[g4 * 4 + 2], t[g4 * 4 + 3]};
+                    *reinterpret_cast<float4_t*>(slab + (row * CHUNKS + (chunk ^ (row & 7))) * 16) = v;
+                }
         }
-        if (a.resid) v += *reinterpret_cast<const float4_t*>(a.resid + (size_t)(m % a.resid_mod) * a.ldr + n);
-        if (a.out_f32) *reinterpret_cast<float4_t*>(a.out_f32 + (size_t)m * a.ldc32 + n) = v;
-        if (a.out_h) {
-            half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-            *reinterpret_cast<half4_t*>(a.out_h + (size_t)m * a.ldc16 + n) = h;
+        // each wave reads back only what it wrote itself: wave-local ordering is enough
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 4
+        for (int it = 0; it < ITEMS / 64; ++it) {
+            const int idx = it * 64 + lane;
+            const int row = idx / CHUNKS, chunk = idx % CHUNKS;
+            float4_t v = *reinterpret_cast<const float4_t*>(slab + (row * CHUNKS + (chunk ^ (row & 7))) * 16);
+            const int m = m0 + wr * WM + row;
+            const int n = n0 + wc * WN + jg * JG * 32 + chunk * 4;
+            if (a.bias) v += *reinterpret_cast<const float4_t*>(a.bias + n);
+            if (ACT == k::ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
+            }
+            if (a.resid) v += *reinterpret_cast<const float4_t*>(a.resid + (size_t)(m % a.resid_mod) * a.ldr + n);
+            if (a.out_f32) *reinterpret_cast<float4_t*>(a.out_f32 + (size_t)m * a.ldc32 + n) = v;
+            if (a.out_h) {
+                half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                *reinterpret_cast<half4_t*>(a.out_h + (size_t)m * a.ldc16 + n) = h;
+            }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // slab reads done before the next group overwrites it
     }
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int NSTAGE>
 void launch(const k::GemmArgs& a, hipStream_t s) {
     const int grid = (a.M / BM) * (a.N / BN);
-    const size_t lds = 2 * (BM + BN) * ROW_BYTES;
+    const size_t lds = (size_t)NSTAGE * (BM + BN) * ROW_BYTES;
+    auto k0 = gemm_f16_kernel<BM, BN, WGM, WGN, NSTAGE, k::ACT_NONE>;
+    auto k1 = gemm_f16_kernel<BM, BN, WGM, WGN, NSTAGE, k::ACT_GELU>;
+    static const int ablate = [] { const char* e = std::getenv("DLIMGEDIT_GEMM_ABLATE"); return e ? std::atoi(e) : 0; }();
+    if (ablate == 1) k0 = gemm_f16_kernel<BM, BN, WGM, WGN, NSTAGE, k::ACT_NONE, 1>;
+    if (ablate == 2) k0 = gemm_f16_kernel<BM, BN, WGM, WGN, NSTAGE, k::ACT_NONE, 2>;
+    if (lds > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+    }
     if (a.act == k::ACT_GELU)
-        hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WGM, WGN, k::ACT_GELU>), dim3(grid), dim3(256), lds, s, a);
+        hipLaunchKernelGGL(k1, dim3(grid), dim3(256), lds, s, a);
     else
-        hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WGM, WGN, k::ACT_NONE>), dim3(grid), dim3(256), lds, s, a);
+        hipLaunchKernelGGL(k0, dim3(grid), dim3(256), lds, s, a);
 }
 
 }  // namespace
@@ -194,32 +228,50 @@ const char* gemm_check(const GemmArgs& a) {
     return nullptr;
 }
 
-// Tile choice for the 256 CUs of an MI355X.  0: 128x128 (2x2 waves), 1: 128x96 (4x1), 2: 128x64 (2x2),
-// 3: 64x64 (2x2).  Prefer the largest tile that still gives every CU at least one workgroup; 128x96
-// makes N = 768 (ViT-B proj/fc2 at batch 1: M = 4096) exactly 256 workgroups.
+// Tile configurations.  At batch 1 (M = 4096) a GEMM is only a few hundred workgroups, so what matters
+// is how evenly they cover the 256 CUs: every configuration is scored by (fill of the last round of
+// workgroup slots) x (relative efficiency of the tile) and the best one is launched.
+struct TileCfg { int bm, bn, per_cu; float eff; };
+constexpr TileCfg kTiles[] = {
+    {128, 384, 1, 1.00f},   // 0: 2x2 waves (64x192 each), 2 stages, 128 KB LDS
+    {128, 288, 1, 1.00f},   // 1: 4x1 waves (32x288 each), 3 stages, 156 KB LDS
+    {128, 128, 2, 0.80f},   // 2: 2x2 waves, 2 stages, 64 KB LDS
+    {128, 96, 1, 0.70f},    // 3: 4x1 waves, 4 stages, 112 KB LDS
+    {128, 64, 3, 0.55f},    // 4: 2x2 waves, 2 stages, 48 KB LDS
+    {64, 64, 4, 0.40f},     // 5: 2x2 waves, 2 stages, 32 KB LDS
+};
+constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
+
 int gemm_pick_tile(const GemmArgs& a) {
     static const int forced = [] {
         const char* e = std::getenv("DLIMGEDIT_GEMM_TILE");      // tuning aid, not a user knob
         return e ? std::atoi(e) : -1;
     }();
-    auto tiles = [&](int bm, int bn) { return (a.M % bm || a.N % bn) ? 0 : (a.M / bm) * (a.N / bn); };
-    const int t[4] = {tiles(128, 128), tiles(128, 96), tiles(128, 64), tiles(64, 64)};
-    if (forced >= 0 && forced < 4 && t[forced] > 0) return forced;
-    if (t[0] >= 512) return 0;
-    if (t[1] >= 256) return 1;
-    if (t[0] >= 256) return 0;
-    if (t[2] >= 256) return 2;
-    if (t[3] > 0) return 3;
-    return t[2] > 0 ? 2 : (t[1] > 0 ? 1 : 0);
+    int best = -1;
+    float best_score = -1.f;
+    for (int i = 0; i < kNumTiles; ++i) {
+        const TileCfg& t = kTiles[i];
+        if (a.M % t.bm || a.N % t.bn) continue;
+        if (i == forced) return i;
+        const int blocks = (a.M / t.bm) * (a.N / t.bn);
+        const int slots = 256 * t.per_cu;
+        const int rounds = (blocks + slots - 1) / slots;
+        const float score = t.eff * (float)blocks / (float)(rounds * slots);
+        if (score > best_score) { best_score = score; best = i; }
+    }
+    return best;
 }
 
 void gemm(const GemmArgs& a, hipStream_t s) {
     if (const char* err = gemm_check(a)) throw_error(err);
     switch (gemm_pick_tile(a)) {
-    case 0: return launch<128, 128, 2, 2>(a, s);
-    case 1: return launch<128, 96, 4, 1>(a, s);
-    case 2: return launch<128, 64, 2, 2>(a, s);
-    default: return launch<64, 64, 2, 2>(a, s);
+    case 0: return launch<128, 384, 2, 2, 2>(a, s);
+    case 1: return launch<128, 288, 4, 1, 3>(a, s);
+    case 2: return launch<128, 128, 2, 2, 2>(a, s);
+    case 3: return launch<128, 96, 4, 1, 4>(a, s);
+    case 4: return launch<128, 64, 2, 2, 2>(a, s);
+    case 5: return launch<64, 64, 2, 2, 2>(a, s);
+    default: throw_error("gemm: no tile configuration fits this shape");
     }
 }
 
