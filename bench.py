@@ -82,7 +82,7 @@ def main() -> None:
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from dlimgedit_amd import api, weights as W
+    from dlimgedit_amd import api, sharding, weights as W
     from dlimgedit_amd.sam_config import get_config
 
     cfg = get_config(args.model)
@@ -132,11 +132,8 @@ def main() -> None:
         step()
     ext.synchronize(env)
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = sharding.max_over_ranks(time.perf_counter() - t0, device="cuda")
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         dist.barrier()
 
     result = None

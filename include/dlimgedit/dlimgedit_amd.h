@@ -12,6 +12,8 @@
 
 #include "dlimgedit.h"
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif

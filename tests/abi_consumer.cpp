@@ -1,0 +1,80 @@
+// Drop-in proof: a consumer written against the REFERENCE's public C++ wrapper
+// (<dlimgedit/dlimgedit.hpp> from the upstream source tree, header-only, DLIMGEDIT_LOAD_DYNAMIC)
+// that loads THIS repository's libdlimgedit.so at run time.  Built by oracle/build_ref.py with
+// -I/root/reference/src/include into oracle/_ref/abi_consumer; nothing of the reference is copied.
+//
+//   abi_consumer <libdlimgedit.so> probe
+//   abi_consumer <libdlimgedit.so> run <model_dir> <rgba.raw> <w> <h> <px> <py> <out_mask.raw>
+#define DLIMGEDIT_LOAD_DYNAMIC
+#include <dlimgedit/dlimgedit.hpp>
+
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+static int fail(const char* what) {
+    std::fprintf(stderr, "abi_consumer: %s\n", what);
+    return 2;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 3) return fail("usage: abi_consumer <lib> probe|run ...");
+    void* lib = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
+    if (!lib) return fail(dlerror());
+    using InitFn = dlimg_Api const* (*)();
+    auto init = reinterpret_cast<InitFn>(dlsym(lib, "dlimg_init"));
+    if (!init) return fail("dlimg_init not exported");
+    dlimg::initialize(init());
+
+    std::string mode = argv[2];
+    if (mode == "probe") {
+        std::printf("cpu=%d gpu=%d\n", int(dlimg::Environment::is_supported(dlimg::Backend::cpu)),
+                    int(dlimg::Environment::is_supported(dlimg::Backend::gpu)));
+        {
+            dlimg::Image img(dlimg::Extent{8, 6}, dlimg::Channels::bgra);
+            std::memset(img.pixels(), 7, img.size());
+            std::printf("image size=%zu\n", img.size());
+        }
+        try {
+            dlimg::Options opts;
+            opts.backend = dlimg::Backend::gpu;
+            opts.model_directory = "/definitely/not/here";
+            dlimg::Environment env(opts);
+            return fail("expected an exception for a missing model directory");
+        } catch (dlimg::Exception const& e) {
+            std::printf("error=%s\n", e.what());
+        }
+        return 0;
+    }
+    if (mode == "run") {
+        if (argc != 10) return fail("run needs <model_dir> <rgba.raw> <w> <h> <px> <py> <out_mask.raw>");
+        const int w = std::atoi(argv[5]), h = std::atoi(argv[6]);
+        std::vector<uint8_t> pixels(size_t(w) * h * 4);
+        std::ifstream in(argv[4], std::ios::binary);
+        if (!in.read(reinterpret_cast<char*>(pixels.data()), std::streamsize(pixels.size()))) return fail("short image file");
+        try {
+            dlimg::Options opts;
+            opts.backend = dlimg::Backend::gpu;
+            opts.model_directory = argv[3];
+            dlimg::Environment env(opts);
+            auto view = dlimg::ImageView(pixels.data(), dlimg::Extent{w, h}, dlimg::Channels::rgba);
+            auto seg = dlimg::Segmentation::process(view, env);
+            std::printf("extent=%dx%d\n", seg.extent().width, seg.extent().height);
+            dlimg::Image mask = seg.compute_mask(dlimg::Point{std::atoi(argv[7]), std::atoi(argv[8])});
+            auto masks = seg.compute_masks(dlimg::Point{std::atoi(argv[7]), std::atoi(argv[8])});
+            std::printf("accuracy=%.6f %.6f %.6f\n", masks[0].accuracy, masks[1].accuracy, masks[2].accuracy);
+            std::ofstream out(argv[9], std::ios::binary);
+            out.write(reinterpret_cast<const char*>(mask.pixels()), std::streamsize(mask.size()));
+        } catch (dlimg::Exception const& e) {
+            std::fprintf(stderr, "dlimg::Exception: %s\n", e.what());
+            return 3;
+        }
+        return 0;
+    }
+    return fail("unknown mode");
+}

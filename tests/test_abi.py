@@ -1,0 +1,149 @@
+"""Drop-in boundary checks that need no GPU: the library loads, exports what include/*.h declares,
+the POD layouts match the reference's, and the non-throwing entry points behave."""
+import ctypes as C
+import re
+import shutil
+import subprocess
+import sys
+import threading
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+INCLUDE = ROOT / "include"
+
+
+@pytest.fixture(scope="module")
+def api():
+    from dlimgedit_amd.build import build
+    build()                                   # hipcc cross-compiles without a GPU
+    from dlimgedit_amd import api
+    return api
+
+
+def test_library_exports_every_declared_symbol(api):
+    lib = api.library()
+    declared = set()
+    for header in INCLUDE.rglob("*.h"):
+        text = header.read_text()
+        declared |= set(re.findall(r"DLIMG_API\s+[\w\s\*]+?\b(dlimg_\w+)\s*\(", text))
+    assert "dlimg_init" in declared and len(declared) >= 15
+    assert declared == {"dlimg_init", *api.ext.EXPORTS}, "python binding and header disagree"
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_only_dlimg_symbols_are_exported():
+    out = subprocess.run(["nm", "-D", "--defined-only", str(ROOT / "dlimgedit_amd" / "lib" / "libdlimgedit.so")],
+                         capture_output=True, text=True, check=True).stdout
+    names = [l.split()[-1] for l in out.splitlines() if " T " in l]
+    assert names and all(n.startswith("dlimg_") for n in names), names
+
+
+def test_pod_layouts_match_reference(api):
+    """dlimg_ImageView 24 B (pixels@16), dlimg_Options 16 B (model_directory@8), 13 reference slots."""
+    assert C.sizeof(api._ImageView) == 24 and api._ImageView.pixels.offset == 16
+    assert api._ImageView.stride.offset == 12 and api._ImageView.channels.offset == 8
+    assert C.sizeof(api._Options) == 16 and api._Options.model_directory.offset == 8
+    names = [n for n, _ in api._API_FIELDS]
+    assert names[:13] == ["is_backend_supported", "create_environment", "destroy_environment",
+                          "process_image_for_segmentation", "get_segmentation_mask", "get_segmentation_extent",
+                          "destroy_segmentation", "segment_objects", "load_image", "save_image", "create_image",
+                          "destroy_image", "last_error"]
+    assert api.REFERENCE_SLOTS == 13 and C.sizeof(api._Api) == 8 * len(names)
+    table = api.api()
+    for n in names:
+        assert getattr(table, n), f"slot {n} is null"
+
+
+def test_header_is_valid_c_and_cpp(tmp_path):
+    cc = shutil.which("gcc")
+    src = tmp_path / "t.c"
+    src.write_text('#include <dlimgedit/dlimgedit_amd.h>\n'
+                   '_Static_assert(sizeof(dlimg_ImageView) == 24, "view");\n'
+                   '_Static_assert(sizeof(dlimg_Options) == 16, "options");\n'
+                   '_Static_assert(sizeof(dlimg_Api) == 15 * sizeof(void*), "table");\n'
+                   'int main(void) { dlimg_Api const* a = 0; (void)a; return 0; }\n')
+    subprocess.run([cc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", f"-I{INCLUDE}", str(src)], check=True)
+    cpp = tmp_path / "t.cpp"
+    cpp.write_text('#include <dlimgedit/dlimgedit.hpp>\nint main() { return dlimg::count(dlimg::Channels::bgra) == 4 ? 0 : 1; }\n')
+    subprocess.run([shutil.which("g++"), "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", f"-I{INCLUDE}", str(cpp)],
+                   check=True)
+
+
+def test_init_is_idempotent(api):
+    lib = api.library()
+    assert C.addressof(lib.dlimg_init().contents) == C.addressof(lib.dlimg_init().contents)
+
+
+def test_backend_probe_never_throws(api):
+    assert api.Environment.is_supported(api.Backend.cpu) is False     # no CPU execution path in this build
+    assert api.Environment.is_supported(api.Backend.gpu) in (True, False)
+    assert api.ext.device_count() >= 0
+
+
+def test_create_and_destroy_image(api):
+    img = api.Image(api.Extent(8, 6), api.Channels.bgra)
+    assert img.size() == 8 * 6 * 4 and img.pixels().shape == (6, 8, 4)
+    img.pixels()[:] = 9
+    assert api.api().create_image(0, 4, 4) is None
+
+
+def test_environment_errors_are_reported_through_last_error(api, tmp_path):
+    with pytest.raises(api.Error, match="does not exist"):
+        api.Environment(api.Options(api.Backend.gpu, str(tmp_path / "missing")))
+    f = tmp_path / "file"
+    f.write_text("x")
+    with pytest.raises(api.Error, match="is not a directory"):
+        api.Environment(api.Options(api.Backend.gpu, str(f)))
+    with pytest.raises(api.Error, match="CPU backend is not available"):
+        api.Environment(api.Options(api.Backend.cpu, str(tmp_path)))
+
+
+def test_out_of_scope_slots_fail_cleanly(api):
+    import numpy as np
+    with pytest.raises(api.Error, match="not part of the MI355X build"):
+        api.Image.load("nothing.png")
+    with pytest.raises(api.Error, match="not part of the MI355X build"):
+        api.Image.save(api.ImageView(np.zeros((2, 2, 4), np.uint8)), "x.png")
+
+
+def test_last_error_is_per_thread(api, tmp_path):
+    """The reference keeps one unsynchronised global string; here each thread sees its own message."""
+    seen = {}
+
+    def worker(name):
+        try:
+            api.Environment(api.Options(api.Backend.gpu, str(tmp_path / name)))
+        except api.Error as e:
+            seen[name] = str(e)
+
+    ts = [threading.Thread(target=worker, args=(f"dir{i}",)) for i in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for i in range(4):
+        assert f"dir{i}" in seen[f"dir{i}"]
+
+
+def test_missing_gpu_fails_loudly_not_silently(api, tmp_path):
+    """On a box without an MI355X the product path must raise; there is no CPU fallback."""
+    if api.Environment.is_supported(api.Backend.gpu):
+        pytest.skip("GPU present")
+    (tmp_path / "segmentation").mkdir()
+    with pytest.raises(api.Error, match="No supported GPU"):
+        api.Environment(api.Options(api.Backend.gpu, str(tmp_path)))
+
+
+def test_reference_wrapper_consumer_runs_against_this_library():
+    """A program compiled against the REFERENCE's header-only C++ wrapper drives this library."""
+    sys.path.insert(0, str(ROOT))
+    from oracle.build_ref import build_abi_consumer
+    exe = build_abi_consumer()
+    if exe is None:
+        pytest.skip("reference source tree not available")
+    r = subprocess.run([str(exe), str(ROOT / "dlimgedit_amd" / "lib" / "libdlimgedit.so"), "probe"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "cpu=0" in r.stdout and "image size=192" in r.stdout
+    assert "error=Model path /definitely/not/here does not exist" in r.stdout

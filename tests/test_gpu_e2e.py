@@ -159,3 +159,29 @@ def test_error_paths(api, session, tmp_path):
         api.Segmentation.process(api.ImageView(synthetic_image(0), api.Channels.rgba), empty)
     with pytest.raises(api.Error, match="not part of the MI355X build"):
         api.segment_objects(api.ImageView(synthetic_image(0), api.Channels.rgba), env)
+
+
+def test_reference_wrapper_consumer_end_to_end(api, session, model_dirs, tmp_path):
+    """A binary compiled ONLY against the reference's public C++ wrapper (oracle/_ref/abi_consumer, built in
+    the build container by oracle/build_ref.py) runs Segmentation::process / compute_mask(s) on this library
+    and gets the same mask as the Python binding."""
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    exe = root / "oracle" / "_ref" / "abi_consumer"
+    if not exe.exists():
+        pytest.skip("oracle/_ref/abi_consumer was not built (reference tree absent at build time)")
+    mdir, _, _ = model_dirs("vit_test")
+    _, _, _, img, seg, _ = session
+    raw = tmp_path / "img.raw"
+    raw.write_bytes(img.tobytes())
+    out = tmp_path / "mask.raw"
+    r = subprocess.run([str(exe), str(root / "dlimgedit_amd" / "lib" / "libdlimgedit.so"), "run", mdir, str(raw),
+                        "1024", "1024", "512", "512", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "extent=1024x1024" in r.stdout
+    got = np.frombuffer(out.read_bytes(), dtype=np.uint8).reshape(1024, 1024)
+    assert np.array_equal(got, seg.compute_mask(api.Point(512, 512)))
+    acc = [float(v) for v in r.stdout.split("accuracy=")[1].split()]
+    want = [m.accuracy for m in seg.compute_masks(api.Point(512, 512))]
+    assert np.allclose(acc, want, atol=1e-5)

@@ -1,0 +1,98 @@
+"""The reference's own known-answer tests for the host glue of the SAM path, restated against the
+CPU oracle (reference: test/test_segmentation.cpp:15-99).  These pin the oracle's glue functions."""
+import numpy as np
+import pytest
+
+from oracle import sam_oracle as O
+
+
+@pytest.mark.parametrize("w,h,max_side,expect", [
+    (13, 19, 26, (18, 26)), (13, 19, 10, (7, 10)),      # "height" sections
+    (19, 13, 26, (26, 18)), (19, 13, 10, (10, 7)),      # "width" sections
+])
+def test_resize_longest_side_extent(w, h, max_side, expect):
+    """ResizeLongestSide.resize (test_segmentation.cpp:15-46): target = int(dim*scale + 0.5)."""
+    assert O.ResizeLongestSide(max_side).target_extent(w, h) == expect
+
+
+def test_resize_longest_side_identity_at_1024():
+    rs = O.ResizeLongestSide(1024)
+    assert rs.target_extent(1024, 683) == (1024, 683) and rs.scale == 1
+
+
+def test_resize_longest_side_transform():
+    """test_segmentation.cpp:48-57."""
+    rs = O.ResizeLongestSide(20)
+    assert rs.target_extent(10, 10) == (20, 20)
+    assert rs.transform(0, 0) == (0, 0)
+    assert rs.transform(10, 10) == (20, 20)
+    assert rs.transform(2, 7) == (4, 14)
+
+
+@pytest.mark.parametrize("channels,nbytes,expected", [
+    (O.CH_RGBA, 4, (0, 1, 2, 4, 5, 32)),
+    (O.CH_RGB, 3, (0, 1, 2, 3, 4, 24)),
+    (O.CH_BGRA, 4, (2, 1, 0, 6, 5, 34)),
+    (O.CH_ARGB, 4, (1, 2, 3, 5, 6, 33)),
+])
+def test_create_image_tensor(channels, nbytes, expected):
+    """SAM.create_image_tensor (test_segmentation.cpp:59-83): 8x6 iota image."""
+    img = np.arange(8 * 6 * nbytes, dtype=np.uint8).reshape(6, 8, nbytes)
+    t = O.create_image_tensor(img, channels)
+    assert t.dtype == np.float32 and t.shape == (6, 8, 3)
+    got = (t[0, 0, 0], t[0, 0, 1], t[0, 0, 2], t[0, 1, 0], t[0, 1, 1], t[1, 0, 0])
+    assert got == tuple(float(e) for e in expected)
+
+
+def test_create_image_tensor_mask_replicates():
+    img = np.arange(12, dtype=np.uint8).reshape(3, 4)
+    t = O.create_image_tensor(img, O.CH_MASK)
+    assert np.array_equal(t[:, :, 0], t[:, :, 1]) and np.array_equal(t[:, :, 0], t[:, :, 2])
+
+
+def test_write_mask_image():
+    """SAM.write_mask_image (test_segmentation.cpp:85-99): strict > 0, cropped with the tensor's stride."""
+    vals = np.array([0.0, 0.0, 0.2, -3.1, 0.0, 5.5, 0.0, 0.7, 0.0, 0.9], dtype=np.float32).reshape(1, 1, 2, 5)
+    m = O.write_mask_image(vals, 0, (4, 2))
+    assert m.tolist() == [[0, 0, 255, 0], [255, 0, 255, 0]]
+
+
+def test_pack_prompt_point_and_region():
+    """segmentation.cpp:135-152: point -> labels (1,-1) with the (0,0) pad point; region -> labels (2,3)."""
+    rs = O.ResizeLongestSide(1024)
+    rs.target_extent(512, 512)          # scale 2
+    c, l = O.pack_prompt(rs, point=(320, 210))
+    assert c.tolist() == [[640, 420], [0, 0]] and l.tolist() == [1, -1]
+    c, l = O.pack_prompt(rs, region=(180, 110, 505, 330))
+    assert c.tolist() == [[360, 220], [1010, 660]] and l.tolist() == [2, 3]
+
+
+def test_coordinate_rounding_for_non_integer_scale():
+    rs = O.ResizeLongestSide(1024)
+    assert rs.target_extent(1800, 1200) == (1024, 683)
+    # int(486 * 0.5688889 + 0.5) etc.: coordinates are rounded to integers in the resized image
+    assert rs.transform(486, 722) == (276, 411)
+
+
+def test_select_single_mask_rule():
+    """SamOnnxModel.select_masks with 2 prompt tokens: token 0 gets -500 and loses unless far ahead."""
+    assert O.select_single(np.array([0.9, 0.1, 0.5, 0.3], np.float32), 2) == 2
+    assert O.select_single(np.array([600.0, 0.1, 0.5, 0.3], np.float32), 2) == 0
+    assert O.select_single(np.array([0.2, 0.7, 0.7, 0.1], np.float32), 2) == 1     # first maximum wins
+
+
+def test_preprocess_pads_with_zero_in_normalised_space():
+    img = np.full((2, 3, 3), 255, np.float32)
+    x = O.preprocess(img)
+    assert x.shape == (3, 1024, 1024)
+    assert np.all(x[:, 2:, :] == 0) and np.all(x[:, :, 3:] == 0)
+    assert np.allclose(x[:, 0, 0], (255 - O.PIXEL_MEAN) / O.PIXEL_STD)
+
+
+def test_patchify_order():
+    chw = np.arange(3 * 32 * 32, dtype=np.float32).reshape(3, 32, 32)
+    p = O.patchify(chw, 16)
+    assert p.shape == (4, 768)
+    # row 1 = patch (py 0, px 1); column c*256 + iy*16 + ix
+    assert p[1, 1 * 256 + 2 * 16 + 3] == chw[1, 2, 16 + 3]
+    assert p[2, 0] == chw[0, 16, 0]
