@@ -375,6 +375,7 @@ class ext:
                 "dlimg_amd_test_gemm": ([ci, ci, ci, vp, vp, vp, vp, ci, ci, vp, vp], ci),
                 "dlimg_amd_test_layernorm": ([vp, vp, vp, cf, ci, ci, ci, vp, vp], ci),
                 "dlimg_amd_test_attention": ([ci, vp, vp, vp, vp, ci, ci, ci, vp], ci),
+                "dlimg_amd_test_resize": ([vp, ci, ci, ci, ci, ci, ci, vp], ci),
                 "dlimg_amd_bench_gemm": ([ci, ci, ci, ci, ci, C.POINTER(C.c_double)], ci),
             }
             for name, (args, res) in sig.items():
@@ -387,7 +388,8 @@ class ext:
                "dlimg_amd_device_alloc", "dlimg_amd_device_free", "dlimg_amd_copy_to_device", "dlimg_amd_copy_to_host",
                "dlimg_amd_encode_and_mask", "dlimg_amd_encode_only", "dlimg_amd_synchronize", "dlimg_amd_set_profiling",
                "dlimg_amd_take_stage_stats", "dlimg_amd_test_preprocess", "dlimg_amd_test_postprocess",
-               "dlimg_amd_test_gemm", "dlimg_amd_test_layernorm", "dlimg_amd_test_attention", "dlimg_amd_bench_gemm")
+               "dlimg_amd_test_gemm", "dlimg_amd_test_layernorm", "dlimg_amd_test_attention", "dlimg_amd_test_resize",
+               "dlimg_amd_bench_gemm")
 
     @staticmethod
     def _ptr(a: Optional[np.ndarray]):
@@ -526,6 +528,16 @@ class ext:
         out = np.empty((batch * 4096, heads * hd), dtype=np.float16)
         _check(cls._l().dlimg_amd_test_attention(int(is_global), qkv.ctypes.data, cls._ptr(qkv_bias), rel_h.ctypes.data,
                                                  rel_w.ctypes.data, batch, heads, hd, out.ctypes.data))
+        return out
+
+    @classmethod
+    def test_resize(cls, pixels: np.ndarray, channels: Channels, out_w: int, out_h: int) -> np.ndarray:
+        pixels = np.ascontiguousarray(pixels)
+        h, w = pixels.shape[:2]
+        c = count(channels)
+        out = np.empty((out_h, out_w, c), dtype=np.uint8)
+        _check(cls._l().dlimg_amd_test_resize(pixels.ctypes.data, w, h, w * c, int(channels), out_w, out_h,
+                                              out.ctypes.data))
         return out
 
     @classmethod

@@ -26,6 +26,8 @@ SOURCES = [
     "kernels/attention_global.hip",
     "kernels/decoder.hip",
     "kernels/postprocess.hip",
+    "kernels/resize.hip",
+    "resize_tables.cpp",
     "weights.cpp",
     "sam_model.cpp",
     "environment.cpp",
@@ -33,6 +35,15 @@ SOURCES = [
     "dlimgedit.cpp",
     "ext_api.cpp",
 ]
+
+
+# Kernels whose results must be bit-identical to the CPU oracle are compiled without mul+add contraction
+# (HIP's default is -ffp-contract=fast, which also fuses the __fmul_rn/__fadd_rn header wrappers).
+EXTRA_FLAGS = {
+    "kernels/postprocess.hip": ["-ffp-contract=off"],
+    "kernels/resize.hip": ["-ffp-contract=off"],
+    "resize_tables.cpp": ["-ffp-contract=off"],
+}
 
 
 def hipcc() -> str:
@@ -59,7 +70,7 @@ def _compile(src: str, force: bool, hdr_mtime: float) -> Path:
     o = OBJ / (src.replace("/", "_") + ".o")
     if not force and o.exists() and o.stat().st_mtime > max(s.stat().st_mtime, hdr_mtime):
         return o
-    cmd = [hipcc(), *_flags(), "-x", "hip", "-c", str(s), "-o", str(o)]
+    cmd = [hipcc(), *_flags(), *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c", str(s), "-o", str(o)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

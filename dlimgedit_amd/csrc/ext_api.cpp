@@ -2,6 +2,7 @@
 // device-resident data, stage clocks, and single-kernel hooks for the parity tests.
 #include "environment.hpp"
 #include "segmentation.hpp"
+#include "resize_tables.hpp"
 
 #include <dlimgedit/dlimgedit_amd.h>
 
@@ -313,6 +314,29 @@ DLIMG_API int dlimg_amd_test_attention(int global, uint16_t const* qkv, float co
         }
         HIP_CHECK(hipDeviceSynchronize());
         download(reinterpret_cast<half_t*>(out), o.get(), rows * D);
+    });
+}
+
+DLIMG_API int dlimg_amd_test_resize(uint8_t const* pixels, int width, int height, int stride, int channels, int out_w,
+                                    int out_h, uint8_t* out_pixels) {
+    return guarded([&] {
+        require_gpu();
+        DLIMG_ASSERT(pixels && out_pixels && width > 0 && height > 0 && out_w > 0 && out_h > 0);
+        const int C = channel_bytes(channels);
+        AxisTable tx = make_axis_table(width, out_w), ty = make_axis_table(height, out_h);
+        float lut[256];
+        srgb_decode_table(lut);
+        Upload<uint8_t> src(pixels, (size_t)stride * height);
+        Upload<int> xf(tx.first.data(), tx.first.size()), xc(tx.count.data(), tx.count.size());
+        Upload<int> yf(ty.first.data(), ty.first.size()), yc(ty.count.data(), ty.count.size());
+        Upload<float> xk(tx.coef.data(), tx.coef.size()), yk(ty.coef.data(), ty.coef.size()), dlut(lut, 256);
+        Upload<uint32_t> enc(kSrgbEncodeTab4, 104);
+        DeviceBuffer<float> tmp((size_t)height * out_w * C);
+        DeviceBuffer<uint8_t> dst((size_t)out_w * out_h * C);
+        k::ResizeAxis ax{xf.get(), xc.get(), xk.get(), tx.taps, out_w}, ay{yf.get(), yc.get(), yk.get(), ty.taps, out_h};
+        k::resize_srgb(src.get(), width, height, stride, C, ax, ay, dlut.get(), enc.get(), tmp.get(), dst.get(), nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+        download(out_pixels, dst.get(), (size_t)out_w * out_h * C);
     });
 }
 

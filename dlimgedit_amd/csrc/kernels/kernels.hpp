@@ -42,6 +42,12 @@ void layernorm(const float* x, const float* w, const float* b, float eps, int ro
 // (float(u8) - mean[c]) / std[c]; pixels outside h x w (zero padding of the graph) are 0.
 void preprocess(const uint8_t* img, int w, int h, int stride, int channels, half_t* patches, hipStream_t);
 
+// ---- K17 longest-side resize (stb_image_resize equivalent; tables from csrc/resize_tables.cpp) ------------
+struct ResizeAxis { const int* first; const int* count; const float* coef; int taps; int out; };   // device pointers
+// src u8 [h][stride] with C bytes per pixel -> dst u8 [ay.out][ax.out*C] packed; tmp: fp32 [h][ax.out][C] scratch
+void resize_srgb(const uint8_t* src, int w, int h, int stride, int C, const ResizeAxis& ax, const ResizeAxis& ay,
+                 const float* decode_lut, const uint32_t* encode_tab, float* tmp, uint8_t* dst, hipStream_t);
+
 // ---- elementwise -----------------------------------------------------------------------------
 // out_h[i] = f16(a[i] + (b ? b[i % b_mod] : 0)); out_f32 likewise (either may be null); n % 4 == 0
 void add_cast(const float* a, const float* b, size_t b_mod, size_t n, float* out_f32, half_t* out_h, hipStream_t);

@@ -15,6 +15,9 @@
 #include "device_common.hpp"
 #include "kernels.hpp"
 
+// bit-exactness contract with the oracle: no mul+add contraction anywhere in this file
+#pragma clang fp contract(off)
+
 namespace dlimg {
 namespace {
 

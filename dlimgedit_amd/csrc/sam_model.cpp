@@ -203,6 +203,7 @@ SamModel::~SamModel() {
     }
     for (auto e : event_pool_) (void)hipEventDestroy(e);
     if (upload_done_) (void)hipEventDestroy(upload_done_);
+    if (resize_upload_done_) (void)hipEventDestroy(resize_upload_done_);
     for (auto e : prompt_done_)
         if (e) (void)hipEventDestroy(e);
     if (stream_) (void)hipStreamDestroy(stream_);
@@ -317,8 +318,63 @@ void SamModel::upload_image(int slot, int batch, uint8_t const* pixels, int w, i
     preprocess_device_image(slot, batch, dev, w, h, (int)row, channels);
 }
 
-void SamModel::upload_and_resize_image(int, int, uint8_t const*, int, int, int, int, int, int) {
-    throw Exception("Images whose longest side is not 1024 pixels need the device resampler, which is not built yet");
+SamModel::AxisDev const& SamModel::axis_table(int in_size, int out_size) {
+    for (auto const& a : axis_cache_)
+        if (a->in_size == in_size && a->out_size == out_size) return *a;
+    AxisTable t = make_axis_table(in_size, out_size);
+    auto a = std::make_unique<AxisDev>();
+    a->in_size = in_size;
+    a->out_size = out_size;
+    a->taps = t.taps;
+    a->first.reserve(t.first.size());
+    a->count.reserve(t.count.size());
+    a->coef.reserve(t.coef.size());
+    HIP_CHECK(hipMemcpy(a->first.get(), t.first.data(), t.first.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(a->count.get(), t.count.data(), t.count.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(a->coef.get(), t.coef.data(), t.coef.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (axis_cache_.size() >= 64) axis_cache_.erase(axis_cache_.begin());
+    axis_cache_.push_back(std::move(a));
+    return *axis_cache_.back();
+}
+
+void SamModel::upload_and_resize_image(int slot, int batch, uint8_t const* pixels, int w, int h, int stride, int channels,
+                                       int rw, int rh) {
+    DLIMG_ASSERT(slot >= 0 && slot < batch);
+    DLIMG_ASSERT(w > 0 && h > 0 && rw > 0 && rh > 0 && rw <= kImageSize && rh <= kImageSize);
+    reserve_encoder(batch);
+    const int bytes = channels > 4 ? 4 : channels;
+    const size_t row = (size_t)w * bytes;
+    if (!srgb_decode_.get()) {
+        float lut[256];
+        srgb_decode_table(lut);
+        srgb_decode_.reserve(256);
+        srgb_encode_.reserve(104);
+        HIP_CHECK(hipMemcpy(srgb_decode_.get(), lut, sizeof(lut), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(srgb_encode_.get(), kSrgbEncodeTab4, sizeof(kSrgbEncodeTab4), hipMemcpyHostToDevice));
+        HIP_CHECK(hipEventCreateWithFlags(&resize_upload_done_, hipEventDisableTiming));
+    }
+    AxisDev const& ax = axis_table(w, rw);
+    AxisDev const& ay = axis_table(h, rh);
+    // the source image, its fp32 intermediate and the staging area are re-used by the next resize:
+    // everything queued on them must have run before they are touched or re-allocated
+    HIP_CHECK(hipEventSynchronize(resize_upload_done_));
+    if (row * h > resize_src_.capacity() || (size_t)h * rw * bytes > resize_tmp_.capacity())
+        HIP_CHECK(hipStreamSynchronize(stream_));
+    resize_pinned_.reserve(row * h);
+    resize_src_.reserve(row * h);
+    resize_tmp_.reserve((size_t)h * rw * bytes);
+    uint8_t* pin = static_cast<uint8_t*>(resize_pinned_.get());
+    for (int y = 0; y < h; ++y) std::memcpy(pin + y * row, pixels + (size_t)y * stride, row);
+    HIP_CHECK(hipMemcpyAsync(resize_src_.get(), pin, row * h, hipMemcpyHostToDevice, stream_));
+    uint8_t* dev = img_dev_.get() + (size_t)slot * kImageSize * kImageSize * 4;
+    k::ResizeAxis kx{ax.first.get(), ax.count.get(), ax.coef.get(), ax.taps, rw};
+    k::ResizeAxis ky{ay.first.get(), ay.count.get(), ay.coef.get(), ay.taps, rh};
+    timed(ST_PRE, (double)row * h + (double)rw * rh * bytes, [&] {
+        k::resize_srgb(resize_src_.get(), w, h, (int)row, bytes, kx, ky, srgb_decode_.get(), srgb_encode_.get(),
+                       resize_tmp_.get(), dev, stream_);
+    });
+    HIP_CHECK(hipEventRecord(resize_upload_done_, stream_));
+    preprocess_device_image(slot, batch, dev, rw, rh, rw * bytes, channels);
 }
 
 void SamModel::encode(int batch) {

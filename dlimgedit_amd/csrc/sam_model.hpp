@@ -9,9 +9,11 @@
 
 #include "common.hpp"
 #include "kernels/kernels.hpp"
+#include "resize_tables.hpp"
 #include "weights.hpp"
 
 #include <array>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -146,6 +148,21 @@ class SamModel {
     hipEvent_t upload_done_ = nullptr;    // guards re-use of img_pinned_ by the next upload
     DeviceBuffer<half_t> patches_, xn_, qkv_, att_, hid_;
     DeviceBuffer<float> x_, neck_f32_, emb_;
+
+    // ---- longest-side resize (images whose longest side is not 1024)
+    struct AxisDev {
+        int in_size = 0, out_size = 0, taps = 0;
+        DeviceBuffer<int> first, count;
+        DeviceBuffer<float> coef;
+    };
+    AxisDev const& axis_table(int in_size, int out_size);
+    std::vector<std::unique_ptr<AxisDev>> axis_cache_;
+    DeviceBuffer<float> srgb_decode_;
+    DeviceBuffer<uint32_t> srgb_encode_;
+    DeviceBuffer<uint8_t> resize_src_;
+    DeviceBuffer<float> resize_tmp_;
+    PinnedBuffer resize_pinned_;
+    hipEvent_t resize_upload_done_ = nullptr;
 
     // ---- decoder workspace (sized for dec_count_ prompts)
     int dec_count_ = 0;

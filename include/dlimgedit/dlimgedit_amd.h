@@ -77,6 +77,10 @@ DLIMG_API int dlimg_amd_test_layernorm(float const* x, float const* w, float con
  * global != 0: rel tables are [127][hd]; else windowed 14x14 with [27][hd] tables and qkv_bias [3*D]. */
 DLIMG_API int dlimg_amd_test_attention(int global, uint16_t const* qkv, float const* qkv_bias, float const* rel_h,
                                        float const* rel_w, int batch, int heads, int hd, uint16_t* out);
+/* K17: the stb_image_resize-equivalent longest-side resampler (default filter, sRGB, clamp):
+ * pixels [height][stride] -> out_pixels [out_h][out_w * bytes_per_pixel] packed. */
+DLIMG_API int dlimg_amd_test_resize(uint8_t const* pixels, int width, int height, int stride, int channels, int out_w,
+                                    int out_h, uint8_t* out_pixels);
 /* Times `iters` launches of the GEMM on device-resident random operands; returns average ms per launch. */
 DLIMG_API int dlimg_amd_bench_gemm(int M, int N, int K, int act, int iters, double* out_ms);
 

@@ -454,7 +454,7 @@ class OracleSegmentation:
         tw, th = self.rs.target_extent(w, h)
         if (tw, th) != (w, h):
             if resized is None:
-                from .stb_resize import resize_srgb  # noqa: WPS433 (oracle-internal)
+                from oracle.stb_resize import resize_srgb
                 resized = resize_srgb(pixels, tw, th)
             assert resized.shape[:2] == (th, tw)
             pixels = resized

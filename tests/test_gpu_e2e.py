@@ -185,3 +185,23 @@ def test_reference_wrapper_consumer_end_to_end(api, session, model_dirs, tmp_pat
     acc = [float(v) for v in r.stdout.split("accuracy=")[1].split()]
     want = [m.accuracy for m in seg.compute_masks(api.Point(512, 512))]
     assert np.allclose(acc, want, atol=1e-5)
+
+
+@pytest.mark.parametrize("w,h,channels,point", [(1800, 1200, 3, (486, 722)), (512, 512, 4, (320, 210)),
+                                                (640, 960, 4, (100, 800))])
+def test_non_1024_images_end_to_end(api, session, w, h, channels, point):
+    """Longest side != 1024: device resize -> padded pre-processing -> encode -> prompt in original
+    coordinates (rounded as the reference does) -> crop + second bilinear back to the original size.
+    Geometries of the reference's own integration tests (truck.jpg 1800x1200, cat_and_hat 512x512)."""
+    from oracle import sam_oracle as O
+    env, params, cfg, *_ = session
+    img = synthetic_image(w, width=w, height=h, channels=4)[:, :, :channels].copy()
+    ch = api.Channels.rgb if channels == 3 else api.Channels.rgba
+    seg = api.Segmentation.process(api.ImageView(img, ch), env)
+    assert seg.extent() == api.Extent(w, h)
+    ora = O.OracleSegmentation(params, cfg).process(img, int(ch))
+    assert np.abs(api.ext.get_embedding(seg) - ora.embedding).max() < EMB_TOL
+    got = seg.compute_mask(api.Point(*point))
+    want = ora.compute_mask(point=point)
+    assert got.shape == (h, w)
+    assert iou(got, want) >= IOU_BAR, iou(got, want)

@@ -243,3 +243,37 @@ def test_attention_global_online_softmax_rescale(ext):
     got = ext.test_attention(True, qkv, None, rel, rel, 1, heads, hd).astype(np.float32)
     ref = O.attention_from_qkv(qkv.astype(np.float32)[None], rel, rel, heads, 64)[0]
     assert np.abs(got - ref).max() < 6e-3
+
+
+# -------------------------------------------------------------------------------------------- K17
+
+@pytest.mark.parametrize("w,h,ow,oh,channels", [
+    (8, 8, 4, 4, 4),            # the reference's KAT geometry
+    (1800, 1200, 1024, 683, 3), # truck.jpg geometry: downsample, rgb
+    (512, 512, 1024, 1024, 4),  # cat_and_hat geometry: 2x upsample (Catmull-Rom)
+    (640, 960, 683, 1024, 4),   # mild upsample, portrait
+    (2048, 1536, 1024, 768, 1), # 2x downsample, mask
+    (37, 91, 416, 1024, 5),     # large upsample of a tiny bgra image
+])
+def test_resize_bit_exact(ext, w, h, ow, oh, channels):
+    """The device resampler equals the oracle's restatement of stbir_resize_uint8_generic byte for byte."""
+    from dlimgedit_amd import api
+    from oracle import stb_resize as R
+    c = api.count(api.Channels(channels))
+    rng = np.random.default_rng(w * 31 + h)
+    img = synthetic_image(w + h, width=w, height=h, channels=4)[:, :, :c].copy()
+    img[rng.integers(0, h, 50), rng.integers(0, w, 50)] = rng.integers(0, 256, (50, c))   # hard edges
+    got = ext.test_resize(img, api.Channels(channels), ow, oh)
+    want = R.resize_srgb(img, ow, oh)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
+
+
+def test_resize_reference_kat_on_device(ext):
+    from dlimgedit_amd import api
+    img = np.zeros((8, 8, 4), np.uint8)
+    for i in range(64):
+        img[i // 8, i % 8] = (255, 4 * (i // 8), 4 * (i % 8), 255)
+    out = ext.test_resize(img, api.Channels.rgba, 4, 4)
+    for i in range(16):
+        assert tuple(int(v) for v in out[i // 4, i % 4]) == (255, 2 + 8 * (i // 4), 2 + 8 * (i % 4), 255)

@@ -96,3 +96,34 @@ def test_patchify_order():
     # row 1 = patch (py 0, px 1); column c*256 + iy*16 + ix
     assert p[1, 1 * 256 + 2 * 16 + 3] == chw[1, 2, 16 + 3]
     assert p[2, 0] == chw[0, 16, 0]
+
+
+def test_image_resize_kat():
+    """Image resize (reference test/test_image.cpp:51-69): 8x8 RGBA ramp -> 4x4 through the restated
+    stb_image_resize call (Mitchell, sRGB, clamp): R = A = 255, G = 2 + 8*row, B = 2 + 8*col."""
+    from oracle import stb_resize as R
+    img = np.zeros((8, 8, 4), np.uint8)
+    for i in range(64):
+        img[i // 8, i % 8] = (255, 4 * (i // 8), 4 * (i % 8), 255)
+    out = R.resize_srgb(img, 4, 4)
+    assert out.shape == (4, 4, 4)
+    for i in range(16):
+        assert tuple(int(v) for v in out[i // 4, i % 4]) == (255, 2 + 8 * (i // 4), 2 + 8 * (i % 4), 255)
+
+
+def test_srgb_tables_round_trip_and_are_monotonic():
+    """Giesen's float->sRGB8 conversion must invert the 256-entry decode table and never decrease."""
+    from oracle import stb_resize as R
+    t = R.srgb_to_linear_table()
+    assert np.array_equal(R.linear_to_srgb_uchar(t), np.arange(256, dtype=np.uint8))
+    y = R.linear_to_srgb_uchar(np.linspace(0, 1, 200001, dtype=np.float32)).astype(int)
+    assert np.all(np.diff(y) >= 0) and y[0] == 0 and y[-1] == 255
+    assert R.linear_to_srgb_uchar(np.array([np.nan, -1.0, 2.0], np.float32)).tolist() == [0, 0, 255]
+
+
+def test_resize_contributors_sum_to_one():
+    from oracle import stb_resize as R
+    for n_in, n_out in [(8, 4), (1800, 1024), (512, 1024), (1200, 683), (13, 18), (19, 26), (5, 5)]:
+        first, count, coef = R.axis_contributors(n_in, n_out)
+        assert np.allclose(coef.sum(axis=1), 1.0, atol=1e-5)
+        assert count.min() >= 1 and first.min() >= -8 and (first + count).max() <= n_in + 8
