@@ -153,7 +153,7 @@ def main() -> None:
             "dtype": "f16",
             "data": "synthetic",
             "config": {"workload": f"SAM {args.model} encoder + 1 point prompt, {B} image(s)/GPU/step, 1024x1024 RGBA, "
-                                   "inputs and masks resident in HBM", "images_per_gpu_per_step": B,
+                                   "inputs and masks resident in HBM", "images_per_gpu_per_step": B, "lanes_per_gpu": ext.lane_count(env),
                        "weights": "seeded synthetic" if args.model_dir is None else "from --model-dir"},
         }
 

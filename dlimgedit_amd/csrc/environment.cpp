@@ -86,8 +86,28 @@ std::string EnvironmentImpl::find_sam_weights() const {
     return (dir / best).string();
 }
 
+EnvironmentImpl::SamLanes::SamLanes(std::string const& weight_path, int device, int count)
+    : weights(std::make_shared<SamWeights>(weight_path, device)) {
+    for (int i = 0; i < count; ++i) lanes.push_back(std::make_unique<SamModel>(weights));
+}
+
+EnvironmentImpl::SamLanes& EnvironmentImpl::lanes() {
+    return sam_.get_or_make([&] {
+        int n = 3;      // three images in flight per GPU (measured best on MI355X); DLIMGEDIT_LANES overrides (1..8)
+        if (const char* e = std::getenv("DLIMGEDIT_LANES")) n = std::atoi(e);
+        n = n < 1 ? 1 : (n > 8 ? 8 : n);
+        return std::make_tuple(find_sam_weights(), device, n);
+    });
+}
+
+int EnvironmentImpl::lane_count() { return int(lanes().lanes.size()); }
+
+SamModel& EnvironmentImpl::lane(int index) { return *lanes().lanes.at(index); }
+
 SamModel& EnvironmentImpl::sam_model() {
-    return sam_.get_or_make([&] { return std::make_tuple(find_sam_weights(), device); });
+    SamLanes& l = lanes();
+    if (single_lane_.load() || l.lanes.size() == 1) return *l.lanes[0];
+    return *l.lanes[next_lane_.fetch_add(1) % l.lanes.size()];
 }
 
 }  // namespace dlimg

@@ -8,7 +8,10 @@
 
 #include <dlimgedit/dlimgedit.h>
 
+#include <atomic>
 #include <filesystem>
+#include <memory>
+#include <vector>
 #include <string>
 
 namespace dlimg {
@@ -25,12 +28,25 @@ class EnvironmentImpl {
 
     explicit EnvironmentImpl(dlimg_Options const& options);
 
-    // Created on first use, once per environment (reference: environment.cpp:144-146).
+    // Weights + execution lanes, created on first use, once per environment (reference:
+    // environment.cpp:144-146).  sam_model() hands out the lanes round-robin; lane(i) addresses one.
     SamModel& sam_model();
+    SamModel& lane(int index);
+    int lane_count();
+    // While set, every request goes to lane 0 (per-kernel clocks must not see other lanes' kernels).
+    void set_single_lane(bool on) { single_lane_.store(on); }
 
   private:
+    struct SamLanes {
+        SamLanes(std::string const& weight_path, int device, int count);
+        std::shared_ptr<SamWeights const> weights;
+        std::vector<std::unique_ptr<SamModel>> lanes;
+    };
+    SamLanes& lanes();
     std::string find_sam_weights() const;
-    Lazy<SamModel> sam_;
+    Lazy<SamLanes> sam_;
+    std::atomic<unsigned> next_lane_{0};
+    std::atomic<bool> single_lane_{false};
 };
 
 }  // namespace dlimg

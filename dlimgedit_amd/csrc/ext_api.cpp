@@ -79,7 +79,7 @@ DLIMG_API int dlimg_amd_device_count(void) { return EnvironmentImpl::device_coun
 
 DLIMG_API int dlimg_amd_model_geometry(dlimg_Environment env, int* out) {
     return guarded([&] {
-        SamGeometry const& g = impl(env).sam_model().geometry();
+        SamGeometry const& g = impl(env).lane(0).geometry();
         out[0] = g.embed_dim;
         out[1] = g.depth;
         out[2] = g.num_heads;
@@ -91,10 +91,8 @@ DLIMG_API int dlimg_amd_get_embedding(dlimg_Segmentation seg, float* out) {
     return guarded([&] {
         SegmentationImpl& s = impl(seg);
         DLIMG_ASSERT(s.embedding() != nullptr && out != nullptr);
-        std::lock_guard<std::mutex> lock(s.model().mutex());
-        HIP_CHECK(hipSetDevice(s.model().device()));
-        s.model().synchronize();
-        download(out, s.embedding(), (size_t)kTokens * kEmbedDim);
+        HIP_CHECK(hipSetDevice(s.environment().device));
+        download(out, s.embedding(), (size_t)kTokens * kEmbedDim);      // process() has synchronised already
     });
 }
 
@@ -109,7 +107,7 @@ DLIMG_API int dlimg_amd_get_logits(dlimg_Segmentation seg, int const* point, int
         if (region) r = Region{Point{region[0], region[1]}, Point{region[2], region[3]}};
         float coords[4], labels[2];
         pack_prompt(s.geometry(), point ? &p : nullptr, !point && region ? &r : nullptr, coords, labels);
-        SamModel& m = s.model();
+        SamModel& m = s.environment().sam_model();
         std::lock_guard<std::mutex> lock(m.mutex());
         HIP_CHECK(hipSetDevice(m.device()));
         float const* emb = s.embedding();
@@ -188,18 +186,28 @@ DLIMG_API int dlimg_amd_encode_and_mask(dlimg_Environment env, dlimg_ImageView c
 
 DLIMG_API int dlimg_amd_synchronize(dlimg_Environment env) {
     return guarded([&] {
-        SamModel& m = impl(env).sam_model();
-        std::lock_guard<std::mutex> lock(m.mutex());
-        HIP_CHECK(hipSetDevice(m.device()));
-        m.synchronize();
+        EnvironmentImpl& e = impl(env);
+        for (int i = 0; i < e.lane_count(); ++i) {
+            SamModel& m = e.lane(i);
+            std::lock_guard<std::mutex> lock(m.mutex());
+            HIP_CHECK(hipSetDevice(m.device()));
+            m.synchronize();
+        }
     });
 }
 
 DLIMG_API int dlimg_amd_set_profiling(dlimg_Environment env, int enabled) {
     return guarded([&] {
-        SamModel& m = impl(env).sam_model();
+        EnvironmentImpl& e = impl(env);
+        for (int i = 0; i < e.lane_count(); ++i) {      // drain everything, then pin requests to lane 0 while clocks run
+            SamModel& m = e.lane(i);
+            std::lock_guard<std::mutex> lock(m.mutex());
+            HIP_CHECK(hipSetDevice(m.device()));
+            m.synchronize();
+        }
+        e.set_single_lane(enabled != 0);
+        SamModel& m = e.lane(0);
         std::lock_guard<std::mutex> lock(m.mutex());
-        HIP_CHECK(hipSetDevice(m.device()));
         m.set_profiling(enabled != 0);
     });
 }
@@ -207,7 +215,7 @@ DLIMG_API int dlimg_amd_set_profiling(dlimg_Environment env, int enabled) {
 DLIMG_API int dlimg_amd_take_stage_stats(dlimg_Environment env, double* out_ms, double* out_work, long* out_launches) {
     static_assert(ST_COUNT == DLIMG_AMD_STAGE_COUNT, "stage table out of sync with the public header");
     return guarded([&] {
-        SamModel& m = impl(env).sam_model();
+        SamModel& m = impl(env).lane(0);
         std::lock_guard<std::mutex> lock(m.mutex());
         HIP_CHECK(hipSetDevice(m.device()));
         StageStats s = m.take_stats();
@@ -217,6 +225,12 @@ DLIMG_API int dlimg_amd_take_stage_stats(dlimg_Environment env, double* out_ms, 
             if (out_launches) out_launches[i] = s.launches[i];
         }
     });
+}
+
+DLIMG_API int dlimg_amd_lane_count(dlimg_Environment env) {
+    int n = 0;
+    guarded([&] { n = impl(env).lane_count(); });
+    return n;
 }
 
 // ---- single-kernel hooks ----------------------------------------------------------------------

@@ -92,7 +92,7 @@ struct Loader {
 
 }  // namespace
 
-SamModel::SamModel(std::string const& weight_path, int device) : device_(device) {
+SamWeights::SamWeights(std::string const& weight_path, int device_index) : device(device_index) {
     WeightFile file(weight_path);
     geom_ = file.geometry();
     const int D = geom_.embed_dim, hd = geom_.head_dim();
@@ -100,10 +100,9 @@ SamModel::SamModel(std::string const& weight_path, int device) : device_(device)
     if (D != hd * geom_.num_heads || (hd != 64 && hd != 80))
         throw Exception("SAM encoder head dimension must be 64 or 80");
 
-    HIP_CHECK(hipSetDevice(device_));
+    HIP_CHECK(hipSetDevice(device));
+    hipStream_t stream_ = nullptr;
     HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-    HIP_CHECK(hipEventCreateWithFlags(&upload_done_, hipEventDisableTiming));
-    for (auto& e : prompt_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     Loader ld{file, stream_, {}};
 
     ld.linear_h("enc.patch", D, kPatchK, true, patch_);
@@ -193,6 +192,14 @@ SamModel::SamModel(std::string const& weight_path, int device) : device_(device)
         ld.linear_f(p + ".2", last, 256, heads_[m][2]);
     }
     HIP_CHECK(hipStreamSynchronize(stream_));
+    HIP_CHECK(hipStreamDestroy(stream_));
+}
+
+SamModel::SamModel(std::shared_ptr<SamWeights const> weights) : device_(weights->device), weights_(std::move(weights)) {
+    HIP_CHECK(hipSetDevice(device_));
+    HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&upload_done_, hipEventDisableTiming));
+    for (auto& e : prompt_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 }
 
 SamModel::~SamModel() {
@@ -272,11 +279,12 @@ void SamModel::synchronize() { HIP_CHECK(hipStreamSynchronize(stream_)); }
 // encoder
 
 void SamModel::reserve_encoder(int batch) {
+    SamWeights const& W = *weights_;
     if (batch <= enc_batch_) return;
     HIP_CHECK(hipStreamSynchronize(stream_));
     const size_t M = (size_t)batch * kTokens;
-    const size_t D = geom_.embed_dim;
-    const size_t wide = std::max<size_t>(geom_.mlp_dim, 9 * kEmbedDim);
+    const size_t D = W.geom_.embed_dim;
+    const size_t wide = std::max<size_t>(W.geom_.mlp_dim, 9 * kEmbedDim);
     img_dev_.reserve((size_t)batch * kImageSize * kImageSize * 4);
     patches_.reserve(M * kPatchK);
     x_.reserve(M * D);
@@ -378,18 +386,19 @@ void SamModel::upload_and_resize_image(int slot, int batch, uint8_t const* pixel
 }
 
 void SamModel::encode(int batch) {
+    SamWeights const& W = *weights_;
     DLIMG_ASSERT(batch > 0 && batch <= enc_batch_);
-    const int D = geom_.embed_dim, H = geom_.num_heads, hd = geom_.head_dim(), mlp = geom_.mlp_dim;
+    const int D = W.geom_.embed_dim, H = W.geom_.num_heads, hd = W.geom_.head_dim(), mlp = W.geom_.mlp_dim;
     const int M = batch * kTokens;
 
     k::GemmArgs g;
-    g.A = patches_.get(); g.lda = kPatchK; g.W = patch_.w.get(); g.ldw = kPatchK; g.bias = patch_.b.get();
-    g.resid = pos_embed_.get(); g.ldr = D; g.resid_mod = kTokens;
+    g.A = patches_.get(); g.lda = kPatchK; g.W = W.patch_.w.get(); g.ldw = kPatchK; g.bias = W.patch_.b.get();
+    g.resid = W.pos_embed_.get(); g.ldr = D; g.resid_mod = kTokens;
     g.out_f32 = x_.get(); g.ldc32 = D; g.M = M; g.N = D; g.K = kPatchK;
     gemm(g);
 
     const double ln_bytes = (double)M * D * 6;
-    for (EncoderLayer const& L : layers_) {
+    for (EncoderLayer const& L : W.layers_) {
         timed(ST_LAYERNORM, ln_bytes, [&] {
             k::layernorm(x_.get(), L.ln1.w.get(), L.ln1.b.get(), kLnEps, M, D, k::ACT_NONE, nullptr, xn_.get(), stream_);
         });
@@ -431,22 +440,22 @@ void SamModel::encode(int batch) {
         k::add_cast(x_.get(), nullptr, 0, (size_t)M * D, nullptr, xn_.get(), stream_);
     });
     g = k::GemmArgs{};
-    g.A = xn_.get(); g.lda = D; g.W = neck1_.w.get(); g.ldw = D;
+    g.A = xn_.get(); g.lda = D; g.W = W.neck1_.w.get(); g.ldw = D;
     g.out_f32 = neck_f32_.get(); g.ldc32 = kEmbedDim; g.M = M; g.N = kEmbedDim; g.K = D;
     gemm(g);
     timed(ST_LAYERNORM, (double)M * kEmbedDim * 6, [&] {
-        k::layernorm(neck_f32_.get(), neck_ln1_.w.get(), neck_ln1_.b.get(), kLnEps, M, kEmbedDim, k::ACT_NONE, nullptr,
+        k::layernorm(neck_f32_.get(), W.neck_ln1_.w.get(), W.neck_ln1_.b.get(), kLnEps, M, kEmbedDim, k::ACT_NONE, nullptr,
                      att_.get(), stream_);
     });
     timed(ST_ENC_OTHER, (double)M * kEmbedDim * 2 * 10, [&] {
         k::im2col3x3(att_.get(), batch, kEmbedDim, hid_.get(), stream_);
     });
     g = k::GemmArgs{};
-    g.A = hid_.get(); g.lda = 9 * kEmbedDim; g.W = neck2_.w.get(); g.ldw = 9 * kEmbedDim;
+    g.A = hid_.get(); g.lda = 9 * kEmbedDim; g.W = W.neck2_.w.get(); g.ldw = 9 * kEmbedDim;
     g.out_f32 = neck_f32_.get(); g.ldc32 = kEmbedDim; g.M = M; g.N = kEmbedDim; g.K = 9 * kEmbedDim;
     gemm(g);
     timed(ST_LAYERNORM, (double)M * kEmbedDim * 8, [&] {
-        k::layernorm(neck_f32_.get(), neck_ln2_.w.get(), neck_ln2_.b.get(), kLnEps, M, kEmbedDim, k::ACT_NONE, emb_.get(),
+        k::layernorm(neck_f32_.get(), W.neck_ln2_.w.get(), W.neck_ln2_.b.get(), kLnEps, M, kEmbedDim, k::ACT_NONE, emb_.get(),
                      nullptr, stream_);
     });
 }
@@ -485,6 +494,7 @@ void SamModel::reserve_decoder(int count) {
 }
 
 void SamModel::decode(float const* const* emb, float const* coords, float const* labels, int count) {
+    SamWeights const& W = *weights_;
     DLIMG_ASSERT(count > 0);
     reserve_decoder(count);
     const int P = count, M = P * kTokens, T = P * kDecTokens;
@@ -501,13 +511,13 @@ void SamModel::decode(float const* const* emb, float const* coords, float const*
         HIP_CHECK(hipMemcpyAsync(labels_.get(), pin + (size_t)P * 4, (size_t)P * 2 * sizeof(float),
                                  hipMemcpyHostToDevice, s));
         HIP_CHECK(hipEventRecord(prompt_done_[ring], s));
-        k::prompt_tokens(coords_.get(), labels_.get(), pe_gauss_.get(), pe_point_.get(), pe_not_a_point_.get(),
-                         iou_token_.get(), mask_tokens_.get(), tokens_.get(), P, s);
+        k::prompt_tokens(coords_.get(), labels_.get(), W.pe_gauss_.get(), W.pe_point_.get(), W.pe_not_a_point_.get(),
+                         W.iou_token_.get(), W.mask_tokens_.get(), tokens_.get(), P, s);
         HIP_CHECK(hipMemcpyAsync(queries_.get(), tokens_.get(), (size_t)T * 256 * sizeof(float),
                                  hipMemcpyDeviceToDevice, s));
         // src = image_embedding + no_mask_embed (has_mask_input == 0, segmentation.cpp:43-45)
         for (int p = 0; p < P; ++p)
-            k::add_cast(emb[p], pe_no_mask_.get(), 256, (size_t)kTokens * 256, keys_.get() + (size_t)p * kTokens * 256,
+            k::add_cast(emb[p], W.pe_no_mask_.get(), 256, (size_t)kTokens * 256, keys_.get() + (size_t)p * kTokens * 256,
                         keys_h_.get() + (size_t)p * kTokens * 256, s);
 
         float* q = queries_.get();
@@ -532,7 +542,7 @@ void SamModel::decode(float const* const* emb, float const* coords, float const*
         };
 
         for (int i = 0; i < 2; ++i) {
-            DecoderLayer const& L = dec_[i];
+            DecoderLayer const& L = W.dec_[i];
             // (1) self attention of the tokens; the first layer has no PE and no residual
             float const* pe = i == 0 ? nullptr : qpe;
             lin(q, pe, L.self_attn.q, nullptr, tq_.get(), 0);
@@ -542,7 +552,7 @@ void SamModel::decode(float const* const* emb, float const* coords, float const*
             lin(tatt_.get(), nullptr, L.self_attn.o, i == 0 ? nullptr : q, q, 0);
             ln_tokens(L.ln1, kLnEps);
             // (2) tokens -> image
-            k::add_cast(keys_.get(), image_pe_.get(), (size_t)kTokens * 256, (size_t)M * 256, nullptr, kp_h_.get(), s);
+            k::add_cast(keys_.get(), W.image_pe_.get(), (size_t)kTokens * 256, (size_t)M * 256, nullptr, kp_h_.get(), s);
             img_gemm(kp_h_.get(), 256, L.img_kq, kq_h_.get(), 256);
             img_gemm(keys_h_.get(), 256, L.img_v, v_h_.get(), 128);
             token_to_image(L.t2i_q, L.t2i_o, kq_h_.get(), 256);
@@ -564,29 +574,29 @@ void SamModel::decode(float const* const* emb, float const* coords, float const*
                          keys_h_.get(), s);
         }
         // final token -> image attention
-        k::add_cast(keys_.get(), image_pe_.get(), (size_t)kTokens * 256, (size_t)M * 256, nullptr, kp_h_.get(), s);
-        img_gemm(kp_h_.get(), 256, final_k_, kq_h_.get(), 128);
-        img_gemm(keys_h_.get(), 256, final_v_, v_h_.get(), 128);
-        token_to_image(final_q_, final_o_, kq_h_.get(), 128);
-        ln_tokens(ln_final_, 1e-5f);
+        k::add_cast(keys_.get(), W.image_pe_.get(), (size_t)kTokens * 256, (size_t)M * 256, nullptr, kp_h_.get(), s);
+        img_gemm(kp_h_.get(), 256, W.final_k_, kq_h_.get(), 128);
+        img_gemm(keys_h_.get(), 256, W.final_v_, v_h_.get(), 128);
+        token_to_image(W.final_q_, W.final_o_, kq_h_.get(), 128);
+        ln_tokens(W.ln_final_, 1e-5f);
 
         // upscaling: ConvT(256->64) -> LN2d -> GELU -> ConvT(64->32) -> GELU, sub-pixels kept in quad order
         k::GemmArgs g;
-        g.A = keys_h_.get(); g.lda = 256; g.W = up1_.w.get(); g.ldw = 256; g.bias = up1_.b.get();
+        g.A = keys_h_.get(); g.lda = 256; g.W = W.up1_.w.get(); g.ldw = 256; g.bias = W.up1_.b.get();
         g.out_f32 = up1_f32_.get(); g.ldc32 = 256; g.M = M; g.N = 256; g.K = 256;
         k::gemm(g, s);
-        k::layernorm(up1_f32_.get(), up_ln_.w.get(), up_ln_.b.get(), kLnEps, M * 4, 64, k::ACT_GELU, nullptr,
+        k::layernorm(up1_f32_.get(), W.up_ln_.w.get(), W.up_ln_.b.get(), kLnEps, M * 4, 64, k::ACT_GELU, nullptr,
                      up1_h_.get(), s);
         g = k::GemmArgs{};
-        g.A = up1_h_.get(); g.lda = 64; g.W = up2_.w.get(); g.ldw = 64; g.bias = up2_.b.get(); g.act = k::ACT_GELU;
+        g.A = up1_h_.get(); g.lda = 64; g.W = W.up2_.w.get(); g.ldw = 64; g.bias = W.up2_.b.get(); g.act = k::ACT_GELU;
         g.out_f32 = up_.get(); g.ldc32 = 128; g.M = M * 4; g.N = 128; g.K = 64;
         k::gemm(g, s);
 
         k::HeadWeights hw;
         for (int m = 0; m < 5; ++m)
             for (int j = 0; j < 3; ++j) {
-                hw.w[m][j] = heads_[m][j].w.get();
-                hw.b[m][j] = heads_[m][j].b.get();
+                hw.w[m][j] = W.heads_[m][j].w.get();
+                hw.b[m][j] = W.heads_[m][j].b.get();
             }
         k::output_heads(q, hw, hyper_.get(), iou_.get(), P, s);
         k::mask_logits(up_.get(), hyper_.get(), logits_.get(), P, s);

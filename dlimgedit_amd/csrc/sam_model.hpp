@@ -59,6 +59,32 @@ struct DecoderLayer {
     LinearH i2t_o;                   // image side output projection (128 -> 256)
 };
 
+// Device-resident weights of one SAM variant; immutable after loading and shared by every execution lane.
+struct SamWeights {
+    explicit SamWeights(std::string const& weight_path, int device);
+    SamWeights(SamWeights const&) = delete;
+    SamWeights& operator=(SamWeights const&) = delete;
+
+    int device = 0;
+    SamGeometry geom_;
+    LinearH patch_;                       // [D, 768] + bias
+    DeviceBuffer<float> pos_embed_;       // [4096, D]
+    std::vector<EncoderLayer> layers_;
+    LinearH neck1_, neck2_;               // 1x1 conv [256, D]; 3x3 conv as [256, 9*256] (tap-major columns)
+    NormW neck_ln1_, neck_ln2_;
+    DeviceBuffer<float> pe_gauss_, pe_point_, pe_not_a_point_, pe_no_mask_;
+    DeviceBuffer<float> image_pe_;        // [4096, 256] dense positional encoding (constant)
+    DeviceBuffer<float> iou_token_, mask_tokens_;
+    std::array<DecoderLayer, 2> dec_;
+    LinearF final_q_, final_o_;
+    LinearH final_k_, final_v_;
+    NormW ln_final_;
+    LinearH up1_, up2_;                   // transposed-conv weights as GEMM operands (sub-pixel-major rows)
+    NormW up_ln_;
+    std::array<std::array<LinearF, 3>, 5> heads_;   // 4 hyper MLPs + IoU head
+
+};
+
 // Stage clock for roofline accounting (HIP events on the executor's own stream).
 enum Stage { ST_PRE = 0, ST_GEMM, ST_LAYERNORM, ST_ATTN_WINDOW, ST_ATTN_GLOBAL, ST_ENC_OTHER, ST_DECODER, ST_POST, ST_COUNT };
 
@@ -70,12 +96,16 @@ struct StageStats {
 
 class SamModel {
   public:
-    SamModel(std::string const& weight_path, int device);
+    // One execution lane: own stream, workspaces and staging buffers over shared weights.  Several lanes
+    // let independent images overlap on the GPU (tails and small kernels of one image hide behind the
+    // large kernels of another) -- the serving counterpart of the reference's "Environment is
+    // thread-safe" contract (reference: src/include/dlimgedit/dlimgedit.hpp:98-101).
+    explicit SamModel(std::shared_ptr<SamWeights const> weights);
     ~SamModel();
     SamModel(SamModel const&) = delete;
     SamModel& operator=(SamModel const&) = delete;
 
-    SamGeometry const& geometry() const { return geom_; }
+    SamGeometry const& geometry() const { return weights_->geom_; }
     hipStream_t stream() const { return stream_; }
     std::mutex& mutex() { return mutex_; }
     int device() const { return device_; }
@@ -122,24 +152,8 @@ class SamModel {
     int device_ = 0;
     hipStream_t stream_ = nullptr;
     std::mutex mutex_;
-    SamGeometry geom_;
 
-    // ---- weights
-    LinearH patch_;                       // [D, 768] + bias
-    DeviceBuffer<float> pos_embed_;       // [4096, D]
-    std::vector<EncoderLayer> layers_;
-    LinearH neck1_, neck2_;               // 1x1 conv [256, D]; 3x3 conv as [256, 9*256] (tap-major columns)
-    NormW neck_ln1_, neck_ln2_;
-    DeviceBuffer<float> pe_gauss_, pe_point_, pe_not_a_point_, pe_no_mask_;
-    DeviceBuffer<float> image_pe_;        // [4096, 256] dense positional encoding (constant)
-    DeviceBuffer<float> iou_token_, mask_tokens_;
-    std::array<DecoderLayer, 2> dec_;
-    LinearF final_q_, final_o_;
-    LinearH final_k_, final_v_;
-    NormW ln_final_;
-    LinearH up1_, up2_;                   // transposed-conv weights as GEMM operands (sub-pixel-major rows)
-    NormW up_ln_;
-    std::array<std::array<LinearF, 3>, 5> heads_;   // 4 hyper MLPs + IoU head
+    std::shared_ptr<SamWeights const> weights_;
 
     // ---- encoder workspace (sized for enc_batch_ images)
     int enc_batch_ = 0;

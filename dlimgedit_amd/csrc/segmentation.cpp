@@ -44,7 +44,9 @@ void check_image(dlimg_ImageView const& image) {
     DLIMG_ASSERT(image.stride >= image.width * channel_bytes(c));
 }
 
-SegmentationImpl::SegmentationImpl(EnvironmentImpl& env) : env_(env), model_(env.sam_model()) {}
+SegmentationImpl::SegmentationImpl(EnvironmentImpl& env) : env_(env) {
+    (void)env.lane_count();     // loads the model (and reports a missing weight file) at the same point as the reference
+}
 
 float* SegmentationImpl::embedding_storage() {
     embedding_.reserve((size_t)kTokens * kEmbedDim);
@@ -106,6 +108,7 @@ void SegmentationImpl::compute_mask(Point const* point, Region const* region, ui
         for (int i = 0; i < 3; ++i) DLIMG_ASSERT(out_masks[i] != nullptr);
     }
 
+    SamModel& model_ = env_.sam_model();
     std::lock_guard<std::mutex> lock(model_.mutex());
     HIP_CHECK(hipSetDevice(model_.device()));
     float const* emb = embedding_.get();
@@ -135,11 +138,11 @@ void SegmentationImpl::compute_mask_batch(SegmentationImpl const* const* segs, i
                                           int const* regions, uint8_t* const* out_masks) {
     if (count <= 0) return;
     DLIMG_ASSERT((points != nullptr) != (regions != nullptr));
-    SamModel& model = segs[0]->model_;
+    SamModel& model = segs[0]->env_.sam_model();
     std::vector<float> coords((size_t)count * 4), labels((size_t)count * 2);
     std::vector<float const*> emb(count);
     for (int i = 0; i < count; ++i) {
-        DLIMG_ASSERT(&segs[i]->model_ == &model);
+        DLIMG_ASSERT(&segs[i]->env_ == &segs[0]->env_);
         DLIMG_ASSERT(segs[i]->embedding_.get() != nullptr && out_masks[i] != nullptr);
         if (points) {
             Point p{points[i * 2], points[i * 2 + 1]};

@@ -53,13 +53,12 @@ class SegmentationImpl {
     Extent extent() const { return image_size_.original; }
     ResizeLongestSide const& geometry() const { return image_size_; }
     float const* embedding() const { return embedding_.get(); }
-    SamModel& model() const { return model_; }
+    EnvironmentImpl& environment() const { return env_; }
     void set_geometry(Extent e) { image_size_.set(e); }
     float* embedding_storage();
 
   private:
     EnvironmentImpl& env_;
-    SamModel& model_;
     ResizeLongestSide image_size_;
     DeviceBuffer<float> embedding_;     // [4096][256] fp32, resident
 };

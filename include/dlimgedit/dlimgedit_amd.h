@@ -49,12 +49,17 @@ DLIMG_API int dlimg_amd_encode_and_mask(dlimg_Environment env, dlimg_ImageView c
                                         int const* points, uint8_t* const* dev_masks);
 /* Encode only / decode only variants of the above, for per-stage rates. */
 DLIMG_API int dlimg_amd_encode_only(dlimg_Environment env, dlimg_ImageView const* dev_images, int count);
+/* Waits for every execution lane of the environment. */
 DLIMG_API int dlimg_amd_synchronize(dlimg_Environment env);
+/* Number of execution lanes (independent streams + workspaces over shared weights; DLIMGEDIT_LANES, default 3).
+ * Successive requests are spread over the lanes round-robin so independent images overlap on the GPU. */
+DLIMG_API int dlimg_amd_lane_count(dlimg_Environment env);
 
 /* ---- stage clocks (HIP events on the executor's stream) -------------------------------------- */
 #define DLIMG_AMD_STAGE_COUNT 8
 /* stage ids: 0 pre, 1 gemm (all MFMA GEMMs of the encoder), 2 layernorm, 3 attention_window,
  * 4 attention_global, 5 encoder_other, 6 decoder (whole prompt+mask decoder), 7 post */
+/* While profiling is enabled all requests run on lane 0 so per-kernel clocks are not disturbed by other lanes. */
 DLIMG_API int dlimg_amd_set_profiling(dlimg_Environment env, int enabled);
 /* Accumulated since the previous call: milliseconds, algorithmic work (FLOPs for stages 1,3,4,6;
  * bytes for the others) and launch counts; arrays of DLIMG_AMD_STAGE_COUNT. Resets the counters. */
