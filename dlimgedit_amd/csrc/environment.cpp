@@ -89,6 +89,7 @@ std::string EnvironmentImpl::find_sam_weights() const {
 EnvironmentImpl::SamLanes::SamLanes(std::string const& weight_path, int device, int count)
     : weights(std::make_shared<SamWeights>(weight_path, device)) {
     for (int i = 0; i < count; ++i) lanes.push_back(std::make_unique<SamModel>(weights));
+    k::gemm_set_shared_gpu(count > 1);
 }
 
 EnvironmentImpl::SamLanes& EnvironmentImpl::lanes() {

@@ -29,6 +29,8 @@ struct GemmArgs {
 };
 const char* gemm_check(const GemmArgs&);
 void gemm(const GemmArgs&, hipStream_t);
+// Tile selection hint: true when kernels of several execution lanes share the GPU.
+void gemm_set_shared_gpu(bool shared);
 
 // ---- row LayerNorm ---------------------------------------------------------------------------
 // y = (x-mean)/sqrt(var+eps)*w+b over rows of length D (<= 1280); optional GELU; f32 and/or f16 out.
