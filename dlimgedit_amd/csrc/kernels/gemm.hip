@@ -29,28 +29,33 @@
 namespace dlimg {
 namespace {
 
-constexpr int BK = 64;          // K elements per tile (128 bytes per row)
-constexpr int ROW_BYTES = 128;
+constexpr int BK_CHECK = 64;    // K must be a multiple of this for every configuration
 
-DLIMG_DEVICE int swz(int row) { return (row >> 1) & 7; }
+// LDS rows hold BKT halves (128 or 64 bytes).  The 16-byte chunk index is XOR-swizzled with row bits so that
+// the 16 rows a ds_read_b128 lane group touches land on 16 different 16-byte slots of the 256-byte bank row.
+template <int BKT> DLIMG_DEVICE int swz(int row) { return BKT == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
 
-// Issue the DMA copies of one ROWS x 64 operand tile (rows r0.. of `src`, K offset k0) into `lds`.
-template <int ROWS>
+// Issue the DMA copies of one ROWS x BKT operand tile (rows r0.. of `src`, K offset k0) into `lds`.
+// One wave-instruction moves 1 KiB = RPP rows; the pieces are dealt round-robin to the NW waves.
+template <int ROWS, int BKT, int NW>
 DLIMG_DEVICE void stage_tile(const half_t* __restrict__ src, int ld, int r0, int k0, char* lds, int wave, int lane) {
-    constexpr int PIECES = ROWS / 8;            // one wave-instruction moves 8 rows x 128 B
-    static_assert(PIECES % 4 == 0, "tile rows must be a multiple of 32");
+    constexpr int ROW_BYTES = BKT * 2;
+    constexpr int RPP = 1024 / ROW_BYTES;       // rows per piece (8 or 16)
+    constexpr int CPR = ROW_BYTES / 16;         // chunks per row (8 or 4)
+    constexpr int PIECES = ROWS / RPP;
+    static_assert(PIECES % NW == 0, "operand tile must split evenly over the waves");
 #pragma unroll
-    for (int q = 0; q < PIECES / 4; ++q) {
-        const int p = q * 4 + wave;
-        int row = p * 8 + (lane >> 3);
-        int chunk = (lane & 7) ^ swz(row);      // source-side swizzle, LDS stays linear
+    for (int q = 0; q < PIECES / NW; ++q) {
+        const int p = q * NW + wave;
+        const int row = p * RPP + lane / CPR;
+        const int chunk = (lane % CPR) ^ swz<BKT>(row);     // source-side swizzle, LDS stays linear
         const half_t* g = src + (size_t)(r0 + row) * ld + k0 + chunk * 8;
-        glds16(g, lds + p * 8 * ROW_BYTES);
+        glds16(g, lds + p * 1024);
     }
 }
 
-DLIMG_DEVICE half8_t read_frag(const char* lds, int row, int chunk) {
-    return *reinterpret_cast<const half8_t*>(lds + row * ROW_BYTES + ((chunk ^ swz(row)) << 4));
+template <int BKT> DLIMG_DEVICE half8_t read_frag(const char* lds, int row, int chunk) {
+    return *reinterpret_cast<const half8_t*>(lds + row * (BKT * 2) + ((chunk ^ swz<BKT>(row)) << 4));
 }
 
 // GELU(x) = 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7):
@@ -73,20 +78,23 @@ template <int N> DLIMG_DEVICE void wait_dma() { asm volatile("s_waitcnt vmcnt(%0
 
 // ABL (tuning builds only): 0 = real kernel, 1 = no MFMA / fragment reads (operand streaming alone),
 // 2 = no operand streaming after the first tile (MFMA + LDS reads alone).  Outputs are wrong for ABL != 0.
-template <int BM, int BN, int WGM, int WGN, int NSTAGE, int ACT, int ABL = 0>
-__global__ __launch_bounds__(256) void gemm_f16_kernel(k::GemmArgs a) {
-    static_assert(WGM * WGN == 4, "four waves per workgroup");
-    static_assert(NSTAGE >= 2 && NSTAGE <= 4, "2..4 LDS stages");
+template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE, int ACT, int ABL = 0>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(k::GemmArgs a) {
+    constexpr int NW = WGM * WGN;                   // waves per workgroup (4 or 8)
+    static_assert(NW == 4 || NW == 8, "four or eight waves per workgroup");
+    static_assert(NSTAGE >= 2 && NSTAGE <= 5, "2..5 LDS stages");
+    static_assert(BKT == 32 || BKT == 64, "K tile of 32 or 64");
+    constexpr int ROW_BYTES = BKT * 2;
     constexpr int WM = BM / WGM, WN = BN / WGN;     // wave tile
     constexpr int TM = WM / 32, TN = WN / 32;       // 32x32 MFMA tiles per wave
     constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;  // stage b: A tile at b*STAGE_BYTES, B tile behind it
-    constexpr int LOADS = (BM + BN) / 32;           // DMA wave-instructions per wave per K-tile
-    // epilogue staging: JG column tiles (JG*32 columns) of the wave tile at a time
+    constexpr int LOADS = (BM + BN) * ROW_BYTES / 1024 / NW;    // DMA wave-instructions per wave per K-tile
+    // epilogue staging: one 32-row tile band x JG column tiles of the wave tile at a time
     constexpr int JG = (TN % 3 == 0) ? 3 : ((TN % 2 == 0) ? 2 : 1);
     constexpr int CHUNKS = JG * 8;                  // 16-byte column chunks per staged row
-    constexpr int OUT_BYTES = WM * CHUNKS * 16;     // per-wave fp32 staging
-    static_assert(4 * OUT_BYTES <= NSTAGE * STAGE_BYTES, "output staging must fit in the operand buffers");
+    constexpr int OUT_BYTES = 32 * CHUNKS * 16;     // per-wave fp32 staging slab
+    static_assert(NW * OUT_BYTES <= NSTAGE * STAGE_BYTES, "output staging must fit in the operand buffers");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = lane_id();
@@ -105,11 +113,11 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(k::GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = zero16();
 
-    const int nk = a.K / BK;
+    const int nk = a.K / BKT;
     auto stage = [&](int kt) {
         char* dst = smem + (kt % NSTAGE) * STAGE_BYTES;
-        stage_tile<BM>(a.A, a.lda, m0, kt * BK, dst, wave, lane);
-        stage_tile<BN>(a.W, a.ldw, n0, kt * BK, dst + A_BYTES, wave, lane);
+        stage_tile<BM, BKT, NW>(a.A, a.lda, m0, kt * BKT, dst, wave, lane);
+        stage_tile<BN, BKT, NW>(a.W, a.ldw, n0, kt * BKT, dst + A_BYTES, wave, lane);
     };
     // prologue: NSTAGE-1 tiles in flight
 #pragma unroll
@@ -119,7 +127,8 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(k::GemmArgs a) {
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt has landed once at most `later` newer tiles of this wave are still in flight
         const int later = min(NSTAGE - 2, nk - 1 - kt);
-        if (later >= 2) wait_dma<2 * LOADS>();
+        if (later >= 3) wait_dma<3 * LOADS>();
+        else if (later == 2) wait_dma<2 * LOADS>();
         else if (later == 1) wait_dma<LOADS>();
         else wait_dma<0>();
         __builtin_amdgcn_s_barrier();            // ... for every wave; and everyone is done reading stage (kt-1)%NSTAGE
@@ -128,12 +137,12 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(k::GemmArgs a) {
         const char* la = smem + (kt % NSTAGE) * STAGE_BYTES;
         const char* lb = la + A_BYTES;
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
+        for (int ks = 0; ks < BKT / 16; ++ks) {
             half8_t fa[TM], fb[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = read_frag(la, wr * WM + i * 32 + l31, ks * 2 + hi);
+            for (int i = 0; i < TM; ++i) fa[i] = read_frag<BKT>(la, wr * WM + i * 32 + l31, ks * 2 + hi);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = read_frag(lb, wc * WN + j * 32 + l31, ks * 2 + hi);
+            for (int j = 0; j < TN; ++j) fb[j] = read_frag<BKT>(lb, wc * WN + j * 32 + l31, ks * 2 + hi);
             // swapped roles: D[row = n][col = m]; lane <-> m, registers <-> 4-groups of consecutive n
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -145,13 +154,12 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(k::GemmArgs a) {
     // ---- epilogue: accumulators -> LDS (row-major slab, chunk ^= row&7) -> coalesced rows -----------
     __syncthreads();                             // operand buffers are dead for every wave
     char* slab = smem + wave * OUT_BYTES;
-    constexpr int ITEMS = WM * CHUNKS;
+    constexpr int ITEMS = 32 * CHUNKS;
     static_assert(ITEMS % 64 == 0, "staged slab must split evenly over 64 lanes");
 #pragma unroll
-    for (int jg = 0; jg < TN / JG; ++jg) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int row = i * 32 + l31;
+        for (int jg = 0; jg < TN / JG; ++jg) {
 #pragma unroll
             for (int jj = 0; jj < JG; ++jj)
 #pragma unroll
@@ -159,43 +167,43 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(k::GemmArgs a) {
                     const int chunk = jj * 8 + g4 * 2 + hi;         // columns 4*chunk .. 4*chunk+3 of the slab
                     const float16_t& t = acc[i][jg * JG + jj];
                     float4_t v = {t[g4 * 4 + 0], t[g4 * 4 + 1], t[g4 * 4 + 2], t[g4 * 4 + 3]};
-                    *reinterpret_cast<float4_t*>(slab + (row * CHUNKS + (chunk ^ (row & 7))) * 16) = v;
+                    *reinterpret_cast<float4_t*>(slab + (l31 * CHUNKS + (chunk ^ (l31 & 7))) * 16) = v;
                 }
-        }
-        // each wave reads back only what it wrote itself: wave-local ordering is enough
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll 4
-        for (int it = 0; it < ITEMS / 64; ++it) {
-            const int idx = it * 64 + lane;
-            const int row = idx / CHUNKS, chunk = idx % CHUNKS;
-            float4_t v = *reinterpret_cast<const float4_t*>(slab + (row * CHUNKS + (chunk ^ (row & 7))) * 16);
-            const int m = m0 + wr * WM + row;
-            const int n = n0 + wc * WN + jg * JG * 32 + chunk * 4;
-            if (a.bias) v += *reinterpret_cast<const float4_t*>(a.bias + n);
-            if (ACT == k::ACT_GELU) {
+            // each wave reads back only what it wrote itself: wave-local ordering is enough
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
+            for (int it = 0; it < ITEMS / 64; ++it) {
+                const int idx = it * 64 + lane;
+                const int row = idx / CHUNKS, chunk = idx % CHUNKS;
+                float4_t v = *reinterpret_cast<const float4_t*>(slab + (row * CHUNKS + (chunk ^ (row & 7))) * 16);
+                const int m = m0 + wr * WM + i * 32 + row;
+                const int n = n0 + wc * WN + jg * JG * 32 + chunk * 4;
+                if (a.bias) v += *reinterpret_cast<const float4_t*>(a.bias + n);
+                if (ACT == k::ACT_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
+                }
+                if (a.resid) v += *reinterpret_cast<const float4_t*>(a.resid + (size_t)(m % a.resid_mod) * a.ldr + n);
+                if (a.out_f32) *reinterpret_cast<float4_t*>(a.out_f32 + (size_t)m * a.ldc32 + n) = v;
+                if (a.out_h) {
+                    half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                    *reinterpret_cast<half4_t*>(a.out_h + (size_t)m * a.ldc16 + n) = h;
+                }
             }
-            if (a.resid) v += *reinterpret_cast<const float4_t*>(a.resid + (size_t)(m % a.resid_mod) * a.ldr + n);
-            if (a.out_f32) *reinterpret_cast<float4_t*>(a.out_f32 + (size_t)m * a.ldc32 + n) = v;
-            if (a.out_h) {
-                half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                *reinterpret_cast<half4_t*>(a.out_h + (size_t)m * a.ldc16 + n) = h;
-            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // slab reads done before the next band overwrites it
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // slab reads done before the next group overwrites it
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int NSTAGE>
+template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE>
 void launch(const k::GemmArgs& a, hipStream_t s) {
     const int grid = (a.M / BM) * (a.N / BN);
-    const size_t lds = (size_t)NSTAGE * (BM + BN) * ROW_BYTES;
-    auto k0 = gemm_f16_kernel<BM, BN, WGM, WGN, NSTAGE, k::ACT_NONE>;
-    auto k1 = gemm_f16_kernel<BM, BN, WGM, WGN, NSTAGE, k::ACT_GELU>;
+    const size_t lds = (size_t)NSTAGE * (BM + BN) * BKT * 2;
+    auto k0 = gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, k::ACT_NONE>;
+    auto k1 = gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, k::ACT_GELU>;
     static const int ablate = [] { const char* e = std::getenv("DLIMGEDIT_GEMM_ABLATE"); return e ? std::atoi(e) : 0; }();
-    if (ablate == 1) k0 = gemm_f16_kernel<BM, BN, WGM, WGN, NSTAGE, k::ACT_NONE, 1>;
-    if (ablate == 2) k0 = gemm_f16_kernel<BM, BN, WGM, WGN, NSTAGE, k::ACT_NONE, 2>;
+    if (ablate == 1) k0 = gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, k::ACT_NONE, 1>;
+    if (ablate == 2) k0 = gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, k::ACT_NONE, 2>;
     if (lds > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -204,10 +212,11 @@ void launch(const k::GemmArgs& a, hipStream_t s) {
             attr_set = true;
         }
     }
+    const dim3 block(64 * WGM * WGN);
     if (a.act == k::ACT_GELU)
-        hipLaunchKernelGGL(k1, dim3(grid), dim3(256), lds, s, a);
+        hipLaunchKernelGGL(k1, dim3(grid), block, lds, s, a);
     else
-        hipLaunchKernelGGL(k0, dim3(grid), dim3(256), lds, s, a);
+        hipLaunchKernelGGL(k0, dim3(grid), block, lds, s, a);
 }
 
 }  // namespace
@@ -216,7 +225,7 @@ namespace k {
 
 const char* gemm_check(const GemmArgs& a) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return "gemm: empty problem";
-    if (a.M % 64 || a.N % 64 || a.K % BK) return "gemm: M, N must be multiples of 64 and K of 64";
+    if (a.M % 64 || a.N % 64 || a.K % BK_CHECK) return "gemm: M, N must be multiples of 64 and K of 64";
     if (a.lda % 8 || a.ldw % 8) return "gemm: operand leading dimensions must be multiples of 8 (16-byte rows)";
     if (a.lda < a.K || a.ldw < a.K) return "gemm: leading dimension smaller than K";
     if (((uintptr_t)a.A | (uintptr_t)a.W) & 15) return "gemm: operands must be 16-byte aligned";
@@ -234,12 +243,13 @@ const char* gemm_check(const GemmArgs& a) {
 // workgroup slots) x (relative efficiency of the tile) and the best one is launched.
 struct TileCfg { int bm, bn, per_cu; float eff; };
 constexpr TileCfg kTiles[] = {
-    {128, 384, 1, 1.00f},   // 0: 2x2 waves (64x192 each), 2 stages, 128 KB LDS
-    {128, 288, 1, 1.00f},   // 1: 4x1 waves (32x288 each), 3 stages, 156 KB LDS
-    {128, 128, 2, 0.80f},   // 2: 2x2 waves, 2 stages, 64 KB LDS
-    {128, 96, 1, 0.70f},    // 3: 4x1 waves, 4 stages, 112 KB LDS
-    {128, 64, 3, 0.55f},    // 4: 2x2 waves, 2 stages, 48 KB LDS
-    {64, 64, 4, 0.40f},     // 5: 2x2 waves, 2 stages, 32 KB LDS
+    {128, 384, 1, 1.00f},   // 0: 2x2 waves (64x192 each), BK 64, 2 stages, 128 KB LDS
+    {128, 288, 1, 1.00f},   // 1: 4x1 waves (32x288 each), BK 64, 3 stages, 156 KB LDS
+    {128, 128, 2, 0.80f},   // 2: 2x2 waves, BK 64, 2 stages, 64 KB LDS
+    {128, 96, 1, 0.70f},    // 3: 4x1 waves, BK 64, 4 stages, 112 KB LDS
+    {128, 64, 3, 0.55f},    // 4: 2x2 waves, BK 64, 2 stages, 48 KB LDS
+    {64, 64, 4, 0.40f},     // 5: 2x2 waves, BK 64, 2 stages, 32 KB LDS
+    {256, 256, 1, 0.00f},   // 6: 8 waves 2x4 (128x64 each), BK 32, 4 stages, 128 KB LDS (only when forced, for now)
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -250,10 +260,8 @@ static std::atomic<bool> g_shared_gpu{false};
 void gemm_set_shared_gpu(bool shared) { g_shared_gpu.store(shared); }
 
 int gemm_pick_tile(const GemmArgs& a) {
-    static const int forced = [] {
-        const char* e = std::getenv("DLIMGEDIT_GEMM_TILE");      // tuning aid, not a user knob
-        return e ? std::atoi(e) : -1;
-    }();
+    const char* forced_env = std::getenv("DLIMGEDIT_GEMM_TILE");   // tuning/test aid, not a user knob
+    const int forced = forced_env ? std::atoi(forced_env) : -1;
     int best = -1;
     float best_score = -1.f;
     for (int i = 0; i < kNumTiles; ++i) {
@@ -273,12 +281,13 @@ int gemm_pick_tile(const GemmArgs& a) {
 void gemm(const GemmArgs& a, hipStream_t s) {
     if (const char* err = gemm_check(a)) throw_error(err);
     switch (gemm_pick_tile(a)) {
-    case 0: return launch<128, 384, 2, 2, 2>(a, s);
-    case 1: return launch<128, 288, 4, 1, 3>(a, s);
-    case 2: return launch<128, 128, 2, 2, 2>(a, s);
-    case 3: return launch<128, 96, 4, 1, 4>(a, s);
-    case 4: return launch<128, 64, 2, 2, 2>(a, s);
-    case 5: return launch<64, 64, 2, 2, 2>(a, s);
+    case 0: return launch<128, 384, 2, 2, 64, 2>(a, s);
+    case 1: return launch<128, 288, 4, 1, 64, 3>(a, s);
+    case 2: return launch<128, 128, 2, 2, 64, 2>(a, s);
+    case 3: return launch<128, 96, 4, 1, 64, 4>(a, s);
+    case 4: return launch<128, 64, 2, 2, 64, 2>(a, s);
+    case 5: return launch<64, 64, 2, 2, 64, 2>(a, s);
+    case 6: return launch<256, 256, 2, 4, 32, 4>(a, s);
     default: throw_error("gemm: no tile configuration fits this shape");
     }
 }

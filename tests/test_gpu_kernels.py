@@ -153,6 +153,22 @@ def test_gemm_parity(ext, M, N, K, act, with_bias, resid_rows):
     assert np.array_equal(out16, out32.astype(np.float16))
 
 
+@pytest.mark.parametrize("tile,M,N,K", [(0, 256, 768, 192), (1, 256, 576, 256), (2, 256, 256, 128), (3, 256, 192, 320),
+                                        (4, 256, 128, 64), (5, 128, 64, 128), (6, 512, 512, 192), (6, 256, 256, 64)])
+def test_gemm_every_tile_configuration(ext, monkeypatch, tile, M, N, K):
+    """Each tile configuration (waves layout, K-tile, pipeline depth) against the fp32 product, incl. K tails
+    shorter than the pipeline depth."""
+    monkeypatch.setenv("DLIMGEDIT_GEMM_TILE", str(tile))
+    rng = np.random.default_rng(tile * 1000 + K)
+    A = rng.standard_normal((M, K)).astype(np.float16)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float16)
+    bias = rng.standard_normal(N).astype(np.float32)
+    resid = rng.standard_normal((M, N)).astype(np.float32)
+    out = ext.test_gemm(A, W, bias, resid, 0)
+    ref = _gemm_ref(A, W, bias, resid, 0)
+    assert np.abs(out - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max())
+
+
 def test_gemm_identity_layout(ext):
     """A = I against an asymmetric W catches a transposed or permuted C write."""
     K = 128
