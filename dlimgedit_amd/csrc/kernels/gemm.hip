@@ -78,8 +78,9 @@ template <int N> DLIMG_DEVICE void wait_dma() { asm volatile("s_waitcnt vmcnt(%0
 
 // ABL (tuning builds only): 0 = real kernel, 1 = no MFMA / fragment reads (operand streaming alone),
 // 2 = no operand streaming after the first tile (MFMA + LDS reads alone).  Outputs are wrong for ABL != 0.
-template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE, int ACT, int ABL = 0>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(k::GemmArgs a) {
+// MINW = waves per SIMD the register allocation must leave room for (workgroups per CU x waves / 4).
+template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE, int MINW, int ACT, int ABL = 0>
+__global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_f16_kernel(k::GemmArgs a) {
     constexpr int NW = WGM * WGN;                   // waves per workgroup (4 or 8)
     static_assert(NW == 4 || NW == 8, "four or eight waves per workgroup");
     static_assert(NSTAGE >= 2 && NSTAGE <= 5, "2..5 LDS stages");
@@ -169,21 +170,39 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(k::GemmArgs a)
                     float4_t v = {t[g4 * 4 + 0], t[g4 * 4 + 1], t[g4 * 4 + 2], t[g4 * 4 + 3]};
                     *reinterpret_cast<float4_t*>(slab + (l31 * CHUNKS + (chunk ^ (l31 & 7))) * 16) = v;
                 }
+            // residual / bias of the whole slab are requested up front: one exposed memory latency per slab
+            constexpr int NIT = ITEMS / 64;
+            constexpr bool BIAS_PER_LANE = (64 % CHUNKS == 0);    // then a lane sees the same columns in every iteration
+            constexpr int NB = BIAS_PER_LANE ? 1 : NIT;
+            float4_t rv[NIT], bv[NB];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = it * 64 + lane;
+                const int row = idx / CHUNKS, chunk = idx % CHUNKS;
+                const int m = m0 + wr * WM + i * 32 + row;
+                const int n = n0 + wc * WN + jg * JG * 32 + chunk * 4;
+                rv[it] = float4_t{0.f, 0.f, 0.f, 0.f};
+                if (a.resid) rv[it] = *reinterpret_cast<const float4_t*>(a.resid + (size_t)(m % a.resid_mod) * a.ldr + n);
+                if (it < NB) {
+                    bv[it] = float4_t{0.f, 0.f, 0.f, 0.f};
+                    if (a.bias) bv[it] = *reinterpret_cast<const float4_t*>(a.bias + n);
+                }
+            }
             // each wave reads back only what it wrote itself: wave-local ordering is enough
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int it = 0; it < ITEMS / 64; ++it) {
+            for (int it = 0; it < NIT; ++it) {
                 const int idx = it * 64 + lane;
                 const int row = idx / CHUNKS, chunk = idx % CHUNKS;
                 float4_t v = *reinterpret_cast<const float4_t*>(slab + (row * CHUNKS + (chunk ^ (row & 7))) * 16);
                 const int m = m0 + wr * WM + i * 32 + row;
                 const int n = n0 + wc * WN + jg * JG * 32 + chunk * 4;
-                if (a.bias) v += *reinterpret_cast<const float4_t*>(a.bias + n);
+                v += bv[BIAS_PER_LANE ? 0 : it];
                 if (ACT == k::ACT_GELU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
                 }
-                if (a.resid) v += *reinterpret_cast<const float4_t*>(a.resid + (size_t)(m % a.resid_mod) * a.ldr + n);
+                v += rv[it];
                 if (a.out_f32) *reinterpret_cast<float4_t*>(a.out_f32 + (size_t)m * a.ldc32 + n) = v;
                 if (a.out_h) {
                     half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
@@ -195,15 +214,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(k::GemmArgs a)
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE>
+template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE, int MINW>
 void launch(const k::GemmArgs& a, hipStream_t s) {
     const int grid = (a.M / BM) * (a.N / BN);
     const size_t lds = (size_t)NSTAGE * (BM + BN) * BKT * 2;
-    auto k0 = gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, k::ACT_NONE>;
-    auto k1 = gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, k::ACT_GELU>;
+    auto k0 = gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_NONE>;
+    auto k1 = gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_GELU>;
     static const int ablate = [] { const char* e = std::getenv("DLIMGEDIT_GEMM_ABLATE"); return e ? std::atoi(e) : 0; }();
-    if (ablate == 1) k0 = gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, k::ACT_NONE, 1>;
-    if (ablate == 2) k0 = gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, k::ACT_NONE, 2>;
+    if (ablate == 1) k0 = gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_NONE, 1>;
+    if (ablate == 2) k0 = gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_NONE, 2>;
     if (lds > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -281,13 +300,13 @@ int gemm_pick_tile(const GemmArgs& a) {
 void gemm(const GemmArgs& a, hipStream_t s) {
     if (const char* err = gemm_check(a)) throw_error(err);
     switch (gemm_pick_tile(a)) {
-    case 0: return launch<128, 384, 2, 2, 64, 2>(a, s);
-    case 1: return launch<128, 288, 4, 1, 64, 3>(a, s);
-    case 2: return launch<128, 128, 2, 2, 64, 2>(a, s);
-    case 3: return launch<128, 96, 4, 1, 64, 4>(a, s);
-    case 4: return launch<128, 64, 2, 2, 64, 2>(a, s);
-    case 5: return launch<64, 64, 2, 2, 64, 2>(a, s);
-    case 6: return launch<256, 256, 2, 4, 32, 4>(a, s);
+    case 0: return launch<128, 384, 2, 2, 64, 2, 1>(a, s);
+    case 1: return launch<128, 288, 4, 1, 64, 3, 1>(a, s);
+    case 2: return launch<128, 128, 2, 2, 64, 2, 4>(a, s);
+    case 3: return launch<128, 96, 4, 1, 64, 4, 1>(a, s);
+    case 4: return launch<128, 64, 2, 2, 64, 2, 3>(a, s);
+    case 5: return launch<64, 64, 2, 2, 64, 2, 4>(a, s);
+    case 6: return launch<256, 256, 2, 4, 32, 4, 2>(a, s);
     default: throw_error("gemm: no tile configuration fits this shape");
     }
 }
