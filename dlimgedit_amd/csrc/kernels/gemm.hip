@@ -283,11 +283,21 @@ int gemm_pick_tile(const GemmArgs& a) {
     const int forced = forced_env ? std::atoi(forced_env) : -1;
     int best = -1;
     float best_score = -1.f;
+    if (g_shared_gpu.load(std::memory_order_relaxed) && forced < 0 && a.M % 256 == 0 && a.N % 256 == 0 &&
+        (a.M / 256) * (a.N / 256) >= 128)
+        return 6;
     for (int i = 0; i < kNumTiles; ++i) {
         const TileCfg& t = kTiles[i];
         if (a.M % t.bm || a.N % t.bn) continue;
         if (i == forced) return i;
-        if (g_shared_gpu.load(std::memory_order_relaxed) && t.per_cu < 2 && forced < 0) continue;
+        if (g_shared_gpu.load(std::memory_order_relaxed) && forced < 0) {
+            // shared GPU: other lanes fill the CUs this launch leaves free, so the only question is operand
+            // traffic per FLOP -- the 256x256 tile (128 FLOP/B) whenever it yields enough workgroups,
+            // otherwise the tiles that can share a CU
+            const int blocks = (a.M / t.bm) * (a.N / t.bn);
+            if (i == 6 && blocks >= 128) return i;
+            if (t.per_cu < 2) continue;
+        }
         const int blocks = (a.M / t.bm) * (a.N / t.bn);
         const int slots = 256 * t.per_cu;
         const int rounds = (blocks + slots - 1) / slots;
