@@ -18,6 +18,8 @@
 #include "device_common.hpp"
 #include "kernels.hpp"
 
+#include <cstdlib>
+
 namespace dlimg {
 namespace {
 
@@ -30,7 +32,9 @@ typedef short short4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) short4_t lds_short4_t;
 constexpr int GW_STRIDE = 33;       // floats per query row of the prologue scratch (32 rel rows + 1)
 
-template <int HD>
+// ABL (tuning builds only, wrong results): 1 = no K/V staging after the first tiles, 2 = no softmax arithmetic,
+// 3 = no P.V product
+template <int HD, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void attention_global_kernel(const half_t* __restrict__ qkv,
                                                                   const float* __restrict__ rel_h,
                                                                   const float* __restrict__ rel_w,
@@ -126,8 +130,10 @@ __global__ __launch_bounds__(256, 2) void attention_global_kernel(const half_t* 
 
     // ---- K/V tile staging ------------------------------------------------------------------------
     // consecutive lanes take consecutive 16-byte chunks of a key row: every global line is used whole
-    half8_t kreg[STAGE_ITERS], vreg[STAGE_ITERS];
-    auto load_tile = [&](int t) {
+    // two register sets: a tile is requested two iterations before it is written to LDS, so a full
+    // iteration of MFMA work covers the (loaded) L2 latency
+    half8_t kregA[STAGE_ITERS], vregA[STAGE_ITERS], kregB[STAGE_ITERS], vregB[STAGE_ITERS];
+    auto load_tile = [&](int t, half8_t* kreg, half8_t* vreg) {
 #pragma unroll
         for (int it = 0; it < STAGE_ITERS; ++it) {
             const int idx = it * 256 + tid;
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void attention_global_kernel(const half_t* 
             }
         }
     };
-    auto write_tile = [&](int buf) {
+    auto write_tile = [&](int buf, const half8_t* kreg, const half8_t* vreg) {
         half_t* kd = lds_k + buf * K_TILE;
         half_t* vd = lds_v + buf * V_TILE;
 #pragma unroll
@@ -157,8 +163,9 @@ __global__ __launch_bounds__(256, 2) void attention_global_kernel(const half_t* 
         for (int idx = tid; idx < 2 * V_TILE / 2; idx += 256) reinterpret_cast<uint32_t*>(lds_v)[idx] = 0u;
         __syncthreads();
     }
-    load_tile(0);
-    write_tile(0);
+    load_tile(0, kregA, vregA);
+    write_tile(0, kregA, vregA);
+    load_tile(1, kregB, vregB);
     __syncthreads();
 
     // transposed-read addressing (cdna_hip_programming.md T10): in each 16-lane group, lane 4q+p points
@@ -172,23 +179,22 @@ __global__ __launch_bounds__(256, 2) void attention_global_kernel(const half_t* 
     float m = -INFINITY, l = 0.f;
 
     constexpr int NT = TOKENS / KT;
-    for (int t = 0; t < NT; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < NT) load_tile(t + 1);
+    static_assert(NT % 2 == 0, "the key loop is unrolled by two");
+    auto process_tile = [&](int t, int buf) {
 
         const half_t* kb = lds_k + buf * K_TILE;
         const half_t* vb = lds_v + buf * V_TILE + tr_off;
         const float rh = relh_lds[(wave * 64 + t) * RELH_STRIDE + l31];
 
+        // S^T tile = relw (initial accumulator, no copy: C and D of the first MFMA are different registers)
+        //            + K . Q^T; the per-tile scalar rh joins in the exponent offset below
         float16_t s[2];
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[jt][r] = relw[jt][r] + rh;
-#pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 half8_t kf = *reinterpret_cast<const half8_t*>(kb + (jt * 32 + l31) * K_STRIDE + ks * 16 + hi * 8);
-                s[jt] = mfma32(kf, qf[ks], s[jt]);
+                s[jt] = mfma32(kf, qf[ks], ks == 0 ? relw[jt] : s[jt]);
             }
         }
 
@@ -198,16 +204,17 @@ __global__ __launch_bounds__(256, 2) void attention_global_kernel(const half_t* 
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) tm = fmaxf(tm, s[jt][r]);
-        tm = fmaxf(tm, swap_halves(tm));
+        tm = fmaxf(tm, swap_halves(tm)) + rh;
         const float m_new = fmaxf(m, tm);
         const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c);
+        const float off = (rh - m_new) * c;
         m = m_new;
         float ps = 0.f;
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float p = __builtin_amdgcn_exp2f((s[jt][r] - m_new) * c);
+                float p = ABL == 2 ? s[jt][r] : __builtin_amdgcn_exp2f(fmaf(s[jt][r], c, off));
                 s[jt][r] = p;
                 ps += p;
             }
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void attention_global_kernel(const half_t* 
                 for (int e = 0; e < 8; ++e) pf[e] = (half_t)s[jt][st * 8 + e];
                 const int key0 = jt * 32 + st * 16;         // element e <-> key0 + 4*hi + 8*(e>>2) + (e&3)
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
+                for (int dt = 0; dt < (ABL == 3 ? 0 : DT); ++dt) {
                     const half_t* vp = vb + key0 * V_STRIDE + dt * 32;
                     const short4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_t*)vp);
                     const short4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_t*)(vp + 8 * V_STRIDE));
@@ -240,7 +247,15 @@ __global__ __launch_bounds__(256, 2) void attention_global_kernel(const half_t* 
             }
         }
 
-        if (t + 1 < NT) write_tile(buf ^ 1);
+    };
+    for (int t = 0; t < NT; t += 2) {
+        if (t + 2 < NT && ABL != 1) load_tile(t + 2, kregA, vregA);
+        process_tile(t, 0);
+        if (ABL != 1) write_tile(1, kregB, vregB);      // tile t+1, requested one iteration ago
+        __syncthreads();
+        if (t + 3 < NT && ABL != 1) load_tile(t + 3, kregB, vregB);
+        process_tile(t + 1, 1);
+        if (t + 2 < NT && ABL != 1) write_tile(0, kregA, vregA);    // tile t+2
         __syncthreads();
     }
 
@@ -274,8 +289,13 @@ void launch_global(const half_t* qkv, const float* rel_h, const float* rel_w, ha
                                   (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(attention_global_kernel<HD>, dim3(B * heads * (TOKENS / 128)), dim3(256), lds, s, qkv, rel_h,
-                       rel_w, out, heads);
+    static const int ablate = [] { const char* e = std::getenv("DLIMGEDIT_ATTN_ABLATE"); return e ? std::atoi(e) : 0; }();
+    auto kern = attention_global_kernel<HD, 0>;
+    if (HD == 64 && ablate == 1) kern = attention_global_kernel<HD, 1>;
+    if (HD == 64 && ablate == 2) kern = attention_global_kernel<HD, 2>;
+    if (HD == 64 && ablate == 3) kern = attention_global_kernel<HD, 3>;
+    if (ablate) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(B * heads * (TOKENS / 128)), dim3(256), lds, s, qkv, rel_h, rel_w, out, heads);
 }
 
 }  // namespace

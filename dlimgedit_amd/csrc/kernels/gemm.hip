@@ -128,7 +128,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_f16_kernel(k::GemmA
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt has landed once at most `later` newer tiles of this wave are still in flight
         const int later = min(NSTAGE - 2, nk - 1 - kt);
-        if (later >= 3) wait_dma<3 * LOADS>();
+        if (later >= 4) wait_dma<4 * LOADS>();
+        else if (later == 3) wait_dma<3 * LOADS>();
         else if (later == 2) wait_dma<2 * LOADS>();
         else if (later == 1) wait_dma<LOADS>();
         else wait_dma<0>();
@@ -268,7 +269,7 @@ constexpr TileCfg kTiles[] = {
     {128, 96, 1, 0.70f},    // 3: 4x1 waves, BK 64, 4 stages, 112 KB LDS
     {128, 64, 3, 0.55f},    // 4: 2x2 waves, BK 64, 2 stages, 48 KB LDS
     {64, 64, 4, 0.40f},     // 5: 2x2 waves, BK 64, 2 stages, 32 KB LDS
-    {256, 256, 1, 0.00f},   // 6: 8 waves 2x4 (128x64 each), BK 32, 4 stages, 128 KB LDS (only when forced, for now)
+    {256, 256, 1, 0.00f},   // 6: 8 waves 2x4 (128x64 each), BK 32, 4 stages, 128 KB LDS (shared-GPU mode or forced)
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -294,8 +295,6 @@ int gemm_pick_tile(const GemmArgs& a) {
             // shared GPU: other lanes fill the CUs this launch leaves free, so the only question is operand
             // traffic per FLOP -- the 256x256 tile (128 FLOP/B) whenever it yields enough workgroups,
             // otherwise the tiles that can share a CU
-            const int blocks = (a.M / t.bm) * (a.N / t.bn);
-            if (i == 6 && blocks >= 128) return i;
             if (t.per_cu < 2) continue;
         }
         const int blocks = (a.M / t.bm) * (a.N / t.bn);
