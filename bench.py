@@ -168,10 +168,19 @@ def main() -> None:
         ext.set_profiling(env, False)
         g = st["gemm"]
         achieved = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        # HBM-side bytes per GEMM launch come from a separate rocprofv3 --pmc run of this same command
+        # (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); null if not collected
+        traffic, traffic_note = None, None
+        tfile = ROOT / "profiles" / "r01_hbm_traffic_pmc.json"
+        if tfile.exists() and args.model == "vit_b" and B == 1:
+            t = json.loads(tfile.read_text())["per_kernel"].get("gemm")
+            if t:
+                traffic = t["fetch_bytes_per_launch_corrected_x2"] + t["write_bytes_per_launch"]
+                traffic_note = "bytes per launch from profiles/r01_hbm_traffic_pmc.json (separate --pmc passes)"
         result["roofline"] = {
             "kernel": "gemm_f16_kernel (all encoder/decoder MFMA GEMM launches)",
             "bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": None,
+            "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
             "launches": g["launches"], "avg_launch_us": 1e3 * g["ms"] / max(1, g["launches"]),
             "flops_per_launch": g["work"] / max(1, g["launches"]),
         }
@@ -208,13 +217,26 @@ def main() -> None:
         t_enc = time.perf_counter() - t0
         cpu_mask = ora.compute_mask(point=(512, 512))
         t_all = time.perf_counter() - t0
-        inter = np.logical_and(gpu_mask > 0, cpu_mask > 0).sum()
-        union = np.logical_or(gpu_mask > 0, cpu_mask > 0).sum()
+
+        def iou_of(a, b):
+            union = np.logical_or(a > 0, b > 0).sum()
+            return float(np.logical_and(a > 0, b > 0).sum()) / float(union) if union else 1.0
+
         result["cpu_baseline"] = {"value": 1.0 / t_all, "unit": "images/s", "cores": threads, "kind": "port",
                                   "sample": f"1 image of the same workload ({args.model} encode {t_enc:.1f} s + 1 point "
                                             f"mask {t_all - t_enc:.2f} s), numpy fp32 oracle, BLAS threads = host cores"}
-        result["mask_iou"] = float(inter) / float(union) if union else 1.0
-        result["mask_foreground_frac"] = float((cpu_mask > 0).mean())
+        # mask IoU vs the CPU oracle: the timed prompt plus further prompts through the drop-in ABI
+        seg = api.Segmentation.process(api.ImageView(imgs[0], api.Channels.rgba), env)
+        checks = [{"prompt": "point(512,512) [timed step]", "iou": iou_of(gpu_mask, cpu_mask),
+                   "foreground": float((cpu_mask > 0).mean())}]
+        for name, gp, op in (("point(200,800)", api.Point(200, 800), dict(point=(200, 800))),
+                             ("point(800,200)", api.Point(800, 200), dict(point=(800, 200))),
+                             ("box(256,256,768,768)", api.Region(api.Point(256, 256), api.Point(768, 768)),
+                              dict(region=(256, 256, 768, 768)))):
+            want = ora.compute_mask(**op)
+            checks.append({"prompt": name, "iou": iou_of(seg.compute_mask(gp), want), "foreground": float((want > 0).mean())})
+        result["mask_iou"] = min(c["iou"] for c in checks)
+        result["mask_iou_checks"] = checks
 
     if rank == 0:
         print(json.dumps(result))

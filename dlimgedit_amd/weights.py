@@ -315,6 +315,9 @@ def from_hf_state_dict(cfg: SamConfig, sd) -> Dict[str, np.ndarray]:
     def a(x):
         return np.ascontiguousarray(x.detach().cpu().numpy() if hasattr(x, "detach") else x, dtype=np.float32)
     d = cfg.embed_dim
+    missing = [hf for _, hf in hf_name_map(cfg) if hf not in sd]
+    if missing:
+        raise ValueError(f"state dict lacks {len(missing)} tensors of {cfg.name} (wrong variant?), e.g. {missing[0]}")
     p = {ours: a(sd[hf]) for ours, hf in hf_name_map(cfg)}
     p["enc.patch.w"] = a(sd["vision_encoder.patch_embed.projection.weight"]).reshape(d, -1)
     p["enc.pos"] = a(sd["vision_encoder.pos_embed"]).reshape(-1, d)
@@ -326,4 +329,96 @@ def from_hf_state_dict(cfg: SamConfig, sd) -> Dict[str, np.ndarray]:
     for n, s in want.items():
         if tuple(p[n].shape) != tuple(s):
             raise ValueError(f"{n}: checkpoint shape {p[n].shape} != {s}")
+    return p
+
+
+# ---------------------------------------------------------------------------------------------
+# Meta `segment_anything` checkpoint naming (sam_vit_{b,l,h}_*.pth): same tensors, different keys
+
+def _meta_attn(prefix: str):
+    return {"q": f"{prefix}.q_proj", "k": f"{prefix}.k_proj", "v": f"{prefix}.v_proj", "o": f"{prefix}.out_proj"}
+
+
+def meta_name_map(cfg: SamConfig) -> List[Tuple[str, str]]:
+    """(our name, key in Meta's `Sam.state_dict()`) for tensors that map one-to-one."""
+    m = [("enc.patch.b", "image_encoder.patch_embed.proj.bias"),
+         ("enc.neck.ln1.w", "image_encoder.neck.1.weight"), ("enc.neck.ln1.b", "image_encoder.neck.1.bias"),
+         ("enc.neck.conv2.w", "image_encoder.neck.2.weight"),
+         ("enc.neck.ln2.w", "image_encoder.neck.3.weight"), ("enc.neck.ln2.b", "image_encoder.neck.3.bias"),
+         ("pe.gauss", "prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"),
+         ("dec.mask_tokens", "mask_decoder.mask_tokens.weight"),
+         ("dec.ln_final.w", "mask_decoder.transformer.norm_final_attn.weight"),
+         ("dec.ln_final.b", "mask_decoder.transformer.norm_final_attn.bias"),
+         ("dec.up1.w", "mask_decoder.output_upscaling.0.weight"), ("dec.up1.b", "mask_decoder.output_upscaling.0.bias"),
+         ("dec.up_ln.w", "mask_decoder.output_upscaling.1.weight"), ("dec.up_ln.b", "mask_decoder.output_upscaling.1.bias"),
+         ("dec.up2.w", "mask_decoder.output_upscaling.3.weight"), ("dec.up2.b", "mask_decoder.output_upscaling.3.bias")]
+    for i in range(cfg.depth):
+        a, b = f"enc.L{i}", f"image_encoder.blocks.{i}"
+        m += [(f"{a}.ln1.w", f"{b}.norm1.weight"), (f"{a}.ln1.b", f"{b}.norm1.bias"),
+              (f"{a}.qkv.w", f"{b}.attn.qkv.weight"), (f"{a}.qkv.b", f"{b}.attn.qkv.bias"),
+              (f"{a}.rel_h", f"{b}.attn.rel_pos_h"), (f"{a}.rel_w", f"{b}.attn.rel_pos_w"),
+              (f"{a}.proj.w", f"{b}.attn.proj.weight"), (f"{a}.proj.b", f"{b}.attn.proj.bias"),
+              (f"{a}.ln2.w", f"{b}.norm2.weight"), (f"{a}.ln2.b", f"{b}.norm2.bias"),
+              (f"{a}.fc1.w", f"{b}.mlp.lin1.weight"), (f"{a}.fc1.b", f"{b}.mlp.lin1.bias"),
+              (f"{a}.fc2.w", f"{b}.mlp.lin2.weight"), (f"{a}.fc2.b", f"{b}.mlp.lin2.bias")]
+
+    def attn(ours, theirs):
+        r = []
+        for p, q in _meta_attn(theirs).items():
+            r += [(f"{ours}.{p}.w", f"{q}.weight"), (f"{ours}.{p}.b", f"{q}.bias")]
+        return r
+    for i in range(DEC_DEPTH):
+        a, b = f"dec.L{i}", f"mask_decoder.transformer.layers.{i}"
+        m += attn(f"{a}.self", f"{b}.self_attn")
+        m += attn(f"{a}.t2i", f"{b}.cross_attn_token_to_image")
+        m += attn(f"{a}.i2t", f"{b}.cross_attn_image_to_token")
+        for k in (1, 2, 3, 4):
+            m += [(f"{a}.ln{k}.w", f"{b}.norm{k}.weight"), (f"{a}.ln{k}.b", f"{b}.norm{k}.bias")]
+        m += [(f"{a}.mlp.fc1.w", f"{b}.mlp.lin1.weight"), (f"{a}.mlp.fc1.b", f"{b}.mlp.lin1.bias"),
+              (f"{a}.mlp.fc2.w", f"{b}.mlp.lin2.weight"), (f"{a}.mlp.fc2.b", f"{b}.mlp.lin2.bias")]
+    m += attn("dec.final", "mask_decoder.transformer.final_attn_token_to_image")
+    for t in range(NUM_MASK_TOKENS):
+        for j in range(3):
+            m += [(f"dec.hyper{t}.{j}.w", f"mask_decoder.output_hypernetworks_mlps.{t}.layers.{j}.weight"),
+                  (f"dec.hyper{t}.{j}.b", f"mask_decoder.output_hypernetworks_mlps.{t}.layers.{j}.bias")]
+    for j in range(3):
+        m += [(f"dec.iou.{j}.w", f"mask_decoder.iou_prediction_head.layers.{j}.weight"),
+              (f"dec.iou.{j}.b", f"mask_decoder.iou_prediction_head.layers.{j}.bias")]
+    return m
+
+
+def to_meta_state_dict(cfg: SamConfig, params: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    d, g = cfg.embed_dim, cfg.grid
+    sd = {theirs: params[ours] for ours, theirs in meta_name_map(cfg)}
+    sd["image_encoder.patch_embed.proj.weight"] = params["enc.patch.w"].reshape(d, 3, cfg.patch_size, cfg.patch_size)
+    sd["image_encoder.pos_embed"] = params["enc.pos"].reshape(1, g, g, d)
+    sd["image_encoder.neck.0.weight"] = params["enc.neck.conv1.w"].reshape(cfg.out_chans, d, 1, 1)
+    for i in range(4):
+        sd[f"prompt_encoder.point_embeddings.{i}.weight"] = params["pe.point"][i:i + 1]
+    sd["prompt_encoder.not_a_point_embed.weight"] = params["pe.not_a_point"].reshape(1, -1)
+    sd["prompt_encoder.no_mask_embed.weight"] = params["pe.no_mask"].reshape(1, -1)
+    sd["mask_decoder.iou_token.weight"] = params["dec.iou_token"].reshape(1, -1)
+    return sd
+
+
+def from_meta_state_dict(cfg: SamConfig, sd) -> Dict[str, np.ndarray]:
+    """Meta checkpoint (`torch.load('sam_vit_b_01ec64.pth')`) -> our tensors.  Unused tensors of the
+    checkpoint (mask_downscaling.*: the mask-input branch, never taken here) are ignored."""
+    def a(x):
+        return np.ascontiguousarray(x.detach().cpu().numpy() if hasattr(x, "detach") else x, dtype=np.float32)
+    d = cfg.embed_dim
+    missing = [theirs for _, theirs in meta_name_map(cfg) if theirs not in sd]
+    if missing:
+        raise ValueError(f"checkpoint lacks {len(missing)} tensors of {cfg.name} (wrong variant?), e.g. {missing[0]}")
+    p = {ours: a(sd[theirs]) for ours, theirs in meta_name_map(cfg)}
+    p["enc.patch.w"] = a(sd["image_encoder.patch_embed.proj.weight"]).reshape(d, -1)
+    p["enc.pos"] = a(sd["image_encoder.pos_embed"]).reshape(-1, d)
+    p["enc.neck.conv1.w"] = a(sd["image_encoder.neck.0.weight"]).reshape(cfg.out_chans, d)
+    p["pe.point"] = np.concatenate([a(sd[f"prompt_encoder.point_embeddings.{i}.weight"]) for i in range(4)], 0)
+    p["pe.not_a_point"] = a(sd["prompt_encoder.not_a_point_embed.weight"]).reshape(-1)
+    p["pe.no_mask"] = a(sd["prompt_encoder.no_mask_embed.weight"]).reshape(-1)
+    p["dec.iou_token"] = a(sd["mask_decoder.iou_token.weight"]).reshape(-1)
+    for n, s, _ in param_specs(cfg):
+        if tuple(p[n].shape) != tuple(s):
+            raise ValueError(f"{n}: checkpoint shape {p[n].shape} != {s} (wrong variant?)")
     return p

@@ -64,3 +64,18 @@ def test_hf_mapping_is_a_bijection_on_our_inventory():
         back = W.from_hf_state_dict(cfg, sd)
         assert set(back) == set(specs)
         assert all(tuple(back[n].shape) == tuple(specs[n]) for n in specs)
+
+
+def test_meta_checkpoint_mapping_round_trips():
+    """Meta `segment_anything` key names <-> ours (tools/convert_checkpoint.py path)."""
+    cfg = CONFIGS["vit_test"]
+    params = W.synthetic_weights(cfg, 5)
+    sd = W.to_meta_state_dict(cfg, params)
+    assert "image_encoder.blocks.1.attn.rel_pos_h" in sd and "mask_decoder.output_upscaling.3.weight" in sd
+    sd["prompt_encoder.mask_downscaling.0.weight"] = np.zeros((4, 1, 2, 2), np.float32)    # unused branch is ignored
+    back = W.from_meta_state_dict(cfg, sd)
+    assert set(back) == set(params)
+    for k in params:
+        assert np.array_equal(back[k], params[k]), k
+    with pytest.raises(ValueError, match="wrong variant"):
+        W.from_meta_state_dict(CONFIGS["vit_b"], sd)
