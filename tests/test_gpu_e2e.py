@@ -205,3 +205,64 @@ def test_non_1024_images_end_to_end(api, session, w, h, channels, point):
     want = ora.compute_mask(point=point)
     assert got.shape == (h, w)
     assert iou(got, want) >= IOU_BAR, iou(got, want)
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (3, 1024), (2048, 16), (1024, 1), (17, 13), (4000, 3000)])
+def test_extreme_geometries(api, session, w, h):
+    """Degenerate and extreme aspect ratios go through resize, padding and the second bilinear without
+    touching memory out of bounds; masks have the input's extent and match the oracle."""
+    from oracle import sam_oracle as O
+    env, params, cfg, *_ = session
+    img = synthetic_image(w * 7 + h, width=w, height=h, channels=4)
+    seg = api.Segmentation.process(api.ImageView(img, api.Channels.rgba), env)
+    assert seg.extent() == api.Extent(w, h)
+    pt = (w // 2, h // 2)
+    got = seg.compute_mask(api.Point(*pt))
+    assert got.shape == (h, w) and set(np.unique(got)) <= {0, 255}
+    if w * h <= 2048 * 16:          # keep the oracle side cheap
+        ora = O.OracleSegmentation(params, cfg).process(img, O.CH_RGBA)
+        want = ora.compute_mask(point=pt)
+        assert (got != want).mean() <= 0.02
+
+
+def test_prompts_outside_the_image_and_degenerate_boxes(api, session):
+    *_, seg, ora = session
+    for pt in [(-50, -50), (5000, 5000), (0, 0), (1023, 1023)]:
+        got = seg.compute_mask(api.Point(*pt))
+        want = ora.compute_mask(point=pt)
+        assert iou(got, want) >= IOU_BAR or (got != want).mean() < 0.01
+    got = seg.compute_mask(api.Region(api.Point(700, 700), api.Point(100, 100)))      # inverted box
+    want = ora.compute_mask(region=(700, 700, 100, 100))
+    assert iou(got, want) >= IOU_BAR or (got != want).mean() < 0.01
+
+
+def test_mask_and_rgb_inputs(api, session):
+    """1-channel (mask) and 3-channel inputs: the channel map replicates / selects as the reference does."""
+    from oracle import sam_oracle as O
+    env, params, cfg, img, *_ = session
+    gray = np.ascontiguousarray(img[:, :, 0])
+    seg = api.Segmentation.process(api.ImageView(gray, api.Channels.mask), env)
+    ora = O.OracleSegmentation(params, cfg).process(gray, O.CH_MASK)
+    assert np.abs(api.ext.get_embedding(seg) - ora.embedding).max() < EMB_TOL
+    rgb = np.ascontiguousarray(img[:, :, :3])
+    seg3 = api.Segmentation.process(api.ImageView(rgb, api.Channels.rgb), env)
+    assert np.array_equal(api.ext.get_embedding(seg3), api.ext.get_embedding(session[4]))
+
+
+def test_invalid_arguments_are_errors_not_crashes(api, session):
+    env, _, _, img, seg, _ = session
+    bad = api.ImageView(img, api.Channels.rgba)
+    bad.channels = 2            # not a dlimg::Channels value
+    with pytest.raises(api.Error, match="Unsupported channel order"):
+        api.Segmentation.process(bad, env)
+    narrow = api.ImageView(img, api.Channels.rgba)
+    narrow.stride = 100         # smaller than one row
+    with pytest.raises(api.Error, match="Assertion failed"):
+        api.Segmentation.process(narrow, env)
+    import ctypes as C
+    masks = (C.c_void_p * 3)(None, None, None)
+    acc = (C.c_float * 3)()
+    pt = (C.c_int * 2)(1, 1)
+    assert api.api().get_segmentation_mask(seg._handle, pt, None, masks, acc) == 1     # null output buffer
+    assert b"Assertion failed" in api.api().last_error()
+    assert api.api().get_segmentation_mask(seg._handle, None, None, masks, acc) == 1    # neither point nor region
