@@ -6,6 +6,7 @@
 
 #include <dlimgedit/dlimgedit_amd.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -361,8 +362,9 @@ DLIMG_API int dlimg_amd_bench_gemm(int M, int N, int K, int act, int iters, doub
         std::vector<half_t> ha((size_t)M * K), hw((size_t)N * K);
         uint32_t seed = 12345u;
         auto rnd = [&] { seed = seed * 1664525u + 1013904223u; return ((seed >> 8) & 0xffff) / 32768.0f - 1.0f; };
-        for (auto& v : ha) v = (half_t)rnd();
-        for (auto& v : hw) v = (half_t)(rnd() * 0.05f);
+        const bool zeros = std::getenv("DLIMGEDIT_BENCH_ZERO") != nullptr;     // clock experiment: all-zero operands
+        for (auto& v : ha) v = zeros ? (half_t)0.f : (half_t)rnd();
+        for (auto& v : hw) v = zeros ? (half_t)0.f : (half_t)(rnd() * 0.05f);
         Upload<half_t> a(ha.data(), ha.size()), w(hw.data(), hw.size());
         DeviceBuffer<half_t> o((size_t)M * N);
         k::GemmArgs g;

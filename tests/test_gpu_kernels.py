@@ -154,7 +154,8 @@ def test_gemm_parity(ext, M, N, K, act, with_bias, resid_rows):
 
 
 @pytest.mark.parametrize("tile,M,N,K", [(0, 256, 768, 192), (1, 256, 576, 256), (2, 256, 256, 128), (3, 256, 192, 320),
-                                        (4, 256, 128, 64), (5, 128, 64, 128), (6, 512, 512, 192), (6, 256, 256, 64)])
+                                        (4, 256, 128, 64), (5, 128, 64, 128), (6, 512, 512, 192), (6, 256, 256, 64),
+                                        (7, 512, 512, 192), (7, 256, 256, 64), (8, 256, 384, 320)])
 def test_gemm_every_tile_configuration(ext, monkeypatch, tile, M, N, K):
     """Each tile configuration (waves layout, K-tile, pipeline depth) against the fp32 product, incl. K tails
     shorter than the pipeline depth."""
