@@ -374,10 +374,11 @@ class ext:
                 "dlimg_amd_test_preprocess": ([vp, ci, ci, ci, ci, vp], ci),
                 "dlimg_amd_test_postprocess": ([vp, ci, vp, ci, ci, vp], ci),
                 "dlimg_amd_test_gemm": ([ci, ci, ci, vp, vp, vp, vp, ci, ci, vp, vp], ci),
+                "dlimg_amd_test_gemm_ln": ([ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, cf, ci, vp, vp, vp], ci),
                 "dlimg_amd_test_layernorm": ([vp, vp, vp, cf, ci, ci, ci, vp, vp], ci),
                 "dlimg_amd_test_attention": ([ci, vp, vp, vp, vp, ci, ci, ci, vp], ci),
                 "dlimg_amd_test_resize": ([vp, ci, ci, ci, ci, ci, ci, vp], ci),
-                "dlimg_amd_bench_gemm": ([ci, ci, ci, ci, ci, C.POINTER(C.c_double)], ci),
+                "dlimg_amd_bench_gemm": ([ci, ci, ci, ci, ci, ci, C.POINTER(C.c_double)], ci),
             }
             for name, (args, res) in sig.items():
                 fn = getattr(lib, name)
@@ -390,7 +391,7 @@ class ext:
                "dlimg_amd_encode_and_mask", "dlimg_amd_encode_only", "dlimg_amd_synchronize", "dlimg_amd_lane_count",
                "dlimg_amd_set_profiling",
                "dlimg_amd_take_stage_stats", "dlimg_amd_test_preprocess", "dlimg_amd_test_postprocess",
-               "dlimg_amd_test_gemm", "dlimg_amd_test_layernorm", "dlimg_amd_test_attention", "dlimg_amd_test_resize",
+               "dlimg_amd_test_gemm", "dlimg_amd_test_gemm_ln", "dlimg_amd_test_layernorm", "dlimg_amd_test_attention", "dlimg_amd_test_resize",
                "dlimg_amd_bench_gemm")
 
     @staticmethod
@@ -514,6 +515,30 @@ class ext:
         return (out32, out16) if want_f16 else out32
 
     @classmethod
+    def test_gemm_ln(cls, A1, W1, bias1, resid, W2, gamma, beta, bias2, eps: float, act: int = 0):
+        """x = A1.W1^T + bias1 + resid; y = act(LayerNorm(x; gamma, beta).W2^T + bias2), with the LayerNorm folded into
+        the second GEMM the way SamWeights does it (csrc/sam_model.cpp, Loader::linear_ln_h).  Returns (x, x as f16, y)."""
+        A1 = np.ascontiguousarray(A1, dtype=np.float16)
+        W1 = np.ascontiguousarray(W1, dtype=np.float16)
+        M, K1 = A1.shape
+        D = W1.shape[0]
+        W2 = np.asarray(W2, dtype=np.float32)
+        N = W2.shape[0]
+        wg = np.ascontiguousarray((W2 * np.asarray(gamma, np.float32)[None, :]).astype(np.float16))
+        colsum = np.ascontiguousarray(wg.astype(np.float64).sum(axis=1).astype(np.float32))
+        b2 = np.ascontiguousarray((np.asarray(bias2, np.float64) + W2.astype(np.float64) @ np.asarray(beta, np.float64))
+                                  .astype(np.float32))
+        bias1 = None if bias1 is None else np.ascontiguousarray(bias1, dtype=np.float32)
+        resid = None if resid is None else np.ascontiguousarray(resid, dtype=np.float32)
+        x = np.empty((M, D), dtype=np.float32)
+        xh = np.empty((M, D), dtype=np.float16)
+        y = np.empty((M, N), dtype=np.float32)
+        _check(cls._l().dlimg_amd_test_gemm_ln(M, D, K1, N, A1.ctypes.data, W1.ctypes.data, cls._ptr(bias1),
+                                               cls._ptr(resid), wg.ctypes.data, colsum.ctypes.data, b2.ctypes.data,
+                                               eps, act, x.ctypes.data, xh.ctypes.data, y.ctypes.data))
+        return x, xh, y
+
+    @classmethod
     def test_layernorm(cls, x, w, b, eps: float, act: int = 0):
         x = np.ascontiguousarray(x, dtype=np.float32)
         w = np.ascontiguousarray(w, dtype=np.float32)
@@ -547,7 +572,7 @@ class ext:
         return out
 
     @classmethod
-    def bench_gemm(cls, M: int, N: int, K: int, act: int = 0, iters: int = 20) -> float:
+    def bench_gemm(cls, M: int, N: int, K: int, act: int = 0, iters: int = 20, flavour: int = 0) -> float:
         ms = C.c_double()
-        _check(cls._l().dlimg_amd_bench_gemm(M, N, K, act, iters, C.byref(ms)))
+        _check(cls._l().dlimg_amd_bench_gemm(M, N, K, act, flavour, iters, C.byref(ms)))
         return ms.value

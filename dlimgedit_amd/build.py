@@ -59,7 +59,7 @@ def _flags() -> list:
 
 
 def _deps_mtime() -> float:
-    hdrs = list(CSRC.rglob("*.hpp")) + list((ROOT / "include").rglob("*.h"))
+    hdrs = list(CSRC.rglob("*.hpp")) + list(CSRC.rglob("*.inc")) + list((ROOT / "include").rglob("*.h"))
     return max(p.stat().st_mtime for p in hdrs)
 
 

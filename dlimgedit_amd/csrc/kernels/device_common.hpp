@@ -14,6 +14,7 @@ typedef _Float16 half_t;
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
 typedef float float4_t __attribute__((ext_vector_type(4)));
 typedef float float16_t __attribute__((ext_vector_type(16)));
 
@@ -48,6 +49,19 @@ DLIMG_DEVICE float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071
 
 // value held by the partner lane in the other 32-lane half
 DLIMG_DEVICE float swap_halves(float v) { return __shfl_xor(v, 32, 64); }
+
+// Sum over each aligned group of 8 lanes, result in all 8, on the DPP path (no LDS round trips as with
+// __shfl_xor): quad_perm [1,0,3,2], quad_perm [2,3,0,1], then row_half_mirror (lane i <-> 7-i, the other quad).
+template <int CTRL>
+DLIMG_DEVICE float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+DLIMG_DEVICE float sum_over_8_lanes(float v) {
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    v += dpp_move<0x141>(v);
+    return v;
+}
 
 // butterfly reductions over the 64 lanes of a wave
 DLIMG_DEVICE float wave_sum(float v) {

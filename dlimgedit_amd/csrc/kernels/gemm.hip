@@ -76,13 +76,65 @@ DLIMG_DEVICE float gelu_fast(float x) {
     return 0.5f * x * (1.0f + copysignf(e, x));
 }
 
+// Epilogue flavours: compile-time, so the plain GEMM does not carry the registers of the other
+// (the shared epilogue code is in gemm_epilogue.inc).
+enum { EPI_PLAIN = 0, EPI_NORM = 1 };
+
+// LayerNorm folded into the GEMM (EPI_NORM).  The A operand is the raw residual stream (its f16 copy), W carries
+// the LayerNorm scale.  The row statistics come from the A fragments the wave holds for the MFMAs anyway:
+//   s1 += sum of the 8 values, s2 += sum of their squares      (v_dot2c_f32_f16, fp32 accumulation)
+// The WGN waves that share a row panel split its 32- (16-) row fragments among themselves (fragment i belongs to
+// wave column i % WGN), so the extra VALU work is spread evenly; the owner leaves (mean, rstd) in LDS and the
+// epilogue applies   y = rstd_m * (acc - mean_m * colsum_n) + bias'_n .
+// No statistics travel through HBM and the summation order is fixed, so results do not depend on timing.
+DLIMG_DEVICE void add_row_moments(const half8_t& f, float& s1, float& s2) {
+    const half2_t one = {(half_t)1.f, (half_t)1.f};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const half2_t h = {f[2 * p], f[2 * p + 1]};
+        s1 = __builtin_amdgcn_fdot2(h, one, s1, false);
+        s2 = __builtin_amdgcn_fdot2(h, h, s2, false);
+    }
+}
+
+// (mean, rstd) of a row from its moments
+DLIMG_DEVICE float2_t row_mean_rstd(float s1, float s2, const k::GemmArgs& a) {
+    const float inv_k = 1.0f / (float)a.K;
+    const float mean = s1 * inv_k;
+    const float var = fmaxf(s2 * inv_k - mean * mean, 0.f);
+    return float2_t{mean, rsqrtf(var + a.ln_eps)};
+}
+
+// LDS behind the operand ring: rowstat [BM] x (mean, rstd), then colvec [2][BN] = bias and LayerNorm column sums of
+// the tile's columns (fetched once at kernel start: per-slab global loads would expose their latency every time)
+constexpr int aux_bytes(int bm, int bn) { return bm * 8 + bn * 8; }
+
+template <int BM, int BN, int NTHREADS, int EPI>
+struct ColumnVectors {
+    float4_t b, c;
+    DLIMG_DEVICE void issue(const k::GemmArgs& a, int n0) {
+        b = c = float4_t{0.f, 0.f, 0.f, 0.f};
+        static_assert(BN / 4 <= NTHREADS, "one float4 of the column vectors per thread");
+        if (threadIdx.x < BN / 4) {
+            if (a.bias) b = *reinterpret_cast<const float4_t*>(a.bias + n0 + threadIdx.x * 4);
+            if (EPI == EPI_NORM) c = *reinterpret_cast<const float4_t*>(a.ln_colsum + n0 + threadIdx.x * 4);
+        }
+    }
+    DLIMG_DEVICE void store(float* colvec) {
+        if (threadIdx.x < BN / 4) {
+            *reinterpret_cast<float4_t*>(colvec + threadIdx.x * 4) = b;
+            if (EPI == EPI_NORM) *reinterpret_cast<float4_t*>(colvec + BN + threadIdx.x * 4) = c;
+        }
+    }
+};
+
 // vmcnt(N): wait until at most N of this wave's DMA copies are still in flight
 template <int N> DLIMG_DEVICE void wait_dma() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // ABL (tuning builds only): 0 = real kernel, 1 = no MFMA / fragment reads (operand streaming alone),
 // 2 = no operand streaming after the first tile (MFMA + LDS reads alone).  Outputs are wrong for ABL != 0.
 // MINW = waves per SIMD the register allocation must leave room for (workgroups per CU x waves / 4).
-template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE, int MINW, int ACT, int ABL = 0>
+template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE, int MINW, int ACT, int EPI = EPI_PLAIN, int ABL = 0>
 __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_f16_kernel(k::GemmArgs a) {
     constexpr int NW = WGM * WGN;                   // waves per workgroup (4 or 8)
     static_assert(NW == 4 || NW == 8, "four or eight waves per workgroup");
@@ -117,16 +169,24 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_f16_kernel(k::GemmA
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = zero16();
 
+    float* rowstat = reinterpret_cast<float*>(smem + NSTAGE * STAGE_BYTES);      // auxiliary area behind the ring
+    float* colvec = rowstat + 2 * BM;
+    float rs1[TM], rs2[TM];                      // EPI_NORM: moments of the A row fragments this wave column owns
+#pragma unroll
+    for (int i = 0; i < TM; ++i) rs1[i] = rs2[i] = 0.f;
     const int nk = a.K / BKT;
     auto stage = [&](int kt) {
         char* dst = smem + (kt % NSTAGE) * STAGE_BYTES;
         stage_tile<BM, BKT, NW>(a.A, a.lda, m0, kt * BKT, dst, wave, lane);
         stage_tile<BN, BKT, NW>(a.W, a.ldw, n0, kt * BKT, dst + A_BYTES, wave, lane);
     };
+    ColumnVectors<BM, BN, 64 * NW, EPI> column_vectors;
+    column_vectors.issue(a, n0);                 // ahead of the operand tiles, consumed behind them
     // prologue: NSTAGE-1 tiles in flight
 #pragma unroll
     for (int t = 0; t < NSTAGE - 1; ++t)
         if (t < nk) stage(t);
+    column_vectors.store(colvec);
 
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt has landed once at most `later` newer tiles of this wave are still in flight
@@ -166,18 +226,43 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_f16_kernel(k::GemmA
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(fb[cur][j], fa[cur][i], acc[i][j]);
+            if (EPI == EPI_NORM) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    if (i % WGN == wc) add_row_moments(fa[cur][i], rs1[i], rs2[i]);
+            }
         }
     }
 
+    if (EPI == EPI_NORM) {                       // lanes l and l+32 hold the two k-halves of row l&31
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if (i % WGN != wc) continue;
+            const float s1 = rs1[i] + swap_halves(rs1[i]), s2 = rs2[i] + swap_halves(rs2[i]);
+            if (hi == 0) reinterpret_cast<float2_t*>(rowstat)[wr * WM + i * 32 + l31] = row_mean_rstd(s1, s2, a);
+        }
+    }
     // ---- epilogue: accumulators -> LDS (row-major slab, chunk ^= row&7) -> coalesced rows -----------
-    __syncthreads();                             // operand buffers are dead for every wave
+    __syncthreads();                             // operand buffers are dead for every wave; aux area is complete
     char* slab = smem + wave * OUT_BYTES;
-    constexpr int ITEMS = 32 * CHUNKS;
-    static_assert(ITEMS % 64 == 0, "staged slab must split evenly over 64 lanes");
+    const int resid_row0 = a.resid ? m0 % a.resid_mod : 0;
+    static_assert((32 * CHUNKS) % 64 == 0, "staged slab must split evenly over 64 lanes");
+    constexpr int NIT = 32 * CHUNKS / 64;        // float4 items per lane per slab
+    constexpr int NJ = TN / JG, NSLAB = TM * NJ; // slabs per 32-row band, per wave
+    // the residual of the next slab is requested while the current one is worked on -- unless the register budget
+    // of the tile (MINW waves per SIMD) has no room for a second buffer
+    constexpr int RV_BUFS = (MINW >= 4 && NIT > 4) ? 1 : 2;
+    float4_t rv[RV_BUFS][NIT];
+    if (RV_BUFS == 2) {
+        const int pf_row_base = wr * WM, pf_col_base = wc * WN;
+        float4_t(&pf_dst)[NIT] = rv[0];
+#include "gemm_epilogue_prefetch.inc"
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int jg = 0; jg < TN / JG; ++jg) {
+        for (int jg = 0; jg < NJ; ++jg) {
+            const int sl = i * NJ + jg;
 #pragma unroll
             for (int jj = 0; jj < JG; ++jj)
 #pragma unroll
@@ -187,46 +272,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_f16_kernel(k::GemmA
                     float4_t v = {t[g4 * 4 + 0], t[g4 * 4 + 1], t[g4 * 4 + 2], t[g4 * 4 + 3]};
                     *reinterpret_cast<float4_t*>(slab + (l31 * CHUNKS + (chunk ^ (l31 & 7))) * 16) = v;
                 }
-            // residual / bias of the whole slab are requested up front: one exposed memory latency per slab
-            constexpr int NIT = ITEMS / 64;
-            constexpr bool BIAS_PER_LANE = (64 % CHUNKS == 0);    // then a lane sees the same columns in every iteration
-            constexpr int NB = BIAS_PER_LANE ? 1 : NIT;
-            float4_t rv[NIT], bv[NB];
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int idx = it * 64 + lane;
-                const int row = idx / CHUNKS, chunk = idx % CHUNKS;
-                const int m = m0 + wr * WM + i * 32 + row;
-                const int n = n0 + wc * WN + jg * JG * 32 + chunk * 4;
-                rv[it] = float4_t{0.f, 0.f, 0.f, 0.f};
-                if (a.resid) rv[it] = *reinterpret_cast<const float4_t*>(a.resid + (size_t)(m % a.resid_mod) * a.ldr + n);
-                if (it < NB) {
-                    bv[it] = float4_t{0.f, 0.f, 0.f, 0.f};
-                    if (a.bias) bv[it] = *reinterpret_cast<const float4_t*>(a.bias + n);
-                }
+            if (sl + RV_BUFS - 1 < NSLAB) {
+                constexpr int AHEAD = RV_BUFS - 1;
+                const int pf_row_base = wr * WM + ((sl + AHEAD) / NJ) * 32;
+                const int pf_col_base = wc * WN + ((sl + AHEAD) % NJ) * JG * 32;
+                float4_t(&pf_dst)[NIT] = rv[(sl + AHEAD) % RV_BUFS];
+#include "gemm_epilogue_prefetch.inc"
             }
-            // each wave reads back only what it wrote itself: wave-local ordering is enough
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int idx = it * 64 + lane;
-                const int row = idx / CHUNKS, chunk = idx % CHUNKS;
-                float4_t v = *reinterpret_cast<const float4_t*>(slab + (row * CHUNKS + (chunk ^ (row & 7))) * 16);
-                const int m = m0 + wr * WM + i * 32 + row;
-                const int n = n0 + wc * WN + jg * JG * 32 + chunk * 4;
-                v += bv[BIAS_PER_LANE ? 0 : it];
-                if (ACT == k::ACT_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
-                }
-                v += rv[it];
-                if (a.out_f32) *reinterpret_cast<float4_t*>(a.out_f32 + (size_t)m * a.ldc32 + n) = v;
-                if (a.out_h) {
-                    half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                    *reinterpret_cast<half4_t*>(a.out_h + (size_t)m * a.ldc16 + n) = h;
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // slab reads done before the next band overwrites it
+            const int row_local_base = wr * WM + i * 32, col_local_base = wc * WN + jg * JG * 32;
+            float4_t(&rv_cur)[NIT] = rv[sl % RV_BUFS];
+#include "gemm_epilogue.inc"
         }
     }
 }
@@ -239,7 +294,7 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 //   A operand: lane l holds rows (l & 15), k = 8*(l >> 4) .. +7  -> one 16-byte read of chunk (l >> 4)
 //   C/D      : col = l & 15, row = 4*(l >> 4) + reg              -> with swapped operands a lane owns 4
 //                                                                    consecutive output columns of one row
-template <int BM, int BN, int WGM, int WGN, int NSTAGE, int MINW, int ACT>
+template <int BM, int BN, int WGM, int WGN, int NSTAGE, int MINW, int ACT, int EPI>
 __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm16_f16_kernel(k::GemmArgs a) {
     constexpr int BKT = 32;
     constexpr int NW = WGM * WGN;
@@ -272,6 +327,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm16_f16_kernel(k::Gem
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
 
+    float* rowstat = reinterpret_cast<float*>(smem + NSTAGE * STAGE_BYTES);      // auxiliary area behind the ring
+    float* colvec = rowstat + 2 * BM;
+    // EPI_NORM: moments of the A row fragments this wave column owns -- fragment i of each half belongs to wave
+    // column i % WGN; the owner picks its fragment with uniform selects (no branches inside the MFMA stream)
+    constexpr int OWN = (TM / 2 + WGN - 1) / WGN;  // owned fragments per half
+    float rs1[2][OWN], rs2[2][OWN];
+#pragma unroll
+    for (int i = 0; i < 2 * OWN; ++i) rs1[i / OWN][i % OWN] = rs2[i / OWN][i % OWN] = 0.f;
     const int nk = a.K / BKT;
     auto stage = [&](int kt) {
         char* dst = smem + (kt % NSTAGE) * STAGE_BYTES;
@@ -281,9 +344,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm16_f16_kernel(k::Gem
     auto frag = [&](const char* lds, int row) {
         return *reinterpret_cast<const half8_t*>(lds + row * ROW_BYTES + ((quad ^ swz16(row)) << 4));
     };
+    ColumnVectors<BM, BN, 64 * NW, EPI> column_vectors;
+    column_vectors.issue(a, n0);                 // ahead of the operand tiles, consumed behind them
 #pragma unroll
     for (int t = 0; t < NSTAGE - 1; ++t)
         if (t < nk) stage(t);
+    column_vectors.store(colvec);
 
     for (int kt = 0; kt < nk; ++kt) {
         const int later = min(NSTAGE - 2, nk - 1 - kt);
@@ -309,6 +375,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm16_f16_kernel(k::Gem
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[h * TH + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[h * TH + i][j], 0, 0, 0);
+            if (EPI == EPI_NORM) {
+#pragma unroll
+                for (int o = 0; o < OWN; ++o) {
+                    half8_t own = fa[o * WGN < TH ? o * WGN : 0];
+#pragma unroll
+                    for (int w = 1; w < WGN; ++w)
+                        if (o * WGN + w < TH) own = (wc == w) ? fa[o * WGN + w] : own;
+                    add_row_moments(own, rs1[h][o], rs2[h][o]);
+                }
+            }
             if (h == 0) {
 #pragma unroll
                 for (int i = 0; i < TH; ++i) fa[i] = frag(la, wr * WM + (TH + i) * 16 + l15);
@@ -316,17 +392,42 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm16_f16_kernel(k::Gem
         }
     }
 
+    if (EPI == EPI_NORM) {                       // lanes l, l+16, l+32, l+48 hold the four k-chunks of row l&15
+        constexpr int TH = TM / 2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int o = 0; o < OWN; ++o) {
+                const int frag = h * TH + o * WGN + wc;      // the fragment these moments belong to
+                float s1 = rs1[h][o], s2 = rs2[h][o];
+                s1 += __shfl_xor(s1, 16, 64);
+                s2 += __shfl_xor(s2, 16, 64);
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (quad == 0 && o * WGN + wc < TH)
+                    reinterpret_cast<float2_t*>(rowstat)[wr * WM + frag * 16 + l15] = row_mean_rstd(s1, s2, a);
+            }
+    }
     // ---- epilogue: 32-row bands through an LDS slab, as in the 32x32 kernel --------------------------
     __syncthreads();
     char* slab = smem + wave * OUT_BYTES;
-    constexpr int ITEMS = 32 * CHUNKS;
-    constexpr int NIT = ITEMS / 64;
-    constexpr bool BIAS_PER_LANE = (64 % CHUNKS == 0);
-    constexpr int NB = BIAS_PER_LANE ? 1 : NIT;
+    const int resid_row0 = a.resid ? m0 % a.resid_mod : 0;
+    constexpr int NIT = 32 * CHUNKS / 64;
+    constexpr int NJ = (WN / 32) / JG, NSLAB = (TM / 2) * NJ;
+    // the residual of the next slab is requested while the current one is worked on -- unless the register budget
+    // of the tile (MINW waves per SIMD) has no room for a second buffer
+    constexpr int RV_BUFS = (MINW >= 4 && NIT > 4) ? 1 : 2;
+    float4_t rv[RV_BUFS][NIT];
+    if (RV_BUFS == 2) {
+        const int pf_row_base = wr * WM, pf_col_base = wc * WN;
+        float4_t(&pf_dst)[NIT] = rv[0];
+#include "gemm_epilogue_prefetch.inc"
+    }
 #pragma unroll
     for (int band = 0; band < TM / 2; ++band) {
 #pragma unroll
-        for (int jg = 0; jg < (WN / 32) / JG; ++jg) {
+        for (int jg = 0; jg < NJ; ++jg) {
+            const int sl = band * NJ + jg;
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii) {
                 const int row = ii * 16 + l15;
@@ -337,85 +438,62 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm16_f16_kernel(k::Gem
                         acc[band * 2 + ii][jg * JG * 2 + jj];
                 }
             }
-            float4_t rv[NIT], bv[NB];
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int idx = it * 64 + lane;
-                const int row = idx / CHUNKS, chunk = idx % CHUNKS;
-                const int m = m0 + wr * WM + band * 32 + row;
-                const int n = n0 + wc * WN + jg * JG * 32 + chunk * 4;
-                rv[it] = float4_t{0.f, 0.f, 0.f, 0.f};
-                if (a.resid) rv[it] = *reinterpret_cast<const float4_t*>(a.resid + (size_t)(m % a.resid_mod) * a.ldr + n);
-                if (it < NB) {
-                    bv[it] = float4_t{0.f, 0.f, 0.f, 0.f};
-                    if (a.bias) bv[it] = *reinterpret_cast<const float4_t*>(a.bias + n);
-                }
+            if (sl + RV_BUFS - 1 < NSLAB) {
+                constexpr int AHEAD = RV_BUFS - 1;
+                const int pf_row_base = wr * WM + ((sl + AHEAD) / NJ) * 32;
+                const int pf_col_base = wc * WN + ((sl + AHEAD) % NJ) * JG * 32;
+                float4_t(&pf_dst)[NIT] = rv[(sl + AHEAD) % RV_BUFS];
+#include "gemm_epilogue_prefetch.inc"
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int idx = it * 64 + lane;
-                const int row = idx / CHUNKS, chunk = idx % CHUNKS;
-                float4_t v = *reinterpret_cast<const float4_t*>(slab + (row * CHUNKS + (chunk ^ (row & 7))) * 16);
-                const int m = m0 + wr * WM + band * 32 + row;
-                const int n = n0 + wc * WN + jg * JG * 32 + chunk * 4;
-                v += bv[BIAS_PER_LANE ? 0 : it];
-                if (ACT == k::ACT_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
-                }
-                v += rv[it];
-                if (a.out_f32) *reinterpret_cast<float4_t*>(a.out_f32 + (size_t)m * a.ldc32 + n) = v;
-                if (a.out_h) {
-                    half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                    *reinterpret_cast<half4_t*>(a.out_h + (size_t)m * a.ldc16 + n) = h;
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int row_local_base = wr * WM + band * 32, col_local_base = wc * WN + jg * JG * 32;
+            float4_t(&rv_cur)[NIT] = rv[sl % RV_BUFS];
+#include "gemm_epilogue.inc"
         }
     }
+}
+
+typedef void (*GemmKernel)(k::GemmArgs);
+
+// Picks the epilogue flavour the arguments ask for and launches; LDS above the default limit is opted into once.
+void launch_flavour(GemmKernel const (&kernels)[4], bool (&attr_set)[4], const k::GemmArgs& a, int grid, int threads,
+                    size_t lds, hipStream_t s) {
+    const int index = (a.ln_colsum ? 2 : 0) + (a.act == k::ACT_GELU ? 1 : 0);
+    if (lds > 48 * 1024 && !attr_set[index]) {
+        if (hipFuncSetAttribute((const void*)kernels[index], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+            throw_error("gemm: the device refuses the LDS size of this tile configuration");
+        attr_set[index] = true;
+    }
+    hipLaunchKernelGGL(kernels[index], dim3(grid), dim3(threads), lds, s, a);
 }
 
 template <int BM, int BN, int WGM, int WGN, int NSTAGE, int MINW>
 void launch16(const k::GemmArgs& a, hipStream_t s) {
-    const int grid = (a.M / BM) * (a.N / BN);
-    const size_t lds = (size_t)NSTAGE * (BM + BN) * 64;
-    auto k0 = gemm16_f16_kernel<BM, BN, WGM, WGN, NSTAGE, MINW, k::ACT_NONE>;
-    auto k1 = gemm16_f16_kernel<BM, BN, WGM, WGN, NSTAGE, MINW, k::ACT_GELU>;
-    if (lds > 64 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
-        }
-    }
-    const dim3 block(64 * WGM * WGN);
-    hipLaunchKernelGGL(a.act == k::ACT_GELU ? k1 : k0, dim3(grid), block, lds, s, a);
+    const size_t lds = (size_t)NSTAGE * (BM + BN) * 64 + aux_bytes(BM, BN);
+    static const GemmKernel kernels[4] = {
+        gemm16_f16_kernel<BM, BN, WGM, WGN, NSTAGE, MINW, k::ACT_NONE, EPI_PLAIN>,
+        gemm16_f16_kernel<BM, BN, WGM, WGN, NSTAGE, MINW, k::ACT_GELU, EPI_PLAIN>,
+        gemm16_f16_kernel<BM, BN, WGM, WGN, NSTAGE, MINW, k::ACT_NONE, EPI_NORM>,
+        gemm16_f16_kernel<BM, BN, WGM, WGN, NSTAGE, MINW, k::ACT_GELU, EPI_NORM>,
+    };
+    static bool attr_set[4] = {};
+    launch_flavour(kernels, attr_set, a, (a.M / BM) * (a.N / BN), 64 * WGM * WGN, lds, s);
 }
 
 template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE, int MINW>
 void launch(const k::GemmArgs& a, hipStream_t s) {
-    const int grid = (a.M / BM) * (a.N / BN);
-    const size_t lds = (size_t)NSTAGE * (BM + BN) * BKT * 2;
-    auto k0 = gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_NONE>;
-    auto k1 = gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_GELU>;
+    const size_t lds = (size_t)NSTAGE * (BM + BN) * BKT * 2 + aux_bytes(BM, BN);
     static const int ablate = [] { const char* e = std::getenv("DLIMGEDIT_GEMM_ABLATE"); return e ? std::atoi(e) : 0; }();
-    if (ablate == 1) k0 = gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_NONE, 1>;
-    if (ablate == 2) k0 = gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_NONE, 2>;
-    if (lds > 64 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
-        }
-    }
-    const dim3 block(64 * WGM * WGN);
-    if (a.act == k::ACT_GELU)
-        hipLaunchKernelGGL(k1, dim3(grid), block, lds, s, a);
-    else
-        hipLaunchKernelGGL(k0, dim3(grid), block, lds, s, a);
+    static const GemmKernel kernels[4] = {
+        ablate == 1   ? gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_NONE, EPI_PLAIN, 1>
+        : ablate == 2 ? gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_NONE, EPI_PLAIN, 2>
+                      : gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_NONE, EPI_PLAIN>,
+        gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_GELU, EPI_PLAIN>,
+        gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_NONE, EPI_NORM>,
+        gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_GELU, EPI_NORM>,
+    };
+    static bool attr_set[4] = {};
+    launch_flavour(kernels, attr_set, a, (a.M / BM) * (a.N / BN), 64 * WGM * WGN, lds, s);
 }
 
 }  // namespace
@@ -428,12 +506,13 @@ const char* gemm_check(const GemmArgs& a) {
     if (a.lda % 8 || a.ldw % 8) return "gemm: operand leading dimensions must be multiples of 8 (16-byte rows)";
     if (a.lda < a.K || a.ldw < a.K) return "gemm: leading dimension smaller than K";
     if (((uintptr_t)a.A | (uintptr_t)a.W) & 15) return "gemm: operands must be 16-byte aligned";
-    if (a.resid && a.resid_mod <= 0) return "gemm: resid_mod must be positive";
+    if (a.resid && (a.resid_mod <= 0 || a.resid_mod % 64)) return "gemm: resid_mod must be a positive multiple of 64";
     if (!a.out_f32 && !a.out_h) return "gemm: no output";
     if ((a.bias && ((uintptr_t)a.bias & 15)) || (a.resid && (((uintptr_t)a.resid & 15) || a.ldr % 4)) ||
         (a.out_f32 && (((uintptr_t)a.out_f32 & 15) || a.ldc32 % 4)) ||
         (a.out_h && (((uintptr_t)a.out_h & 7) || a.ldc16 % 4)))
         return "gemm: bias/residual/output rows must be 16-byte (f16 output: 8-byte) aligned";
+    if (a.ln_colsum && ((uintptr_t)a.ln_colsum & 15)) return "gemm: LayerNorm column sums must be 16-byte aligned";
     return nullptr;
 }
 
@@ -465,12 +544,15 @@ int gemm_pick_tile(const GemmArgs& a) {
     const int forced = forced_env ? std::atoi(forced_env) : -1;
     int best = -1;
     float best_score = -1.f;
+    // a residual that wraps (row m % resid_mod) must wrap on tile boundaries: the epilogue adds row offsets to the
+    // tile's first residual row without a modulo per element
+    auto wraps_inside = [&](int bm) { return a.resid && a.resid_mod % bm != 0; };
     if (g_shared_gpu.load(std::memory_order_relaxed) && forced < 0 && a.M % 256 == 0 && a.N % 256 == 0 &&
-        (a.M / 256) * (a.N / 256) >= 128)
+        (a.M / 256) * (a.N / 256) >= 128 && !wraps_inside(256))
         return 7;
     for (int i = 0; i < kNumTiles; ++i) {
         const TileCfg& t = kTiles[i];
-        if (a.M % t.bm || a.N % t.bn) continue;
+        if (a.M % t.bm || a.N % t.bn || wraps_inside(t.bm)) continue;
         if (i == forced) return i;
         if (g_shared_gpu.load(std::memory_order_relaxed) && forced < 0) {
             // shared GPU: other lanes fill the CUs this launch leaves free, so the only question is operand

@@ -26,6 +26,11 @@ struct GemmArgs {
     half_t* out_h = nullptr;    int ldc16 = 0;
     int M = 0, N = 0, K = 0;
     int act = ACT_NONE;
+    // LayerNorm folded into the GEMM (ln_colsum != nullptr): A is the raw, un-normalised input, W carries the
+    // LayerNorm scale (W * diag(gamma)), bias carries b + W.beta; the kernel takes mean / variance of each A row
+    // from the operand fragments it streams anyway and applies  rstd_m * (acc - mean_m * ln_colsum[n]) + bias[n].
+    const float* ln_colsum = nullptr;            // [N] sum over k of the (f16-rounded) scaled weight
+    float ln_eps = 0.f;
 };
 const char* gemm_check(const GemmArgs&);
 void gemm(const GemmArgs&, hipStream_t);

@@ -1,6 +1,7 @@
 #include "sam_model.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace dlimg {
@@ -37,6 +38,33 @@ struct Loader {
         l.in = in;
         l.has_bias = bias;
         if (bias) f32(prefix + ".b", {out}, l.b);
+    }
+    // Linear layer behind a LayerNorm, with the norm folded in: y = W (g*(x-mu)*rstd + beta) + b
+    //   = rstd * ((W g) x - mu * rowsum(W g)) + (b + W beta).  The GEMM multiplies the raw x by W g and applies
+    // the rest per output element; rowsum is taken over the f16 values the GEMM really multiplies with.
+    void linear_ln_h(std::string const& prefix, std::string const& norm, int out, int in, LinearH& l) {
+        HostTensor const& w = file.get(prefix + ".w", {out, in});
+        HostTensor const& b = file.get(prefix + ".b", {out});
+        HostTensor const& gamma = file.get(norm + ".w", {in});
+        HostTensor const& beta = file.get(norm + ".b", {in});
+        std::vector<float> wg((size_t)out * in), colsum(out), bias(out);
+        for (int n = 0; n < out; ++n) {
+            double sum = 0, shift = 0;
+            for (int i = 0; i < in; ++i) {
+                const float v = w.data[(size_t)n * in + i] * gamma.data[i];
+                wg[(size_t)n * in + i] = v;
+                sum += (double)(float)(half_t)v;
+                shift += (double)w.data[(size_t)n * in + i] * beta.data[i];
+            }
+            colsum[n] = (float)sum;
+            bias[n] = (float)(b.data[n] + shift);
+        }
+        f16_host(wg.data(), wg.size(), l.w);
+        f32_host(bias, l.b);
+        f32_host(colsum, l.colsum);
+        l.out = out;
+        l.in = in;
+        l.has_bias = true;
     }
     void linear_f(std::string const& prefix, int out, int in, LinearF& l) {
         f32(prefix + ".w", {out, in}, l.w);
@@ -99,6 +127,9 @@ SamWeights::SamWeights(std::string const& weight_path, int device_index) : devic
     if (D % 64 || geom_.mlp_dim % 64) throw Exception("SAM encoder width must be a multiple of 64");
     if (D != hd * geom_.num_heads || (hd != 64 && hd != 80))
         throw Exception("SAM encoder head dimension must be 64 or 80");
+    // The encoder's LayerNorms run inside the GEMMs around them (see encode()); DLIMGEDIT_FUSED_LN=0 keeps
+    // them as separate kernels for A/B measurements.
+    if (const char* e = std::getenv("DLIMGEDIT_FUSED_LN")) fused_ln_ = std::atoi(e) != 0;
 
     HIP_CHECK(hipSetDevice(device));
     hipStream_t stream_ = nullptr;
@@ -113,13 +144,19 @@ SamWeights::SamWeights(std::string const& weight_path, int device_index) : devic
         const std::string p = "enc.L" + std::to_string(i);
         L.global = geom_.is_global(i);
         const int span = L.global ? 64 : 14;
-        ld.norm(p + ".ln1", D, L.ln1);
-        ld.linear_h(p + ".qkv", 3 * D, D, true, L.qkv);
+        ld.f32(p + ".qkv.b", {3 * D}, L.qkv_pad);
+        if (fused_ln_) {
+            ld.linear_ln_h(p + ".qkv", p + ".ln1", 3 * D, D, L.qkv);
+            ld.linear_ln_h(p + ".fc1", p + ".ln2", geom_.mlp_dim, D, L.fc1);
+        } else {
+            ld.norm(p + ".ln1", D, L.ln1);
+            ld.norm(p + ".ln2", D, L.ln2);
+            ld.linear_h(p + ".qkv", 3 * D, D, true, L.qkv);
+            ld.linear_h(p + ".fc1", geom_.mlp_dim, D, true, L.fc1);
+        }
         ld.f32(p + ".rel_h", {2 * span - 1, hd}, L.rel_h);
         ld.f32(p + ".rel_w", {2 * span - 1, hd}, L.rel_w);
         ld.linear_h(p + ".proj", D, D, true, L.proj);
-        ld.norm(p + ".ln2", D, L.ln2);
-        ld.linear_h(p + ".fc1", geom_.mlp_dim, D, true, L.fc1);
         ld.linear_h(p + ".fc2", D, geom_.mlp_dim, true, L.fc2);
     }
     ld.linear_h("enc.neck.conv1", kEmbedDim, D, false, neck1_);
@@ -391,20 +428,37 @@ void SamModel::encode(int batch) {
     const int D = W.geom_.embed_dim, H = W.geom_.num_heads, hd = W.geom_.head_dim(), mlp = W.geom_.mlp_dim;
     const int M = batch * kTokens;
 
+    // Block structure: x += proj(attn(qkv(LN1(x)))); x += fc2(gelu(fc1(LN2(x)))).  With folded LayerNorms every
+    // GEMM that writes the residual stream x (fp32) also leaves its f16 copy; the next GEMM multiplies that copy
+    // by the gamma-scaled weight, takes the row moments from the operand fragments it streams and normalises in
+    // its epilogue: the stream is read once (as f16) per consumer instead of LN read + LN write + GEMM read.
+    const bool fused = W.fused_ln_;
+    auto writes_stream = [&](k::GemmArgs& a) {
+        a.resid_mod = a.resid == x_.get() ? M : a.resid_mod;
+        a.out_f32 = x_.get(); a.ldc32 = D; a.M = M; a.N = D;
+        if (fused) { a.out_h = xn_.get(); a.ldc16 = D; }
+    };
+    auto reads_stream = [&](k::GemmArgs& a, LinearH const& lin, NormW const& norm) {
+        if (fused) {
+            a.ln_colsum = lin.colsum.get(); a.ln_eps = kLnEps;
+        } else {
+            timed(ST_LAYERNORM, (double)M * D * 6, [&] {
+                k::layernorm(x_.get(), norm.w.get(), norm.b.get(), kLnEps, M, D, k::ACT_NONE, nullptr, xn_.get(), stream_);
+            });
+        }
+        a.A = xn_.get(); a.lda = D; a.W = lin.w.get(); a.ldw = D; a.bias = lin.b.get(); a.M = M; a.N = lin.out; a.K = D;
+    };
+
     k::GemmArgs g;
     g.A = patches_.get(); g.lda = kPatchK; g.W = W.patch_.w.get(); g.ldw = kPatchK; g.bias = W.patch_.b.get();
-    g.resid = W.pos_embed_.get(); g.ldr = D; g.resid_mod = kTokens;
-    g.out_f32 = x_.get(); g.ldc32 = D; g.M = M; g.N = D; g.K = kPatchK;
+    g.resid = W.pos_embed_.get(); g.ldr = D; g.resid_mod = kTokens; g.K = kPatchK;
+    writes_stream(g);
     gemm(g);
 
-    const double ln_bytes = (double)M * D * 6;
     for (EncoderLayer const& L : W.layers_) {
-        timed(ST_LAYERNORM, ln_bytes, [&] {
-            k::layernorm(x_.get(), L.ln1.w.get(), L.ln1.b.get(), kLnEps, M, D, k::ACT_NONE, nullptr, xn_.get(), stream_);
-        });
         g = k::GemmArgs{};
-        g.A = xn_.get(); g.lda = D; g.W = L.qkv.w.get(); g.ldw = D; g.bias = L.qkv.b.get();
-        g.out_h = qkv_.get(); g.ldc16 = 3 * D; g.M = M; g.N = 3 * D; g.K = D;
+        reads_stream(g, L.qkv, L.ln1);
+        g.out_h = qkv_.get(); g.ldc16 = 3 * D;
         gemm(g);
         if (L.global) {
             const double fl = (double)batch * (4.0 * kTokens * (double)kTokens * D + 4.0 * kTokens * 64.0 * hd * H);
@@ -414,31 +468,32 @@ void SamModel::encode(int batch) {
         } else {
             const double fl = (double)batch * 25.0 * (4.0 * 196.0 * 196.0 * D + 4.0 * 196.0 * 14.0 * hd * H);
             timed(ST_ATTN_WINDOW, fl, [&] {
-                k::attention_window(qkv_.get(), L.qkv.b.get(), L.rel_h.get(), L.rel_w.get(), att_.get(), batch, H, hd,
+                k::attention_window(qkv_.get(), L.qkv_pad.get(), L.rel_h.get(), L.rel_w.get(), att_.get(), batch, H, hd,
                                     stream_);
             });
         }
         g = k::GemmArgs{};
-        g.A = att_.get(); g.lda = D; g.W = L.proj.w.get(); g.ldw = D; g.bias = L.proj.b.get();
-        g.resid = x_.get(); g.ldr = D; g.resid_mod = M; g.out_f32 = x_.get(); g.ldc32 = D; g.M = M; g.N = D; g.K = D;
-        gemm(g);
-        timed(ST_LAYERNORM, ln_bytes, [&] {
-            k::layernorm(x_.get(), L.ln2.w.get(), L.ln2.b.get(), kLnEps, M, D, k::ACT_NONE, nullptr, xn_.get(), stream_);
-        });
-        g = k::GemmArgs{};
-        g.A = xn_.get(); g.lda = D; g.W = L.fc1.w.get(); g.ldw = D; g.bias = L.fc1.b.get(); g.act = k::ACT_GELU;
-        g.out_h = hid_.get(); g.ldc16 = mlp; g.M = M; g.N = mlp; g.K = D;
+        g.A = att_.get(); g.lda = D; g.W = L.proj.w.get(); g.ldw = D; g.bias = L.proj.b.get(); g.K = D;
+        g.resid = x_.get(); g.ldr = D;
+        writes_stream(g);
         gemm(g);
         g = k::GemmArgs{};
-        g.A = hid_.get(); g.lda = mlp; g.W = L.fc2.w.get(); g.ldw = mlp; g.bias = L.fc2.b.get();
-        g.resid = x_.get(); g.ldr = D; g.resid_mod = M; g.out_f32 = x_.get(); g.ldc32 = D; g.M = M; g.N = D; g.K = mlp;
+        reads_stream(g, L.fc1, L.ln2);
+        g.act = k::ACT_GELU; g.out_h = hid_.get(); g.ldc16 = mlp;
+        gemm(g);
+        g = k::GemmArgs{};
+        g.A = hid_.get(); g.lda = mlp; g.W = L.fc2.w.get(); g.ldw = mlp; g.bias = L.fc2.b.get(); g.K = mlp;
+        g.resid = x_.get(); g.ldr = D;
+        writes_stream(g);
         gemm(g);
     }
 
     // neck: 1x1 conv -> LayerNorm2d -> 3x3 conv (pad 1) -> LayerNorm2d, all channel-last
-    timed(ST_ENC_OTHER, (double)M * D * 6, [&] {
-        k::add_cast(x_.get(), nullptr, 0, (size_t)M * D, nullptr, xn_.get(), stream_);
-    });
+    if (!fused) {
+        timed(ST_ENC_OTHER, (double)M * D * 6, [&] {
+            k::add_cast(x_.get(), nullptr, 0, (size_t)M * D, nullptr, xn_.get(), stream_);
+        });
+    }
     g = k::GemmArgs{};
     g.A = xn_.get(); g.lda = D; g.W = W.neck1_.w.get(); g.ldw = D;
     g.out_f32 = neck_f32_.get(); g.ldc32 = kEmbedDim; g.M = M; g.N = kEmbedDim; g.K = D;

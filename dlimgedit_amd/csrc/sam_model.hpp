@@ -32,6 +32,9 @@ struct LinearH {                    // f16 weight for MFMA GEMMs, fp32 bias
     DeviceBuffer<float> b;
     int out = 0, in = 0;
     bool has_bias = false;
+    // set when a preceding LayerNorm is folded in: w = W * diag(gamma), b = b + W.beta and
+    // colsum[n] = sum_k w[n][k] (of the f16-rounded values) for the mean correction in the GEMM epilogue
+    DeviceBuffer<float> colsum;
 };
 struct LinearF {                    // fp32 weight for the token-side kernels
     DeviceBuffer<float> w, b;
@@ -43,6 +46,7 @@ struct EncoderLayer {
     bool global = false;
     NormW ln1, ln2;
     LinearH qkv, proj, fc1, fc2;
+    DeviceBuffer<float> qkv_pad;     // q|k|v of a window's zero-padding token = the plain qkv bias
     DeviceBuffer<float> rel_h, rel_w;
 };
 
@@ -67,6 +71,7 @@ struct SamWeights {
 
     int device = 0;
     SamGeometry geom_;
+    bool fused_ln_ = true;            // encoder LayerNorms folded into the qkv / fc1 GEMMs
     LinearH patch_;                       // [D, 768] + bias
     DeviceBuffer<float> pos_embed_;       // [4096, D]
     std::vector<EncoderLayer> layers_;

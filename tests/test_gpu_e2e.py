@@ -148,6 +148,22 @@ def test_head_dim_80_variant(api, model_dirs):
     assert iou(seg.compute_mask(api.Point(512, 512)), ora.compute_mask(point=(512, 512))) >= IOU_BAR
 
 
+def test_folded_and_separate_layernorm_agree(api, session, model_dirs, monkeypatch):
+    """The encoder's LayerNorms run inside the GEMMs by default; DLIMGEDIT_FUSED_LN=0 keeps them as separate kernels.
+    Both must sit within the embedding tolerance of the oracle and close to each other."""
+    env, params, cfg, img, seg, ora = session
+    monkeypatch.setenv("DLIMGEDIT_FUSED_LN", "0")
+    mdir, _, _ = model_dirs("vit_test")
+    env_split = api.Environment(api.Options(api.Backend.gpu, mdir))
+    seg_split = api.Segmentation.process(api.ImageView(img, api.Channels.rgba), env_split)
+    folded, split = api.ext.get_embedding(seg), api.ext.get_embedding(seg_split)
+    assert not np.array_equal(folded, split)                 # really two code paths
+    assert np.abs(split - ora.embedding).max() < EMB_TOL
+    assert np.abs(folded - ora.embedding).max() < EMB_TOL
+    assert np.abs(folded - split).max() < EMB_TOL
+    assert iou(seg_split.compute_mask(api.Point(512, 512)), ora.compute_mask(point=(512, 512))) >= IOU_BAR
+
+
 def test_error_paths(api, session, tmp_path):
     env, *_ = session
     with pytest.raises(api.Error, match="does not exist"):

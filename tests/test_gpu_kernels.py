@@ -180,6 +180,74 @@ def test_gemm_identity_layout(ext):
     assert np.array_equal(out, W.astype(np.float32).T[:128])
 
 
+@pytest.mark.parametrize("M,D,K1,N,act,tile", [
+    (4096, 768, 768, 2304, 0, None),       # ViT-B proj -> LN1 -> qkv
+    (4096, 768, 3072, 3072, 1, None),      # ViT-B fc2 -> LN2 -> fc1 + GELU
+    (4096, 1280, 1280, 3840, 0, None),     # ViT-H width (40 statistic groups per row)
+    (4096, 128, 768, 384, 0, None),        # test width, patch embedding as producer
+    (4096, 320, 320, 1280, 1, None),       # head_dim-80 test width
+    (512, 1024, 256, 512, 0, 6),           # 32x32x16 256x256 tile on both sides
+    (512, 1024, 256, 512, 1, 7),           # 16x16x32 256x256 tile on both sides
+    (256, 256, 128, 256, 0, 2),
+    (256, 256, 128, 384, 0, 8),
+])
+def test_gemm_folded_layernorm(ext, monkeypatch, M, D, K1, N, act, tile):
+    """LayerNorm folded into the GEMMs around it: the producer leaves the f16 copy of the stream, the consumer
+    multiplies it by W*gamma, takes the row moments from its own operand fragments and normalises in its epilogue.
+    Checked against the oracle's LayerNorm + fp64 product and against the un-fused kernels' own error."""
+    if tile is not None:
+        monkeypatch.setenv("DLIMGEDIT_GEMM_TILE", str(tile))
+    O = _oracle()
+    rng = np.random.default_rng(M + D + N)
+    A1 = rng.standard_normal((M, K1)).astype(np.float16)
+    W1 = (rng.standard_normal((D, K1)) / np.sqrt(K1)).astype(np.float16)
+    b1 = rng.standard_normal(D).astype(np.float32)
+    resid = (rng.standard_normal((M, D)) * 3 + 1).astype(np.float32)
+    resid[:, 5] += 60.0                      # one massive-activation channel, as trained ViTs have them
+    gamma = (1 + 0.2 * rng.standard_normal(D)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(D)).astype(np.float32)
+    W2 = (rng.standard_normal((N, D)) / np.sqrt(D)).astype(np.float32)
+    b2 = rng.standard_normal(N).astype(np.float32)
+
+    x, xh, y = ext.test_gemm_ln(A1, W1, b1, resid, W2, gamma, beta, b2, 1e-6, act)
+    x_ref = _gemm_ref(A1, W1, b1, resid, 0)
+    assert np.abs(x - x_ref).max() <= 2e-3 * max(1.0, np.abs(x_ref).max())
+    assert np.array_equal(xh, x.astype(np.float16))
+
+    xn = O.layer_norm(x.astype(np.float64), gamma.astype(np.float64), beta.astype(np.float64), 1e-6)
+    ref = xn @ W2.astype(np.float64).T + b2
+    if act:
+        ref = O.gelu(ref)
+    err = y - ref
+    # the same two steps as separate kernels (LayerNorm -> f16, GEMM with f16 W) bound what f16 operands cost
+    _, xn16 = ext.test_layernorm(x, gamma, beta, 1e-6)
+    err_split = ext.test_gemm(xn16, W2.astype(np.float16), b2, None, act) - ref
+    rms, rms_split = np.sqrt((err ** 2).mean()), np.sqrt((err_split ** 2).mean())
+    assert rms <= 2.0 * rms_split + 1e-4, (rms, rms_split)
+    assert np.abs(err).max() <= 2e-2, np.abs(err).max()
+
+    _, _, y2 = ext.test_gemm_ln(A1, W1, b1, resid, W2, gamma, beta, b2, 1e-6, act)
+    assert np.array_equal(y, y2)             # fixed summation order, no atomics
+
+
+def test_gemm_folded_layernorm_offset_rows(ext):
+    """Rows whose mean is large against their spread (|mean| = 30 sigma): the raw-moment variance still holds."""
+    O = _oracle()
+    rng = np.random.default_rng(5)
+    M, D, N = 256, 768, 256
+    x0 = (rng.standard_normal((M, D)) + 30.0).astype(np.float32)
+    eye = np.eye(D, dtype=np.float16)
+    gamma, beta = np.ones(D, np.float32), np.zeros(D, np.float32)
+    W2 = (rng.standard_normal((N, D)) / np.sqrt(D)).astype(np.float32)
+    x, xh, y = ext.test_gemm_ln(np.zeros((M, D), np.float16), eye, None, x0, W2, gamma, beta, np.zeros(N, np.float32),
+                                1e-6, 0)
+    assert np.array_equal(x, x0)
+    # the consumer normalises the f16 stream it multiplies with: that is the reference
+    ref = O.layer_norm(xh.astype(np.float64), gamma.astype(np.float64), beta.astype(np.float64), 1e-6) \
+        @ W2.astype(np.float16).astype(np.float64).T
+    assert np.abs(y - ref).max() <= 5e-3, np.abs(y - ref).max()
+
+
 def test_gemm_rejects_bad_shapes(ext):
     from dlimgedit_amd import api
     A = np.zeros((100, 64), np.float16)

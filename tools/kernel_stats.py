@@ -1,0 +1,22 @@
+"""Per-kernel launch count / average / total from a rocprofv3 rocpd database (rocprofv3 --kernel-trace -d DIR -o NAME).
+usage: python tools/kernel_stats.py gpurun_out/prof/NAME_results.db [top]"""
+import sqlite3
+import sys
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1])
+    top = int(sys.argv[2]) if len(sys.argv) > 2 else 25
+    tabs = [r[0] for r in db.execute("select name from sqlite_master where type in ('table','view')")]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    sym = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    q = (f"select s.kernel_name, count(*), avg(d.end-d.start)/1000.0, sum(d.end-d.start)/1e6 from {kd} d "
+         f"join {sym} s on d.kernel_id=s.id group by s.kernel_name order by 4 desc")
+    print(f"{'calls':>7} {'avg_us':>9} {'total_ms':>9}  kernel")
+    for name, n, avg, tot in db.execute(q).fetchall()[:top]:
+        name = name.replace("_ZN5dlimg12_GLOBAL__N_1", "").replace("EEEvNS_1k8GemmArgsE.kd", "")
+        print(f"{n:7d} {avg:9.1f} {tot:9.2f}  {name[:100]}")
+
+
+if __name__ == "__main__":
+    main()
