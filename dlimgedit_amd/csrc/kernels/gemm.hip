@@ -25,6 +25,7 @@
 
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 
 namespace dlimg {
 namespace {
@@ -330,8 +331,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm16_f16_kernel(k::Gem
     float* rowstat = reinterpret_cast<float*>(smem + NSTAGE * STAGE_BYTES);      // auxiliary area behind the ring
     float* colvec = rowstat + 2 * BM;
     // EPI_NORM: moments of the A row fragments this wave column owns -- fragment i of each half belongs to wave
-    // column i % WGN; the owner picks its fragment with uniform selects (no branches inside the MFMA stream)
+    // column i % WGN.  The owner reads its fragments a second time from LDS (two extra ds_reads per step): picking
+    // them out of the MFMA operands needs a branch or 24 selects per step inside the MFMA stream, which costs more.
     constexpr int OWN = (TM / 2 + WGN - 1) / WGN;  // owned fragments per half
+    static_assert(EPI != EPI_NORM || (TM / 2) % WGN == 0, "every wave column owns the same number of row fragments");
     float rs1[2][OWN], rs2[2][OWN];
 #pragma unroll
     for (int i = 0; i < 2 * OWN; ++i) rs1[i / OWN][i % OWN] = rs2[i / OWN][i % OWN] = 0.f;
@@ -351,45 +354,96 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm16_f16_kernel(k::Gem
         if (t < nk) stage(t);
     column_vectors.store(colvec);
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int later = min(NSTAGE - 2, nk - 1 - kt);
-        if (later >= 3) wait_dma<3 * LOADS>();
-        else if (later == 2) wait_dma<2 * LOADS>();
-        else if (later == 1) wait_dma<LOADS>();
+    // Fragments travel one K tile ahead of the MFMAs that use them: while the matrix pipe works on tile kt (all of
+    // its operands already in registers), the wave passes the barrier for tile kt+1 and requests that tile's B
+    // fragments and the first half of its A fragments; the second half of the current A fragments is requested at
+    // the top of the step and is needed half a step later.  Neither the barrier nor the LDS latency is exposed.
+    static_assert(NSTAGE >= 3, "a tile is read one step before it is multiplied");
+    constexpr int TH = TM / 2;
+    half8_t fb[2][TN], fal[2][TH], fah[TH];
+    auto wait_tile = [&](int newer) {            // wave's copies of a tile have landed; `newer` tiles may be in flight
+        if (newer >= 2) wait_dma<2 * LOADS>();
+        else if (newer == 1) wait_dma<LOADS>();
         else wait_dma<0>();
-        __builtin_amdgcn_s_barrier();
+    };
+    auto read_next = [&](int buf, int kt) {
         const char* la = smem + (kt % NSTAGE) * STAGE_BYTES;
         const char* lb = la + A_BYTES;
-        // the B fragments stay live for the whole tile, the A fragments are fetched in two halves
-        constexpr int TH = TM / 2;
-        half8_t fb[TN], fa[TH];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[j] = frag(lb, wc * WN + j * 16 + l15);
+        for (int j = 0; j < TN; ++j) fb[buf][j] = frag(lb, wc * WN + j * 16 + l15);
 #pragma unroll
-        for (int i = 0; i < TH; ++i) fa[i] = frag(la, wr * WM + i * 16 + l15);
-        if (kt + NSTAGE - 1 < nk) stage(kt + NSTAGE - 1);
+        for (int i = 0; i < TH; ++i) fal[buf][i] = frag(la, wr * WM + i * 16 + l15);
+    };
+    // STEADY: far enough from the end that every step prefetches and stages -- no branches, so the whole step is
+    // one basic block and the compiler's wait counts stay exact (at a join they collapse to "wait for everything")
+    auto step = [&](int kt, auto cur_tag, auto steady_tag) {
+        constexpr int cur = decltype(cur_tag)::value;
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        const char* la = smem + (kt % NSTAGE) * STAGE_BYTES;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int i = 0; i < TH; ++i) fah[i] = frag(la, wr * WM + (TH + i) * 16 + l15);
+        half8_t own[2][OWN];
+        if (EPI == EPI_NORM) {
 #pragma unroll
-            for (int i = 0; i < TH; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[h * TH + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[h * TH + i][j], 0, 0, 0);
-            if (EPI == EPI_NORM) {
-#pragma unroll
-                for (int o = 0; o < OWN; ++o) {
-                    half8_t own = fa[o * WGN < TH ? o * WGN : 0];
-#pragma unroll
-                    for (int w = 1; w < WGN; ++w)
-                        if (o * WGN + w < TH) own = (wc == w) ? fa[o * WGN + w] : own;
-                    add_row_moments(own, rs1[h][o], rs2[h][o]);
-                }
-            }
-            if (h == 0) {
-#pragma unroll
-                for (int i = 0; i < TH; ++i) fa[i] = frag(la, wr * WM + (TH + i) * 16 + l15);
+            for (int o = 0; o < OWN; ++o) {
+                own[0][o] = frag(la, wr * WM + (o * WGN + wc) * 16 + l15);
+                own[1][o] = frag(la, wr * WM + (TH + o * WGN + wc) * 16 + l15);
             }
         }
+        if (STEADY) {
+            wait_dma<(NSTAGE - 3) * LOADS>();
+            __builtin_amdgcn_s_barrier();        // tile kt+1 is visible; nobody still reads tile kt-1
+            read_next(cur ^ 1, kt + 1);
+            stage(kt + NSTAGE - 1);
+        } else if (kt + 1 < nk) {
+            wait_tile(min(NSTAGE - 3, nk - 2 - kt));
+            __builtin_amdgcn_s_barrier();
+            read_next(cur ^ 1, kt + 1);
+            if (kt + NSTAGE - 1 < nk) stage(kt + NSTAGE - 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);       // keep the requests above ahead of the MFMAs below
+#pragma unroll
+        for (int i = 0; i < TH; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[cur][j], fal[cur][i], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TH; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[TH + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[cur][j], fah[i], acc[TH + i][j], 0, 0, 0);
+        if (EPI == EPI_NORM) {
+#pragma unroll
+            for (int o = 0; o < OWN; ++o) {
+                add_row_moments(own[0][o], rs1[0][o], rs2[0][o]);
+                add_row_moments(own[1][o], rs1[1][o], rs2[1][o]);
+            }
+            // the dot products go behind the MFMAs of the second half, one each: by then the step's LDS requests have
+            // been waited for anyway (no extra wait), and they run while the matrix pipe is busy
+            __builtin_amdgcn_sched_group_barrier(0x008, TH * TN, 0);
+#pragma unroll
+            for (int r = 0; r < OWN * 16; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, (TH * TN) / (OWN * 16), 0);     // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                          // one VALU
+            }
+        }
+    };
+    wait_tile(min(NSTAGE - 2, nk - 1));
+    __builtin_amdgcn_s_barrier();
+    read_next(0, 0);
+    // lgkmcnt(0): the loop is entered with nothing pending, like its back edge -- otherwise the compiler's merged
+    // view at the loop header makes the first step wait for the requests it has just issued
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    using Even = std::integral_constant<int, 0>;
+    using Odd = std::integral_constant<int, 1>;
+    int kt = 0;
+    for (; kt + 2 + (NSTAGE - 1) <= nk; kt += 2) {
+        step(kt, Even{}, std::true_type{});
+        step(kt + 1, Odd{}, std::true_type{});
+    }
+    for (; kt < nk; kt += 2) {
+        step(kt, Even{}, std::false_type{});
+        if (kt + 1 < nk) step(kt + 1, Odd{}, std::false_type{});
     }
 
     if (EPI == EPI_NORM) {                       // lanes l, l+16, l+32, l+48 hold the four k-chunks of row l&15
@@ -547,14 +601,15 @@ int gemm_pick_tile(const GemmArgs& a) {
     // a residual that wraps (row m % resid_mod) must wrap on tile boundaries: the epilogue adds row offsets to the
     // tile's first residual row without a modulo per element
     auto wraps_inside = [&](int bm) { return a.resid && a.resid_mod % bm != 0; };
-    if (g_shared_gpu.load(std::memory_order_relaxed) && forced < 0 && a.M % 256 == 0 && a.N % 256 == 0 &&
+    const bool shared = g_shared_gpu.load(std::memory_order_relaxed);
+    if (shared && forced < 0 && a.M % 256 == 0 && a.N % 256 == 0 &&
         (a.M / 256) * (a.N / 256) >= 128 && !wraps_inside(256))
         return 7;
     for (int i = 0; i < kNumTiles; ++i) {
         const TileCfg& t = kTiles[i];
         if (a.M % t.bm || a.N % t.bn || wraps_inside(t.bm)) continue;
         if (i == forced) return i;
-        if (g_shared_gpu.load(std::memory_order_relaxed) && forced < 0) {
+        if (shared && forced < 0) {
             // shared GPU: other lanes fill the CUs this launch leaves free, so the only question is operand
             // traffic per FLOP -- the 256x256 tile (128 FLOP/B) whenever it yields enough workgroups,
             // otherwise the tiles that can share a CU
