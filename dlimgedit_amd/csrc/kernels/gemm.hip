@@ -582,7 +582,7 @@ constexpr TileCfg kTiles[] = {
     {128, 64, 3, 0.55f},    // 4: 2x2 waves, BK 64, 2 stages, 48 KB LDS
     {64, 64, 4, 0.40f},     // 5: 2x2 waves, BK 64, 2 stages, 32 KB LDS
     {256, 256, 1, 0.00f},   // 6: 8 waves 2x4 (128x64 each), BK 32, 4 stages, 128 KB LDS (shared-GPU mode or forced)
-    {256, 256, 1, 0.00f},   // 7: as 6 on v_mfma_f32_16x16x32_f16 (forced only until measured)
+    {256, 256, 1, 1.45f},   // 7: as 6 on v_mfma_f32_16x16x32_f16, fragments one K tile ahead (4096^3: 1010 TFLOP/s)
     {128, 128, 2, 0.00f},   // 8: 2x2 waves on 16x16x32, BK 32, 4 stages, 64 KB LDS (forced only until measured)
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);

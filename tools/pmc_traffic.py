@@ -1,0 +1,62 @@
+"""HBM-side bytes per kernel launch from two rocprofv3 counter passes (FETCH_SIZE and WRITE_SIZE cannot share a pass):
+
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_fetch -o fetch -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_write -o write -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch/fetch_results.db gpurun_out/pmc_write/write_results.db profiles/rNN_hbm_traffic_pmc.json
+
+Units and the gfx950 correction follow MI355X_MICROARCH.md (HBM section): both counters are in KB; FETCH_SIZE reports
+half the bytes of wide coalesced reads and is doubled; Infinity-Cache hits are included."""
+import json
+import sqlite3
+import sys
+
+GROUPS = [("gemm", ("gemm_f16_kernel", "gemm16_f16_kernel")), ("attn_window", ("attention_window_kernel",)),
+          ("attn_global", ("attention_global_kernel",)), ("layernorm", ("layernorm",)), ("pre", ("preprocess_kernel",)),
+          ("post", ("postprocess_kernel",))]
+
+
+def group_of(name):
+    for g, keys in GROUPS:
+        if any(k in name for k in keys):
+            return g
+    return "other"
+
+
+def collect(db_path, counter):
+    db = sqlite3.connect(db_path)
+    out = {}
+    for name, value in db.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
+        g = out.setdefault(group_of(name), [0, 0.0])
+        g[0] += 1
+        g[1] += value
+    return out
+
+
+def main():
+    fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+    per_kernel = {}
+    for g in sorted(set(fetch) | set(write)):
+        n_f, kb_f = fetch.get(g, [0, 0.0])
+        n_w, kb_w = write.get(g, [0, 0.0])
+        per_kernel[g] = {
+            "launches_in_run": n_f,
+            "fetch_size_kb_per_launch_raw": kb_f / max(n_f, 1),
+            "fetch_bytes_per_launch_corrected_x2": 2.0 * 1024.0 * kb_f / max(n_f, 1),
+            "write_bytes_per_launch": 1024.0 * kb_w / max(n_w, 1),
+        }
+    doc = {
+        "command": "python bench.py --steps 5 --warmup 1 --no-cpu-baseline (separate --pmc passes for FETCH_SIZE and WRITE_SIZE)",
+        "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced reads); "
+                "counters are in KB; includes Infinity-Cache hits",
+        "per_kernel": per_kernel,
+    }
+    doc.update(per_kernel.get("gemm", {}))
+    with open(sys.argv[3], "w") as f:
+        json.dump(doc, f, indent=1)
+    for g, v in per_kernel.items():
+        print(f"{g:12s} launches {v['launches_in_run']:5d}  fetch {v['fetch_bytes_per_launch_corrected_x2'] / 1e6:8.2f} MB  "
+              f"write {v['write_bytes_per_launch'] / 1e6:8.2f} MB per launch")
+
+
+if __name__ == "__main__":
+    main()
