@@ -303,17 +303,18 @@ DLIMG_API int dlimg_amd_test_gemm_ln(int M, int D, int K1, int N, uint16_t const
         Upload<half_t> w1(reinterpret_cast<half_t const*>(W1), (size_t)D * K1);
         Upload<half_t> wg(reinterpret_cast<half_t const*>(Wg), (size_t)N * D);
         Upload<float> b1(bias1, bias1 ? D : 0), r(resid, resid ? (size_t)M * D : 0), cs(colsum, N), b2(bias2, bias2 ? N : 0);
-        DeviceBuffer<float> x((size_t)M * D), y((size_t)M * N);
+        DeviceBuffer<float> x((size_t)M * D), y((size_t)M * N), stats((size_t)M * 24 * 2);
         DeviceBuffer<half_t> xh((size_t)M * D);
-        k::GemmArgs g;      // producer: writes the stream and its f16 copy
+        k::GemmArgs g;      // producer: writes the stream, its f16 copy and the per-tile row statistics
         g.A = a1.get(); g.lda = K1; g.W = w1.get(); g.ldw = K1; g.bias = bias1 ? b1.get() : nullptr;
         g.resid = resid ? r.get() : nullptr; g.ldr = D; g.resid_mod = M;
-        g.out_f32 = x.get(); g.ldc32 = D; g.out_h = xh.get(); g.ldc16 = D;
+        g.out_f32 = x.get(); g.ldc32 = D; g.out_h = xh.get(); g.ldc16 = D; g.stats_out = stats.get();
         g.M = M; g.N = D; g.K = K1;
+        const int groups = D / k::gemm_tile_columns(g);
         k::gemm(g, nullptr);
         g = k::GemmArgs{};  // consumer: LayerNorm folded in
         g.A = xh.get(); g.lda = D; g.W = wg.get(); g.ldw = D; g.bias = bias2 ? b2.get() : nullptr;
-        g.ln_colsum = cs.get(); g.ln_eps = eps;
+        g.ln_stats = stats.get(); g.ln_groups = groups; g.ln_colsum = cs.get(); g.ln_eps = eps;
         g.out_f32 = y.get(); g.ldc32 = N; g.M = M; g.N = N; g.K = D; g.act = act;
         k::gemm(g, nullptr);
         HIP_CHECK(hipDeviceSynchronize());
@@ -399,27 +400,37 @@ DLIMG_API int dlimg_amd_bench_gemm(int M, int N, int K, int act, int flavour, in
         for (auto& v : hw) v = zeros ? (half_t)0.f : (half_t)(rnd() * 0.05f);
         Upload<half_t> a(ha.data(), ha.size()), w(hw.data(), hw.size());
         DeviceBuffer<half_t> o((size_t)M * N);
-        DeviceBuffer<float> o32, colsum, bias;
+        DeviceBuffer<float> o32, colsum, bias, stats;
         k::GemmArgs g;
         g.A = a.get(); g.lda = K; g.W = w.get(); g.ldw = K; g.out_h = o.get(); g.ldc16 = N;
         g.M = M; g.N = N; g.K = K; g.act = act;
         // flavour 0: f16 output only; 1: LayerNorm folded in; 2: residual-stream writer (bias + fp32 residual in
-        // place); 3: the same plus the f16 copy of the stream; 4: f16 output with bias
+        // place); 3: the same plus the f16 copy of the stream and its row statistics; 4: f16 output with bias
         DLIMG_ASSERT(flavour >= 0 && flavour <= 4);
         std::vector<float> cs(N, 0.5f);
         bias.reserve(N);
         HIP_CHECK(hipMemcpy(bias.get(), cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
         if (flavour == 1) {
-            colsum.reserve(N);
+            DLIMG_ASSERT(K % 128 == 0);
+            const int groups = K / 128;              // as left by a producer with 128-column tiles
+            std::vector<float> st((size_t)groups * M * 2);
+            for (size_t i = 0; i < st.size(); i += 2) { st[i] = rnd(); st[i + 1] = 128.f; }
+            stats.reserve(st.size()); colsum.reserve(N);
+            HIP_CHECK(hipMemcpy(stats.get(), st.data(), st.size() * 4, hipMemcpyHostToDevice));
             HIP_CHECK(hipMemcpy(colsum.get(), cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
-            g.ln_colsum = colsum.get(); g.ln_eps = 1e-6f; g.bias = bias.get();
+            g.ln_stats = stats.get(); g.ln_groups = groups; g.ln_colsum = colsum.get(); g.ln_eps = 1e-6f;
+            g.bias = bias.get();
         } else if (flavour == 4) {
             g.bias = bias.get();
         } else if (flavour >= 2) {
             o32.reserve((size_t)M * N);
             HIP_CHECK(hipMemset(o32.get(), 0, (size_t)M * N * 4));
             g.bias = bias.get(); g.resid = o32.get(); g.ldr = N; g.resid_mod = M; g.out_f32 = o32.get(); g.ldc32 = N;
-            g.out_h = flavour == 3 ? o.get() : nullptr;
+            g.out_h = nullptr;
+            if (flavour == 3) {
+                stats.reserve((size_t)M * 24 * 2);
+                g.out_h = o.get(); g.stats_out = stats.get();
+            }
         }
         hipStream_t s;
         HIP_CHECK(hipStreamCreate(&s));

@@ -77,33 +77,79 @@ DLIMG_DEVICE float gelu_fast(float x) {
     return 0.5f * x * (1.0f + copysignf(e, x));
 }
 
-// Epilogue flavours: compile-time, so the plain GEMM does not carry the registers of the other
+// Epilogue flavours: compile-time, so the plain GEMM does not carry the registers of the others
 // (the shared epilogue code is in gemm_epilogue.inc).
-enum { EPI_PLAIN = 0, EPI_NORM = 1 };
+enum { EPI_PLAIN = 0, EPI_NORM = 1, EPI_STATS = 2 };
 
-// LayerNorm folded into the GEMM (EPI_NORM).  The A operand is the raw residual stream (its f16 copy), W carries
-// the LayerNorm scale.  The row statistics come from the A fragments the wave holds for the MFMAs anyway:
-//   s1 += sum of the 8 values, s2 += sum of their squares      (v_dot2c_f32_f16, fp32 accumulation)
-// The WGN waves that share a row panel split its 32- (16-) row fragments among themselves (fragment i belongs to
-// wave column i % WGN), so the extra VALU work is spread evenly; the owner leaves (mean, rstd) in LDS and the
-// epilogue applies   y = rstd_m * (acc - mean_m * colsum_n) + bias'_n .
-// No statistics travel through HBM and the summation order is fixed, so results do not depend on timing.
-DLIMG_DEVICE void add_row_moments(const half8_t& f, float& s1, float& s2) {
-    const half2_t one = {(half_t)1.f, (half_t)1.f};
+// LayerNorm folded into the GEMMs around it.
+//   EPI_STATS (the GEMM that writes the residual stream): besides the result, every workgroup leaves for each of its
+//     rows the (sum, sum of squared deviations from the tile mean) over the tile's BN columns -- reduced over 8 lanes
+//     by DPP per 32 columns in the epilogue, merged per row in LDS in a fixed order -> stats[N/BN][M] in HBM, a few
+//     bytes per row.
+//   EPI_NORM (the GEMM that consumes the normalised stream): A is the raw stream (its f16 copy), W carries the
+//     LayerNorm scale; the workgroup merges the N/BN partials of its rows (Chan et al.) into (mean, rstd) while the
+//     first operand tiles are in flight, and the epilogue applies  y = rstd_m * (acc - mean_m * colsum_n) + bias'_n .
+// No atomics, fixed summation order: results do not depend on timing.  Nothing is added to the MFMA loops (VALU work
+// there costs the GEMM 10-20 %, measured).
+constexpr int kStatRegs = 12;                    // partials per lane: N/BN <= 12 * (threads per row)
+
+template <int BM, int NTHREADS, int EPI>
+struct RowStats {
+    static constexpr int TPR = NTHREADS / BM;    // adjacent lanes that share a row
+    static_assert(TPR >= 1 && TPR <= 8 && (TPR & (TPR - 1)) == 0 && BM * TPR == NTHREADS, "row statistics layout");
+    float2_t q[EPI == EPI_NORM ? kStatRegs : 1];
+
+    DLIMG_DEVICE void issue(const k::GemmArgs& a, int m0) {
+        if (EPI != EPI_NORM) return;
+        const int r = threadIdx.x / TPR, sub = threadIdx.x % TPR;
+        // [group][row]: the lanes of one load instruction read runs of consecutive rows
+        const float2_t* p = reinterpret_cast<const float2_t*>(a.ln_stats) + (size_t)sub * a.M + (m0 + r);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const half2_t h = {f[2 * p], f[2 * p + 1]};
-        s1 = __builtin_amdgcn_fdot2(h, one, s1, false);
-        s2 = __builtin_amdgcn_fdot2(h, h, s2, false);
+        for (int u = 0; u < kStatRegs; ++u) {
+            q[u] = float2_t{0.f, -1.f};          // M2 < 0 marks "no such group"
+            if (sub + u * TPR < a.ln_groups) q[u] = p[(size_t)u * TPR * a.M];
+        }
     }
-}
+    DLIMG_DEVICE void finish(const k::GemmArgs& a, float* rowstat) {
+        if (EPI != EPI_NORM) return;
+        float s1 = 0.f;
+#pragma unroll
+        for (int u = 0; u < kStatRegs; ++u) s1 += q[u][0];
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) s1 += __shfl_xor(s1, o, 64);
+        const float n_g = (float)(a.K / a.ln_groups), inv_n_g = 1.0f / n_g;
+        const float mean = s1 / (float)a.K;
+        float m2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < kStatRegs; ++u) {
+            const float dm = q[u][0] * inv_n_g - mean;
+            m2 += q[u][1] >= 0.f ? q[u][1] + n_g * dm * dm : 0.f;
+        }
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) m2 += __shfl_xor(m2, o, 64);
+        if (threadIdx.x % TPR == 0)
+            reinterpret_cast<float2_t*>(rowstat)[threadIdx.x / TPR] = float2_t{mean, rsqrtf(m2 / (float)a.K + a.ln_eps)};
+    }
+};
 
-// (mean, rstd) of a row from its moments
-DLIMG_DEVICE float2_t row_mean_rstd(float s1, float s2, const k::GemmArgs& a) {
-    const float inv_k = 1.0f / (float)a.K;
-    const float mean = s1 * inv_k;
-    const float var = fmaxf(s2 * inv_k - mean * mean, 0.f);
-    return float2_t{mean, rsqrtf(var + a.ln_eps)};
+// EPI_STATS, after the last slab: one thread per row merges the 32-column partials of the tile (LDS, [BM][BN/32])
+// in column order and writes the tile's (sum, M2) of that row.
+template <int BM, int BN>
+DLIMG_DEVICE void write_tile_stats(const k::GemmArgs& a, const float2_t* rowpart, int m0, int n0) {
+    constexpr int G = BN / 32;
+    for (int r = threadIdx.x; r < BM; r += blockDim.x) {
+        float s1 = 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) s1 += rowpart[r * G + g][0];
+        const float mean = s1 * (1.0f / (float)BN);
+        float m2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float dm = rowpart[r * G + g][0] * (1.0f / 32.0f) - mean;
+            m2 += rowpart[r * G + g][1] + 32.0f * dm * dm;
+        }
+        reinterpret_cast<float2_t*>(a.stats_out)[(size_t)(n0 / BN) * a.M + m0 + r] = float2_t{s1, m2};
+    }
 }
 
 // LDS behind the operand ring: rowstat [BM] x (mean, rstd), then colvec [2][BN] = bias and LayerNorm column sums of
@@ -172,9 +218,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_f16_kernel(k::GemmA
 
     float* rowstat = reinterpret_cast<float*>(smem + NSTAGE * STAGE_BYTES);      // auxiliary area behind the ring
     float* colvec = rowstat + 2 * BM;
-    float rs1[TM], rs2[TM];                      // EPI_NORM: moments of the A row fragments this wave column owns
-#pragma unroll
-    for (int i = 0; i < TM; ++i) rs1[i] = rs2[i] = 0.f;
     const int nk = a.K / BKT;
     auto stage = [&](int kt) {
         char* dst = smem + (kt % NSTAGE) * STAGE_BYTES;
@@ -182,12 +225,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_f16_kernel(k::GemmA
         stage_tile<BN, BKT, NW>(a.W, a.ldw, n0, kt * BKT, dst + A_BYTES, wave, lane);
     };
     ColumnVectors<BM, BN, 64 * NW, EPI> column_vectors;
+    RowStats<BM, 64 * NW, EPI> row_stats;
     column_vectors.issue(a, n0);                 // ahead of the operand tiles, consumed behind them
+    row_stats.issue(a, m0);
     // prologue: NSTAGE-1 tiles in flight
 #pragma unroll
     for (int t = 0; t < NSTAGE - 1; ++t)
         if (t < nk) stage(t);
     column_vectors.store(colvec);
+    row_stats.finish(a, rowstat);
 
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt has landed once at most `later` newer tiles of this wave are still in flight
@@ -227,25 +273,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_f16_kernel(k::GemmA
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(fb[cur][j], fa[cur][i], acc[i][j]);
-            if (EPI == EPI_NORM) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    if (i % WGN == wc) add_row_moments(fa[cur][i], rs1[i], rs2[i]);
-            }
         }
     }
 
-    if (EPI == EPI_NORM) {                       // lanes l and l+32 hold the two k-halves of row l&31
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            if (i % WGN != wc) continue;
-            const float s1 = rs1[i] + swap_halves(rs1[i]), s2 = rs2[i] + swap_halves(rs2[i]);
-            if (hi == 0) reinterpret_cast<float2_t*>(rowstat)[wr * WM + i * 32 + l31] = row_mean_rstd(s1, s2, a);
-        }
-    }
     // ---- epilogue: accumulators -> LDS (row-major slab, chunk ^= row&7) -> coalesced rows -----------
     __syncthreads();                             // operand buffers are dead for every wave; aux area is complete
     char* slab = smem + wave * OUT_BYTES;
+    float2_t* rowpart = reinterpret_cast<float2_t*>(smem + NW * OUT_BYTES);   // EPI_STATS: [BM][BN/32] behind the slabs
+    static_assert(NW * OUT_BYTES + BM * (BN / 32) * 8 <= NSTAGE * STAGE_BYTES, "tile statistics must fit behind the slabs");
     const int resid_row0 = a.resid ? m0 % a.resid_mod : 0;
     static_assert((32 * CHUNKS) % 64 == 0, "staged slab must split evenly over 64 lanes");
     constexpr int NIT = 32 * CHUNKS / 64;        // float4 items per lane per slab
@@ -284,6 +319,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_f16_kernel(k::GemmA
             float4_t(&rv_cur)[NIT] = rv[sl % RV_BUFS];
 #include "gemm_epilogue.inc"
         }
+    }
+    if (EPI == EPI_STATS) {
+        __syncthreads();
+        write_tile_stats<BM, BN>(a, rowpart, m0, n0);
     }
 }
 
@@ -330,14 +369,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm16_f16_kernel(k::Gem
 
     float* rowstat = reinterpret_cast<float*>(smem + NSTAGE * STAGE_BYTES);      // auxiliary area behind the ring
     float* colvec = rowstat + 2 * BM;
-    // EPI_NORM: moments of the A row fragments this wave column owns -- fragment i of each half belongs to wave
-    // column i % WGN.  The owner reads its fragments a second time from LDS (two extra ds_reads per step): picking
-    // them out of the MFMA operands needs a branch or 24 selects per step inside the MFMA stream, which costs more.
-    constexpr int OWN = (TM / 2 + WGN - 1) / WGN;  // owned fragments per half
-    static_assert(EPI != EPI_NORM || (TM / 2) % WGN == 0, "every wave column owns the same number of row fragments");
-    float rs1[2][OWN], rs2[2][OWN];
-#pragma unroll
-    for (int i = 0; i < 2 * OWN; ++i) rs1[i / OWN][i % OWN] = rs2[i / OWN][i % OWN] = 0.f;
     const int nk = a.K / BKT;
     auto stage = [&](int kt) {
         char* dst = smem + (kt % NSTAGE) * STAGE_BYTES;
@@ -348,11 +379,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm16_f16_kernel(k::Gem
         return *reinterpret_cast<const half8_t*>(lds + row * ROW_BYTES + ((quad ^ swz16(row)) << 4));
     };
     ColumnVectors<BM, BN, 64 * NW, EPI> column_vectors;
+    RowStats<BM, 64 * NW, EPI> row_stats;
     column_vectors.issue(a, n0);                 // ahead of the operand tiles, consumed behind them
+    row_stats.issue(a, m0);
 #pragma unroll
     for (int t = 0; t < NSTAGE - 1; ++t)
         if (t < nk) stage(t);
     column_vectors.store(colvec);
+    row_stats.finish(a, rowstat);
 
     // Fragments travel one K tile ahead of the MFMAs that use them: while the matrix pipe works on tile kt (all of
     // its operands already in registers), the wave passes the barrier for tile kt+1 and requests that tile's B
@@ -382,14 +416,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm16_f16_kernel(k::Gem
         const char* la = smem + (kt % NSTAGE) * STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < TH; ++i) fah[i] = frag(la, wr * WM + (TH + i) * 16 + l15);
-        half8_t own[2][OWN];
-        if (EPI == EPI_NORM) {
-#pragma unroll
-            for (int o = 0; o < OWN; ++o) {
-                own[0][o] = frag(la, wr * WM + (o * WGN + wc) * 16 + l15);
-                own[1][o] = frag(la, wr * WM + (TH + o * WGN + wc) * 16 + l15);
-            }
-        }
         if (STEADY) {
             wait_dma<(NSTAGE - 3) * LOADS>();
             __builtin_amdgcn_s_barrier();        // tile kt+1 is visible; nobody still reads tile kt-1
@@ -412,21 +438,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm16_f16_kernel(k::Gem
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 acc[TH + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[cur][j], fah[i], acc[TH + i][j], 0, 0, 0);
-        if (EPI == EPI_NORM) {
-#pragma unroll
-            for (int o = 0; o < OWN; ++o) {
-                add_row_moments(own[0][o], rs1[0][o], rs2[0][o]);
-                add_row_moments(own[1][o], rs1[1][o], rs2[1][o]);
-            }
-            // the dot products go behind the MFMAs of the second half, one each: by then the step's LDS requests have
-            // been waited for anyway (no extra wait), and they run while the matrix pipe is busy
-            __builtin_amdgcn_sched_group_barrier(0x008, TH * TN, 0);
-#pragma unroll
-            for (int r = 0; r < OWN * 16; ++r) {
-                __builtin_amdgcn_sched_group_barrier(0x008, (TH * TN) / (OWN * 16), 0);     // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                          // one VALU
-            }
-        }
     };
     wait_tile(min(NSTAGE - 2, nk - 1));
     __builtin_amdgcn_s_barrier();
@@ -446,25 +457,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm16_f16_kernel(k::Gem
         if (kt + 1 < nk) step(kt + 1, Odd{}, std::false_type{});
     }
 
-    if (EPI == EPI_NORM) {                       // lanes l, l+16, l+32, l+48 hold the four k-chunks of row l&15
-        constexpr int TH = TM / 2;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int o = 0; o < OWN; ++o) {
-                const int frag = h * TH + o * WGN + wc;      // the fragment these moments belong to
-                float s1 = rs1[h][o], s2 = rs2[h][o];
-                s1 += __shfl_xor(s1, 16, 64);
-                s2 += __shfl_xor(s2, 16, 64);
-                s1 += __shfl_xor(s1, 32, 64);
-                s2 += __shfl_xor(s2, 32, 64);
-                if (quad == 0 && o * WGN + wc < TH)
-                    reinterpret_cast<float2_t*>(rowstat)[wr * WM + frag * 16 + l15] = row_mean_rstd(s1, s2, a);
-            }
-    }
     // ---- epilogue: 32-row bands through an LDS slab, as in the 32x32 kernel --------------------------
     __syncthreads();
     char* slab = smem + wave * OUT_BYTES;
+    float2_t* rowpart = reinterpret_cast<float2_t*>(smem + NW * OUT_BYTES);   // EPI_STATS: [BM][BN/32] behind the slabs
+    static_assert(NW * OUT_BYTES + BM * (BN / 32) * 8 <= NSTAGE * STAGE_BYTES, "tile statistics must fit behind the slabs");
     const int resid_row0 = a.resid ? m0 % a.resid_mod : 0;
     constexpr int NIT = 32 * CHUNKS / 64;
     constexpr int NJ = (WN / 32) / JG, NSLAB = (TM / 2) * NJ;
@@ -504,14 +501,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm16_f16_kernel(k::Gem
 #include "gemm_epilogue.inc"
         }
     }
+    if (EPI == EPI_STATS) {
+        __syncthreads();
+        write_tile_stats<BM, BN>(a, rowpart, m0, n0);
+    }
 }
 
 typedef void (*GemmKernel)(k::GemmArgs);
 
 // Picks the epilogue flavour the arguments ask for and launches; LDS above the default limit is opted into once.
-void launch_flavour(GemmKernel const (&kernels)[4], bool (&attr_set)[4], const k::GemmArgs& a, int grid, int threads,
+void launch_flavour(GemmKernel const (&kernels)[5], bool (&attr_set)[5], const k::GemmArgs& a, int grid, int threads,
                     size_t lds, hipStream_t s) {
-    const int index = (a.ln_colsum ? 2 : 0) + (a.act == k::ACT_GELU ? 1 : 0);
+    const int index = a.stats_out ? 4 : (a.ln_stats ? 2 : 0) + (a.act == k::ACT_GELU ? 1 : 0);
     if (lds > 48 * 1024 && !attr_set[index]) {
         if (hipFuncSetAttribute((const void*)kernels[index], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess)
@@ -524,13 +525,14 @@ void launch_flavour(GemmKernel const (&kernels)[4], bool (&attr_set)[4], const k
 template <int BM, int BN, int WGM, int WGN, int NSTAGE, int MINW>
 void launch16(const k::GemmArgs& a, hipStream_t s) {
     const size_t lds = (size_t)NSTAGE * (BM + BN) * 64 + aux_bytes(BM, BN);
-    static const GemmKernel kernels[4] = {
+    static const GemmKernel kernels[5] = {
         gemm16_f16_kernel<BM, BN, WGM, WGN, NSTAGE, MINW, k::ACT_NONE, EPI_PLAIN>,
         gemm16_f16_kernel<BM, BN, WGM, WGN, NSTAGE, MINW, k::ACT_GELU, EPI_PLAIN>,
         gemm16_f16_kernel<BM, BN, WGM, WGN, NSTAGE, MINW, k::ACT_NONE, EPI_NORM>,
         gemm16_f16_kernel<BM, BN, WGM, WGN, NSTAGE, MINW, k::ACT_GELU, EPI_NORM>,
+        gemm16_f16_kernel<BM, BN, WGM, WGN, NSTAGE, MINW, k::ACT_NONE, EPI_STATS>,
     };
-    static bool attr_set[4] = {};
+    static bool attr_set[5] = {};
     launch_flavour(kernels, attr_set, a, (a.M / BM) * (a.N / BN), 64 * WGM * WGN, lds, s);
 }
 
@@ -538,15 +540,16 @@ template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE, int MINW>
 void launch(const k::GemmArgs& a, hipStream_t s) {
     const size_t lds = (size_t)NSTAGE * (BM + BN) * BKT * 2 + aux_bytes(BM, BN);
     static const int ablate = [] { const char* e = std::getenv("DLIMGEDIT_GEMM_ABLATE"); return e ? std::atoi(e) : 0; }();
-    static const GemmKernel kernels[4] = {
+    static const GemmKernel kernels[5] = {
         ablate == 1   ? gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_NONE, EPI_PLAIN, 1>
         : ablate == 2 ? gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_NONE, EPI_PLAIN, 2>
                       : gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_NONE, EPI_PLAIN>,
         gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_GELU, EPI_PLAIN>,
         gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_NONE, EPI_NORM>,
         gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_GELU, EPI_NORM>,
+        gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_NONE, EPI_STATS>,
     };
-    static bool attr_set[4] = {};
+    static bool attr_set[5] = {};
     launch_flavour(kernels, attr_set, a, (a.M / BM) * (a.N / BN), 64 * WGM * WGN, lds, s);
 }
 
@@ -566,7 +569,11 @@ const char* gemm_check(const GemmArgs& a) {
         (a.out_f32 && (((uintptr_t)a.out_f32 & 15) || a.ldc32 % 4)) ||
         (a.out_h && (((uintptr_t)a.out_h & 7) || a.ldc16 % 4)))
         return "gemm: bias/residual/output rows must be 16-byte (f16 output: 8-byte) aligned";
-    if (a.ln_colsum && ((uintptr_t)a.ln_colsum & 15)) return "gemm: LayerNorm column sums must be 16-byte aligned";
+    if (a.ln_stats && (!a.ln_colsum || ((uintptr_t)a.ln_colsum & 15) || a.ln_groups <= 0 || a.K % a.ln_groups ||
+                       a.ln_groups > kStatRegs * 2))
+        return "gemm: folded LayerNorm needs aligned column sums and 1..24 statistic groups that divide K";
+    if (a.stats_out && (a.ln_stats || a.act != ACT_NONE))
+        return "gemm: row statistics cannot be combined with an activation or a folded LayerNorm";
     return nullptr;
 }
 
@@ -615,13 +622,22 @@ int gemm_pick_tile(const GemmArgs& a) {
             // otherwise the tiles that can share a CU
             if (t.per_cu < 2) continue;
         }
+        static const bool exp8 = std::getenv("DLIMGEDIT_EXP_TILE8") != nullptr;
+        const float eff = (i == 8 && exp8) ? 0.85f : t.eff;
         const int blocks = (a.M / t.bm) * (a.N / t.bn);
         const int slots = 256 * t.per_cu;
         const int rounds = (blocks + slots - 1) / slots;
-        const float score = t.eff * (float)blocks / (float)(rounds * slots);
+        const float score = eff * (float)blocks / (float)(rounds * slots);
         if (score > best_score) { best_score = score; best = i; }
     }
     return best;
+}
+
+int gemm_tile_columns(const GemmArgs& a) {
+    if (const char* err = gemm_check(a)) throw_error(err);
+    const int tile = gemm_pick_tile(a);
+    if (tile < 0) throw_error("gemm: no tile configuration fits this shape");
+    return kTiles[tile].bn;
 }
 
 void gemm(const GemmArgs& a, hipStream_t s) {

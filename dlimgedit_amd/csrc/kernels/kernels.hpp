@@ -26,13 +26,19 @@ struct GemmArgs {
     half_t* out_h = nullptr;    int ldc16 = 0;
     int M = 0, N = 0, K = 0;
     int act = ACT_NONE;
-    // LayerNorm folded into the GEMM (ln_colsum != nullptr): A is the raw, un-normalised input, W carries the
-    // LayerNorm scale (W * diag(gamma)), bias carries b + W.beta; the kernel takes mean / variance of each A row
-    // from the operand fragments it streams anyway and applies  rstd_m * (acc - mean_m * ln_colsum[n]) + bias[n].
+    // LayerNorm folded into the GEMMs around it (gemm.hip).  Producer: stats_out receives, per tile column block and
+    // row, the (sum, sum of squared deviations) of the fp32 result -- [N / gemm_tile_columns()][M][2].  Consumer: A is
+    // the raw, un-normalised input, W carries the LayerNorm scale (W * diag(gamma)), bias carries b + W.beta; ln_stats
+    // are the producer's partials ([ln_groups][M][2], groups of K / ln_groups columns) and the epilogue applies
+    // rstd_m * (acc - mean_m * ln_colsum[n]) + bias[n].
+    float* stats_out = nullptr;
+    const float* ln_stats = nullptr;
+    int ln_groups = 0;
     const float* ln_colsum = nullptr;            // [N] sum over k of the (f16-rounded) scaled weight
     float ln_eps = 0.f;
 };
 const char* gemm_check(const GemmArgs&);
+int gemm_tile_columns(const GemmArgs&);       // BN of the tile configuration gemm() will use for these arguments
 void gemm(const GemmArgs&, hipStream_t);
 // Tile selection hint: true when kernels of several execution lanes share the GPU.
 void gemm_set_shared_gpu(bool shared);

@@ -326,6 +326,7 @@ void SamModel::reserve_encoder(int batch) {
     patches_.reserve(M * kPatchK);
     x_.reserve(M * D);
     xn_.reserve(M * D);
+    xstat_.reserve(M * 24 * 2);              // at most 24 tile column blocks per row (kernels/gemm.hip)
     qkv_.reserve(M * 3 * D);
     att_.reserve(M * std::max<size_t>(D, kEmbedDim));
     hid_.reserve(M * wide);
@@ -429,18 +430,23 @@ void SamModel::encode(int batch) {
     const int M = batch * kTokens;
 
     // Block structure: x += proj(attn(qkv(LN1(x)))); x += fc2(gelu(fc1(LN2(x)))).  With folded LayerNorms every
-    // GEMM that writes the residual stream x (fp32) also leaves its f16 copy; the next GEMM multiplies that copy
-    // by the gamma-scaled weight, takes the row moments from the operand fragments it streams and normalises in
-    // its epilogue: the stream is read once (as f16) per consumer instead of LN read + LN write + GEMM read.
+    // GEMM that writes the residual stream x (fp32) also leaves its f16 copy and, per tile column block, the row
+    // statistics of what it wrote; the next GEMM multiplies the f16 copy by the gamma-scaled weight, merges the
+    // statistics of its rows and normalises in its epilogue: the stream is read once (as f16) per consumer instead
+    // of LN read + LN write + GEMM read.
     const bool fused = W.fused_ln_;
+    int stat_groups = 0;                         // tile column blocks of the GEMM that last wrote the stream
     auto writes_stream = [&](k::GemmArgs& a) {
         a.resid_mod = a.resid == x_.get() ? M : a.resid_mod;
         a.out_f32 = x_.get(); a.ldc32 = D; a.M = M; a.N = D;
-        if (fused) { a.out_h = xn_.get(); a.ldc16 = D; }
+        if (fused) {
+            a.out_h = xn_.get(); a.ldc16 = D; a.stats_out = xstat_.get();
+            stat_groups = D / k::gemm_tile_columns(a);
+        }
     };
     auto reads_stream = [&](k::GemmArgs& a, LinearH const& lin, NormW const& norm) {
         if (fused) {
-            a.ln_colsum = lin.colsum.get(); a.ln_eps = kLnEps;
+            a.ln_stats = xstat_.get(); a.ln_groups = stat_groups; a.ln_colsum = lin.colsum.get(); a.ln_eps = kLnEps;
         } else {
             timed(ST_LAYERNORM, (double)M * D * 6, [&] {
                 k::layernorm(x_.get(), norm.w.get(), norm.b.get(), kLnEps, M, D, k::ACT_NONE, nullptr, xn_.get(), stream_);

@@ -166,7 +166,7 @@ class SamModel {
     PinnedBuffer img_pinned_;
     hipEvent_t upload_done_ = nullptr;    // guards re-use of img_pinned_ by the next upload
     DeviceBuffer<half_t> patches_, xn_, qkv_, att_, hid_;
-    DeviceBuffer<float> x_, neck_f32_, emb_;
+    DeviceBuffer<float> x_, xstat_, neck_f32_, emb_;
 
     // ---- longest-side resize (images whose longest side is not 1024)
     struct AxisDev {

@@ -78,7 +78,8 @@ DLIMG_API int dlimg_amd_test_gemm(int M, int N, int K, uint16_t const* A, uint16
                                   float const* resid, int resid_rows, int act, float* out_f32, uint16_t* out_f16);
 /* Two chained GEMMs with the LayerNorm between them folded in ("LayerNorm inside the GEMMs"):
  *   x = A1[M,K1] . W1[D,K1]^T + bias1 + resid[M,D]        -> out_x [M,D] fp32 and out_xh [M,D] f16
- *   y = act(rstd * (xh . Wg[N,D]^T - mean * colsum[N]) + bias2[N])   -> out_y [M,N]; mean / rstd of the rows of xh
+ *   y = act(rstd * (xh . Wg[N,D]^T - mean * colsum[N]) + bias2[N])   -> out_y [M,N]; mean / rstd of the rows of x,
+ *       merged from the per-tile statistics the first GEMM leaves
  * Wg = W * diag(gamma) in f16, colsum = row sums of Wg, bias2 = b + W.beta: prepared by the caller. */
 DLIMG_API int dlimg_amd_test_gemm_ln(int M, int D, int K1, int N, uint16_t const* A1, uint16_t const* W1,
                                      float const* bias1, float const* resid, uint16_t const* Wg, float const* colsum,
@@ -95,7 +96,7 @@ DLIMG_API int dlimg_amd_test_attention(int global, uint16_t const* qkv, float co
 DLIMG_API int dlimg_amd_test_resize(uint8_t const* pixels, int width, int height, int stride, int channels, int out_w,
                                     int out_h, uint8_t* out_pixels);
 /* Times `iters` launches of the GEMM on device-resident random operands; returns average ms per launch.
- * flavour 0: f16 output; 1: LayerNorm folded in; 2: bias + fp32 residual in place; 3: 2 + f16 copy of the result;
+ * flavour 0: f16 output; 1: LayerNorm folded in; 2: bias + fp32 residual in place; 3: 2 + f16 copy of the result + row statistics;
  * 4: f16 output with bias. */
 DLIMG_API int dlimg_amd_bench_gemm(int M, int N, int K, int act, int flavour, int iters, double* out_ms);
 
