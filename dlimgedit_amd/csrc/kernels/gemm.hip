@@ -396,7 +396,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm16_f16_kernel(k::Gem
     constexpr int TH = TM / 2;
     half8_t fb[2][TN], fal[2][TH], fah[TH];
     auto wait_tile = [&](int newer) {            // wave's copies of a tile have landed; `newer` tiles may be in flight
-        if (newer >= 2) wait_dma<2 * LOADS>();
+        static_assert((NSTAGE - 2) * LOADS < 64 && NSTAGE <= 8, "vmcnt is a 6-bit counter");
+        if (newer >= 6) wait_dma<6 * LOADS>();
+        else if (newer == 5) wait_dma<5 * LOADS>();
+        else if (newer == 4) wait_dma<4 * LOADS>();
+        else if (newer == 3) wait_dma<3 * LOADS>();
+        else if (newer == 2) wait_dma<2 * LOADS>();
         else if (newer == 1) wait_dma<LOADS>();
         else wait_dma<0>();
     };
@@ -622,8 +627,7 @@ int gemm_pick_tile(const GemmArgs& a) {
             // otherwise the tiles that can share a CU
             if (t.per_cu < 2) continue;
         }
-        static const bool exp8 = std::getenv("DLIMGEDIT_EXP_TILE8") != nullptr;
-        const float eff = (i == 8 && exp8) ? 0.85f : t.eff;
+        const float eff = t.eff;
         const int blocks = (a.M / t.bm) * (a.N / t.bn);
         const int slots = 256 * t.per_cu;
         const int rounds = (blocks + slots - 1) / slots;
