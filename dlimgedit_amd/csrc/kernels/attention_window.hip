@@ -87,23 +87,62 @@ __global__ __launch_bounds__(448) void attention_window_kernel(const half_t* __r
             qf[ks] = *reinterpret_cast<const half8_t*>(base + (size_t)qs.token * ld + head * HD + ks * 16 + hi * 8);
     }
 
+    // ---- K and V of the window are requested now and parked in registers: their latency runs behind the
+    // rel-pos prologue below, whose LDS scratch aliases the K / V images.
+    // consecutive threads take consecutive 16-byte chunks of one slot: whole global lines per request
+    static_assert((SLOTS * CHUNKS) % 448 == 0, "K/V chunks split evenly over the workgroup");
+    constexpr int KV_IT = SLOTS * CHUNKS / 448;
+    half8_t kreg[KV_IT], vreg[KV_IT];
+#pragma unroll
+    for (int it = 0; it < KV_IT; ++it) {
+        const int idx = tid + it * 448;
+        const int slot = idx / CHUNKS, ch = idx % CHUNKS;
+        const WinSlot ws = win_slot(slot, wy, wx);
+        kreg[it] = zero_h8();
+        vreg[it] = zero_h8();
+        if (!ws.dummy) {
+            if (ws.pad) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    kreg[it][e] = (half_t)qkv_bias[D + head * HD + ch * 8 + e];
+                    vreg[it][e] = (half_t)qkv_bias[2 * D + head * HD + ch * 8 + e];
+                }
+            } else {
+                const half_t* row = base + (size_t)ws.token * ld + head * HD + ch * 8;
+                kreg[it] = *reinterpret_cast<const half8_t*>(row + D);
+                vreg[it] = *reinterpret_cast<const half8_t*>(row + 2 * D);
+            }
+        }
+    }
+
     // ---- decomposed rel-pos: G[r][i] = rel[r] . q_i  via MFMA, gathered into per-lane registers ----
     float* g = lds_g + wave * 32 * G_STRIDE;
     const int ty_q = qslot >> 4, tx_q = qslot & 15;
     float bh[WS];       // bias from the key's row, index = key ty
     float bw[8];        // bias from the key's column, index e <-> tx = (e&3) + 8*(e>>2) + 4*hi
     {
-        float16_t acc = zero16();
+        // both tables' fragments are requested before the first MFMA: one memory latency, not two
+        half8_t rfh[KS], rfw[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            half8_t rf = zero_h8();
+            rfh[ks] = zero_h8();
+            rfw[ks] = zero_h8();
             if (l31 < 2 * WS - 1) {
-                const float* r = rel_h + l31 * HD + ks * 16 + hi * 8;
+                const float4_t* rh = reinterpret_cast<const float4_t*>(rel_h + l31 * HD + ks * 16 + hi * 8);
+                const float4_t* rw = reinterpret_cast<const float4_t*>(rel_w + l31 * HD + ks * 16 + hi * 8);
+                const float4_t h0 = rh[0], h1 = rh[1], w0 = rw[0], w1 = rw[1];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) rf[e] = (half_t)r[e];
+                for (int e = 0; e < 4; ++e) {
+                    rfh[ks][e] = (half_t)h0[e];
+                    rfh[ks][4 + e] = (half_t)h1[e];
+                    rfw[ks][e] = (half_t)w0[e];
+                    rfw[ks][4 + e] = (half_t)w1[e];
+                }
             }
-            acc = mfma32(rf, qf[ks], acc);
         }
+        float16_t acc = zero16();
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = mfma32(rfh[ks], qf[ks], acc);
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[l31 * G_STRIDE + acc_row(r, hi)] = acc[r];
         __syncthreads();
@@ -112,15 +151,7 @@ __global__ __launch_bounds__(448) void attention_window_kernel(const half_t* __r
         __syncthreads();
         acc = zero16();
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            half8_t rf = zero_h8();
-            if (l31 < 2 * WS - 1) {
-                const float* r = rel_w + l31 * HD + ks * 16 + hi * 8;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) rf[e] = (half_t)r[e];
-            }
-            acc = mfma32(rf, qf[ks], acc);
-        }
+        for (int ks = 0; ks < KS; ++ks) acc = mfma32(rfw[ks], qf[ks], acc);
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[l31 * G_STRIDE + acc_row(r, hi)] = acc[r];
         __syncthreads();
@@ -133,27 +164,13 @@ __global__ __launch_bounds__(448) void attention_window_kernel(const half_t* __r
         __syncthreads();        // scratch is dead; K / V images may be written over it
     }
 
-    // ---- stage K and V (both row-major, padded rows) of the whole window -------------------------
-    // consecutive threads take consecutive 16-byte chunks of one slot: whole global lines per request
-    for (int idx = tid; idx < SLOTS * CHUNKS; idx += 448) {
-        const int slot = idx / CHUNKS, ch = idx % CHUNKS;
-        const WinSlot ws = win_slot(slot, wy, wx);
-        half8_t kv = zero_h8(), vv = zero_h8();
-        if (!ws.dummy) {
-            if (ws.pad) {
+    // ---- K and V (both row-major, padded rows) of the whole window: registers -> LDS ------------------
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    kv[e] = (half_t)qkv_bias[D + head * HD + ch * 8 + e];
-                    vv[e] = (half_t)qkv_bias[2 * D + head * HD + ch * 8 + e];
-                }
-            } else {
-                const half_t* row = base + (size_t)ws.token * ld + head * HD + ch * 8;
-                kv = *reinterpret_cast<const half8_t*>(row + D);
-                vv = *reinterpret_cast<const half8_t*>(row + 2 * D);
-            }
-        }
-        *reinterpret_cast<half8_t*>(lds_k + slot * K_STRIDE + ch * 8) = kv;
-        *reinterpret_cast<half8_t*>(lds_v + slot * V_STRIDE + ch * 8) = vv;
+    for (int it = 0; it < KV_IT; ++it) {
+        const int idx = tid + it * 448;
+        const int slot = idx / CHUNKS, ch = idx % CHUNKS;
+        *reinterpret_cast<half8_t*>(lds_k + slot * K_STRIDE + ch * 8) = kreg[it];
+        *reinterpret_cast<half8_t*>(lds_v + slot * V_STRIDE + ch * 8) = vreg[it];
     }
     if (DT * 32 > HD) {         // V columns beyond the head dimension must not hold NaN patterns
         constexpr int PADC = (DT * 32 - HD) / 8;
