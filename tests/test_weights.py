@@ -1,6 +1,7 @@
 """Weight inventory, seeded generator and the DLW file format (dlimgedit_amd/weights.py)."""
 import numpy as np
 import pytest
+from pathlib import Path
 
 from dlimgedit_amd import weights as W
 from dlimgedit_amd.sam_config import CONFIGS, get_config
@@ -79,3 +80,33 @@ def test_meta_checkpoint_mapping_round_trips():
         assert np.array_equal(back[k], params[k]), k
     with pytest.raises(ValueError, match="wrong variant"):
         W.from_meta_state_dict(CONFIGS["vit_b"], sd)
+
+
+@pytest.mark.parametrize("fmt", ["pth", "safetensors"])
+def test_convert_checkpoint_tool(tmp_path, fmt):
+    """tools/convert_checkpoint.py end to end: a Meta-style .pth / an HF-style .safetensors file in, the DLW file the
+    library loads out."""
+    import subprocess
+    import sys
+    import torch
+    cfg = CONFIGS["vit_test"]
+    params = W.synthetic_weights(cfg, 3)
+    if fmt == "pth":
+        sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in W.to_meta_state_dict(cfg, params).items()}
+        src = tmp_path / "sam_test.pth"
+        torch.save(sd, src)
+        extra = []
+    else:
+        from safetensors.torch import save_file
+        sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in W.to_hf_state_dict(cfg, params).items()}
+        src = tmp_path / "model.safetensors"
+        save_file(sd, str(src))
+        extra = ["--hf"]
+    tool = Path(__file__).resolve().parent.parent / "tools" / "convert_checkpoint.py"
+    r = subprocess.run([sys.executable, str(tool), str(src), "vit_test", str(tmp_path / "models"), *extra],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    cfg2, back = W.load_weights(tmp_path / "models" / "segmentation" / W.weight_file_name(cfg))
+    assert cfg2["embed_dim"] == cfg.embed_dim and cfg2["depth"] == cfg.depth
+    for name, value in params.items():
+        assert np.array_equal(back[name], value), name
