@@ -98,7 +98,8 @@ def test_convert_checkpoint_tool(tmp_path, fmt):
         extra = []
     else:
         from safetensors.torch import save_file
-        sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in W.to_hf_state_dict(cfg, params).items()}
+        # HF ties two names to one tensor; a file holds them as separate copies
+        sd = {k: torch.from_numpy(np.array(v, copy=True)) for k, v in W.to_hf_state_dict(cfg, params).items()}
         src = tmp_path / "model.safetensors"
         save_file(sd, str(src))
         extra = ["--hf"]
