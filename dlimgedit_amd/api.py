@@ -378,6 +378,9 @@ class ext:
                 "dlimg_amd_test_layernorm": ([vp, vp, vp, cf, ci, ci, ci, vp, vp], ci),
                 "dlimg_amd_test_attention": ([ci, vp, vp, vp, vp, ci, ci, ci, vp], ci),
                 "dlimg_amd_test_resize": ([vp, ci, ci, ci, ci, ci, ci, vp], ci),
+                "dlimg_amd_birefnet_prepare_image": ([vp, ci, ci, ci, ci, vp, vp, vp], ci),
+                "dlimg_amd_birefnet_process_mask": ([vp, ci, ci, vp], ci),
+                "dlimg_amd_resize_mask": ([vp, ci, ci, ci, ci, ci, vp], ci),
                 "dlimg_amd_bench_gemm": ([ci, ci, ci, ci, ci, ci, C.POINTER(C.c_double)], ci),
             }
             for name, (args, res) in sig.items():
@@ -392,6 +395,7 @@ class ext:
                "dlimg_amd_set_profiling",
                "dlimg_amd_take_stage_stats", "dlimg_amd_test_preprocess", "dlimg_amd_test_postprocess",
                "dlimg_amd_test_gemm", "dlimg_amd_test_gemm_ln", "dlimg_amd_test_layernorm", "dlimg_amd_test_attention", "dlimg_amd_test_resize",
+               "dlimg_amd_birefnet_prepare_image", "dlimg_amd_birefnet_process_mask", "dlimg_amd_resize_mask",
                "dlimg_amd_bench_gemm")
 
     @staticmethod
@@ -569,6 +573,36 @@ class ext:
         out = np.empty((out_h, out_w, c), dtype=np.uint8)
         _check(cls._l().dlimg_amd_test_resize(pixels.ctypes.data, w, h, w * c, int(channels), out_w, out_h,
                                               out.ctypes.data))
+        return out
+
+    @classmethod
+    def birefnet_prepare_image(cls, image: np.ndarray, channels: "Channels", mean, std) -> np.ndarray:
+        """BiRefNet::prepare_image: u8 [H,W,C] -> f32 [1,3,H,W] (reference: segmentation.cpp:244-256)."""
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        h, w = image.shape[:2]
+        mean = np.ascontiguousarray(mean, dtype=np.float32)
+        std = np.ascontiguousarray(std, dtype=np.float32)
+        out = np.empty((1, 3, h, w), dtype=np.float32)
+        _check(cls._l().dlimg_amd_birefnet_prepare_image(image.ctypes.data, w, h, image.strides[0], int(channels),
+                                                         mean.ctypes.data, std.ctypes.data, out.ctypes.data))
+        return out
+
+    @classmethod
+    def birefnet_process_mask(cls, logits: np.ndarray) -> np.ndarray:
+        """BiRefNet::process_mask: f32 [H,W] -> u8 [H,W] (reference: segmentation.cpp:258-270)."""
+        logits = np.ascontiguousarray(logits, dtype=np.float32)
+        h, w = logits.shape
+        out = np.empty((h, w), dtype=np.uint8)
+        _check(cls._l().dlimg_amd_birefnet_process_mask(logits.ctypes.data, w, h, out.ctypes.data))
+        return out
+
+    @classmethod
+    def resize_mask(cls, mask: np.ndarray, out_w: int, out_h: int) -> np.ndarray:
+        """dlimg::resize_mask: u8 [H,W] -> u8 [out_h,out_w], box filter (reference: image.cpp:53-62)."""
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        h, w = mask.shape
+        out = np.empty((out_h, out_w), dtype=np.uint8)
+        _check(cls._l().dlimg_amd_resize_mask(mask.ctypes.data, w, h, mask.strides[0], out_w, out_h, out.ctypes.data))
         return out
 
     @classmethod

@@ -27,6 +27,7 @@ SOURCES = [
     "kernels/decoder.hip",
     "kernels/postprocess.hip",
     "kernels/resize.hip",
+    "kernels/objects.hip",
     "resize_tables.cpp",
     "weights.cpp",
     "sam_model.cpp",
@@ -42,6 +43,7 @@ SOURCES = [
 EXTRA_FLAGS = {
     "kernels/postprocess.hip": ["-ffp-contract=off"],
     "kernels/resize.hip": ["-ffp-contract=off"],
+    "kernels/objects.hip": ["-ffp-contract=off"],
     "resize_tables.cpp": ["-ffp-contract=off"],
 }
 

@@ -388,6 +388,57 @@ DLIMG_API int dlimg_amd_test_resize(uint8_t const* pixels, int width, int height
     });
 }
 
+// ---- pre / post-processing of segment_objects (BiRefNet) -------------------------
+
+DLIMG_API int dlimg_amd_birefnet_prepare_image(uint8_t const* pixels, int width, int height, int stride, int channels,
+                                               float const* mean, float const* std, float* out_nchw) {
+    return guarded([&] {
+        require_gpu();
+        DLIMG_ASSERT(pixels && mean && std && out_nchw && width > 0 && height > 0);
+        const int C = channel_bytes(channels);
+        if (C < 3) throw Exception("prepare_image: needs an image with at least three channels");
+        DLIMG_ASSERT(stride >= width * C);
+        Upload<uint8_t> src(pixels, (size_t)stride * height);
+        DeviceBuffer<float> dst((size_t)3 * width * height);
+        k::birefnet_prepare_image(src.get(), width, height, stride, C, mean, std, dst.get(), nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+        download(out_nchw, dst.get(), (size_t)3 * width * height);
+    });
+}
+
+DLIMG_API int dlimg_amd_birefnet_process_mask(float const* logits, int width, int height, uint8_t* out_mask) {
+    return guarded([&] {
+        require_gpu();
+        DLIMG_ASSERT(logits && out_mask && width > 0 && height > 0);
+        Upload<float> src(logits, (size_t)width * height);
+        DeviceBuffer<uint8_t> dst((size_t)width * height);
+        k::birefnet_process_mask(src.get(), width, height, dst.get(), nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+        download(out_mask, dst.get(), (size_t)width * height);
+    });
+}
+
+DLIMG_API int dlimg_amd_resize_mask(uint8_t const* mask, int width, int height, int stride, int out_w, int out_h,
+                                    uint8_t* out_mask) {
+    return guarded([&] {
+        require_gpu();
+        DLIMG_ASSERT(mask && out_mask && width > 0 && height > 0 && out_w > 0 && out_h > 0 && stride >= width);
+        AxisTable tx = make_axis_table(width, out_w, ResizeFilter::box), ty = make_axis_table(height, out_h, ResizeFilter::box);
+        float lut[256];
+        for (int i = 0; i < 256; ++i) lut[i] = float(i) / 255.0f;        // STBIR_COLORSPACE_LINEAR decode
+        Upload<uint8_t> src(mask, (size_t)stride * height);
+        Upload<int> xf(tx.first.data(), tx.first.size()), xc(tx.count.data(), tx.count.size());
+        Upload<int> yf(ty.first.data(), ty.first.size()), yc(ty.count.data(), ty.count.size());
+        Upload<float> xk(tx.coef.data(), tx.coef.size()), yk(ty.coef.data(), ty.coef.size()), dlut(lut, 256);
+        DeviceBuffer<float> tmp((size_t)height * out_w);
+        DeviceBuffer<uint8_t> dst((size_t)out_w * out_h);
+        k::ResizeAxis ax{xf.get(), xc.get(), xk.get(), tx.taps, out_w}, ay{yf.get(), yc.get(), yk.get(), ty.taps, out_h};
+        k::resize_srgb(src.get(), width, height, stride, 1, ax, ay, dlut.get(), nullptr, tmp.get(), dst.get(), nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+        download(out_mask, dst.get(), (size_t)out_w * out_h);
+    });
+}
+
 DLIMG_API int dlimg_amd_bench_gemm(int M, int N, int K, int act, int flavour, int iters, double* out_ms) {
     return guarded([&] {
         require_gpu();

@@ -15,6 +15,7 @@ typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef float float2_t __attribute__((ext_vector_type(2)));
+typedef float float3_t __attribute__((ext_vector_type(3)));
 typedef float float4_t __attribute__((ext_vector_type(4)));
 typedef float float16_t __attribute__((ext_vector_type(16)));
 

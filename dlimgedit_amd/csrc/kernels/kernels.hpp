@@ -107,6 +107,11 @@ void mask_logits(const float* up, const float* hyper, float* logits, int P, hipS
 // (256->1024, crop to prepadded ph x pw, -> out_h x out_w), threshold > 0 -> 255/0 into job.dst (device, packed rows).
 // If job.select_iou != nullptr the plane is chosen on device as argmax over planes 1..3 of
 // select_iou[0..3] (SamOnnxModel.select_masks with 2 prompt points) starting from job.src as plane 0.
+// BiRefNet pre/post (kernels/objects.hip): channels 0..2 of an HWC u8 image -> normalised f32 planes; logits -> u8
+void birefnet_prepare_image(const uint8_t* pixels, int w, int h, int stride, int bytes_pp, const float mean[3],
+                            const float std[3], float* out, hipStream_t s);
+void birefnet_process_mask(const float* logits, int w, int h, uint8_t* out, hipStream_t s);
+
 struct PostJob { const float* src; const float* select_iou; uint8_t* dst; int out_w, out_h, pre_w, pre_h; };
 void postprocess_masks(const PostJob* jobs_host, int count, hipStream_t);
 

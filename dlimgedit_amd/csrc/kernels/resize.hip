@@ -3,6 +3,7 @@
 // Two separable passes over host-built contributor tables (csrc/resize_tables.cpp):
 //   horizontal: u8 --sRGB table--> linear float, weighted gather along x into fp32 rows of the output width
 //   vertical  : weighted gather along y, float --Giesen table--> sRGB u8
+// The same two passes with a linear decode table and no encode table are dlimg::resize_mask (image.cpp:53-62).
 // Every multiply and add is explicitly rounded (no fma) and runs in increasing source order, so the
 // result is bit-identical to oracle/stb_resize.py.  Edges clamp.
 #include "device_common.hpp"
@@ -52,12 +53,19 @@ DLIMG_DEVICE uint8_t linear_to_srgb_uchar(float in, const uint32_t* tab4) {
     return (uint8_t)((bias + scale * t) >> 16);
 }
 
+// STBIR_COLORSPACE_LINEAR encode: (int)(saturate(v) * 255 + 0.5)
+DLIMG_DEVICE uint8_t linear_to_uchar(float v) {
+    v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
+    return (uint8_t)(int)__fadd_rn(__fmul_rn(v, 255.0f), 0.5f);
+}
+
+template <bool SRGB>
 __global__ __launch_bounds__(256) void resize_v_kernel(const float* __restrict__ tmp, int h, int ow, int C,
                                                        const int* __restrict__ first, const int* __restrict__ count,
                                                        const float* __restrict__ coef, int taps, int oh,
                                                        const uint32_t* __restrict__ encode, uint8_t* __restrict__ dst) {
     __shared__ uint32_t tab4[104];
-    if (threadIdx.x < 104) tab4[threadIdx.x] = encode[threadIdx.x];
+    if (SRGB && threadIdx.x < 104) tab4[threadIdx.x] = encode[threadIdx.x];
     __syncthreads();
     const long total = (long)oh * ow;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -72,7 +80,7 @@ __global__ __launch_bounds__(256) void resize_v_kernel(const float* __restrict__
             for (int c = 0; c < C; ++c) acc[c] = __fadd_rn(acc[c], __fmul_rn(px[c], wgt));
         }
         uint8_t* out = dst + (size_t)i * C;
-        for (int c = 0; c < C; ++c) out[c] = linear_to_srgb_uchar(acc[c], tab4);
+        for (int c = 0; c < C; ++c) out[c] = SRGB ? linear_to_srgb_uchar(acc[c], tab4) : linear_to_uchar(acc[c]);
     }
 }
 
@@ -88,8 +96,12 @@ void resize_srgb(const uint8_t* src, int w, int h, int stride, int C, const Resi
     auto grid = [](long n) { long g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); };
     hipLaunchKernelGGL(resize_h_kernel, dim3(grid(n1)), dim3(256), 0, s, src, w, h, stride, C, ax.first, ax.count, ax.coef,
                        ax.taps, ax.out, decode_lut, tmp);
-    hipLaunchKernelGGL(resize_v_kernel, dim3(grid(n2)), dim3(256), 0, s, tmp, h, ax.out, C, ay.first, ay.count, ay.coef,
-                       ay.taps, ay.out, encode_tab, dst);
+    if (encode_tab)
+        hipLaunchKernelGGL(resize_v_kernel<true>, dim3(grid(n2)), dim3(256), 0, s, tmp, h, ax.out, C, ay.first, ay.count,
+                           ay.coef, ay.taps, ay.out, encode_tab, dst);
+    else        // linear colour space (resize_mask): decode_lut holds i / 255
+        hipLaunchKernelGGL(resize_v_kernel<false>, dim3(grid(n2)), dim3(256), 0, s, tmp, h, ax.out, C, ay.first, ay.count,
+                           ay.coef, ay.taps, ay.out, encode_tab, dst);
 }
 
 }  // namespace k

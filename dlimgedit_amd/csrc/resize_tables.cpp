@@ -25,14 +25,29 @@ float mitchell(float x) {
     return 0.0f;
 }
 
+// STBIR_FILTER_BOX: the trapezoid that is a box widened by the scale (s <= 1)
+float trapezoid(float x, float s) {
+    const float half = s / 2;
+    const float t = 0.5f + half;
+    x = std::fabs(x);
+    if (x >= t) return 0.0f;
+    const float r = 0.5f - half;
+    if (x <= r) return 1.0f;
+    return (t - x) / s;
+}
+
 }  // namespace
 
-AxisTable make_axis_table(int in_size, int out_size) {
+AxisTable make_axis_table(int in_size, int out_size, ResizeFilter filter) {
     AxisTable t;
     t.in_size = in_size;
     t.out_size = out_size;
     const float scale = float(out_size) / float(in_size);
-    const float support = 2.0f;
+    const bool box = filter == ResizeFilter::box;
+    const float filter_scale = scale > 1 ? 1 / scale : scale;      // the kernel's second argument
+    const float support = box ? 0.5f + filter_scale / 2 : 2.0f;
+    auto up_kernel = [&](float x) { return box ? trapezoid(x, filter_scale) : catmullrom(x); };
+    auto down_kernel = [&](float x) { return box ? trapezoid(x, filter_scale) : mitchell(x); };
     std::vector<std::vector<std::pair<int, float>>> lists(out_size);
 
     if (scale > 1) {  // gather: coefficients of the input pixels under each output pixel, normalised to 1
@@ -46,7 +61,7 @@ AxisTable make_axis_table(int in_size, int out_size) {
             const int last = int(std::floor(hi - 0.5));
             std::vector<float> cs;
             for (int i = 0; i <= last - first; ++i) {
-                const float c = catmullrom(in_center - (float(i + first) + 0.5f));
+                const float c = up_kernel(in_center - (float(i + first) + 0.5f));
                 if (i == 0 && c == 0) {      // a leading zero drops the pixel
                     ++first;
                     --i;
@@ -75,7 +90,7 @@ AxisTable make_axis_table(int in_size, int out_size) {
             s.j = j;
             s.first = int(std::floor(lo + 0.5));
             const int last = int(std::floor(hi - 0.5));
-            for (int i = s.first; i <= last; ++i) s.cs.push_back(mitchell((float(i) + 0.5f) - out_center) * scale);
+            for (int i = s.first; i <= last; ++i) s.cs.push_back(down_kernel((float(i) + 0.5f) - out_center) * scale);
             scat.push_back(std::move(s));
         }
         std::vector<float> totals(out_size, 0.0f);

@@ -15,7 +15,10 @@ struct AxisTable {
     std::vector<float> coef;     // [out][taps], zero padded
 };
 
-AxisTable make_axis_table(int in_size, int out_size);
+// default_: STBIR_FILTER_DEFAULT (Catmull-Rom when the axis grows, Mitchell otherwise); box: STBIR_FILTER_BOX
+enum class ResizeFilter { default_, box };
+
+AxisTable make_axis_table(int in_size, int out_size, ResizeFilter filter = ResizeFilter::default_);
 
 // stbir__srgb_uchar_to_linear_float (256 entries) and fp32_to_srgb8_tab4 (104 entries)
 void srgb_decode_table(float out[256]);

@@ -95,6 +95,19 @@ DLIMG_API int dlimg_amd_test_attention(int global, uint16_t const* qkv, float co
  * pixels [height][stride] -> out_pixels [out_h][out_w * bytes_per_pixel] packed. */
 DLIMG_API int dlimg_amd_test_resize(uint8_t const* pixels, int width, int height, int stride, int channels, int out_w,
                                     int out_h, uint8_t* out_pixels);
+/* Pre- and post-processing of dlimg_segment_objects (BiRefNet), the parts the reference library computes itself;
+ * the network is an ONNX graph there and is not part of this build.  Host buffers in and out.
+ *   prepare_image  replaces BiRefNet::prepare_image   (/root/reference/src/segmentation.cpp:244-256):
+ *                  channels 0..2 of an HWC u8 image -> out_nchw [3][height][width] f32 = (x / 255 - mean) / std
+ *   process_mask   replaces BiRefNet::process_mask    (/root/reference/src/segmentation.cpp:258-270):
+ *                  logits [height][width] f32 -> u8 = uint8_t(sigmoid(x) * 255.f)
+ *   resize_mask    replaces dlimg::resize_mask        (/root/reference/src/image.cpp:53-62):
+ *                  stb_image_resize, 1 channel, box filter, linear colour space, clamped edges */
+DLIMG_API int dlimg_amd_birefnet_prepare_image(uint8_t const* pixels, int width, int height, int stride, int channels,
+                                               float const* mean, float const* std, float* out_nchw);
+DLIMG_API int dlimg_amd_birefnet_process_mask(float const* logits, int width, int height, uint8_t* out_mask);
+DLIMG_API int dlimg_amd_resize_mask(uint8_t const* mask, int width, int height, int stride, int out_w, int out_h,
+                                    uint8_t* out_mask);
 /* Times `iters` launches of the GEMM on device-resident random operands; returns average ms per launch.
  * flavour 0: f16 output; 1: LayerNorm folded in; 2: bias + fp32 residual in place; 3: 2 + f16 copy of the result + row statistics;
  * 4: f16 output with bias. */

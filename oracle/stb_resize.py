@@ -99,13 +99,32 @@ def _mitchell(x: f32) -> f32:
     return f32(0)
 
 
-def axis_contributors(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+def _trapezoid(x: f32, s: f32) -> f32:
+    """STBIR_FILTER_BOX: stbir__filter_trapezoid(x, s), s <= 1."""
+    half = f32(s / f32(2))
+    t = f32(f32(0.5) + half)
+    x = f32(abs(x))
+    if x >= t:
+        return f32(0)
+    r = f32(f32(0.5) - half)
+    if x <= r:
+        return f32(1)
+    return f32(f32(t - x) / s)
+
+
+def axis_contributors(in_size: int, out_size: int, box: bool = False) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """Gather-form contributor table of one axis: (first[out], count[out], coef[out, max_taps]).
-    Source indices first..first+count-1 may fall outside [0, in_size): they clamp to the edge."""
+    Source indices first..first+count-1 may fall outside [0, in_size): they clamp to the edge.
+    box=False: STBIR_FILTER_DEFAULT (Catmull-Rom up, Mitchell down, support 2); box=True: STBIR_FILTER_BOX
+    (trapezoid, support 0.5 + s/2 with s = 1/scale when upsampling and scale when downsampling)."""
     scale = f32(out_size) / f32(in_size)
-    support = f32(2)
+    up = scale > 1                                  # stbir__use_upsampling
+    filter_scale = f32(f32(1) / scale) if up else scale
+    support = f32(f32(0.5) + f32(filter_scale / f32(2))) if box else f32(2)
+    up_kernel = (lambda x: _trapezoid(x, filter_scale)) if box else _catmullrom
+    down_kernel = (lambda x: _trapezoid(x, filter_scale)) if box else _mitchell
     lists: List[List[Tuple[int, f32]]] = [[] for _ in range(out_size)]
-    if scale > 1:                                   # stbir__use_upsampling
+    if up:
         radius = support * scale                    # out_filter_radius
         for n in range(out_size):
             center = f32(n) + f32(0.5)
@@ -117,7 +136,7 @@ def axis_contributors(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarr
             coefs = []
             i = 0
             while i <= last - first:
-                c = _catmullrom(in_center - (f32(i + first) + f32(0.5)))
+                c = up_kernel(in_center - (f32(i + first) + f32(0.5)))
                 if i == 0 and c == 0:               # leading zero: drop the pixel
                     first += 1
                     continue
@@ -143,7 +162,7 @@ def axis_contributors(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarr
             out_center = center * scale
             first = int(math.floor(float(lo) + 0.5))
             last = int(math.floor(float(hi) - 0.5))
-            cs = [f32(_mitchell((f32(i) + f32(0.5)) - out_center) * scale) for i in range(first, last + 1)]
+            cs = [f32(down_kernel((f32(i) + f32(0.5)) - out_center) * scale) for i in range(first, last + 1)]
             scat.append((j, first, cs))
         totals = [f32(0)] * out_size
         for j, first, cs in scat:                   # per-output normalisation, summed in input order
@@ -202,3 +221,19 @@ def resize_srgb(pixels: np.ndarray, out_w: int, out_h: int) -> np.ndarray:
     full = _apply_axis(rows, vf, vc, vk, axis=0)
     out = linear_to_srgb_uchar(full)
     return out[:, :, 0] if squeeze else out
+
+
+def resize_mask(mask: np.ndarray, out_w: int, out_h: int) -> np.ndarray:
+    """u8 [H,W] -> u8 [out_h,out_w]: stbir_resize_uint8_generic(1 channel, EDGE_CLAMP, FILTER_BOX, COLORSPACE_LINEAR),
+    the call of dlimg::resize_mask (/root/reference/src/image.cpp:53-62).  Linear colour space: decode x / 255,
+    encode (int)(saturate(v) * 255 + 0.5).  The reference holds no known-answer test for this call: parity unpinned
+    beyond the contributor machinery shared with resize_srgb (which its KAT pins)."""
+    mask = np.asarray(mask, dtype=np.uint8)
+    h, w = mask.shape
+    lin = (mask.astype(f32) / f32(255)).astype(f32)
+    hf, hc, hk = axis_contributors(w, out_w, box=True)
+    vf, vc, vk = axis_contributors(h, out_h, box=True)
+    rows = _apply_axis(lin, hf, hc, hk, axis=1)
+    full = _apply_axis(rows, vf, vc, vk, axis=0)
+    sat = np.clip(full, f32(0), f32(1)).astype(f32)
+    return (sat * f32(255) + f32(0.5)).astype(f32).astype(np.int32).astype(np.uint8)

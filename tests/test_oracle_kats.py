@@ -127,3 +127,52 @@ def test_resize_contributors_sum_to_one():
         first, count, coef = R.axis_contributors(n_in, n_out)
         assert np.allclose(coef.sum(axis=1), 1.0, atol=1e-5)
         assert count.min() >= 1 and first.min() >= -8 and (first + count).max() <= n_in + 8
+
+
+# ------------------------------------------------------------- BiRefNet pre/post
+
+def test_birefnet_prepare_image_kat():
+    """/root/reference/test/test_segmentation.cpp:152-167 (BiRefNet.prepare_image): 4x3 RGBA image of 0..47."""
+    from oracle import birefnet_oracle as B
+    img = np.arange(4 * 3 * 4, dtype=np.uint8).reshape(3, 4, 4)
+    t = B.prepare_image(img, mean=(0.4, 0.5, 0.6), std=(0.1, 0.2, 0.5))
+    approx = lambda v: pytest.approx(v, rel=1e-5)       # Catch's Approx default
+    assert t.shape == (1, 3, 3, 4) and t.dtype == np.float32
+    assert t[0, 0, 0, 0] == approx(-4.0)
+    assert t[0, 0, 0, 1] == approx((4.0 / 255.0 - 0.4) / 0.1)
+    assert t[0, 0, 0, 2] == approx((8.0 / 255.0 - 0.4) / 0.1)
+    assert t[0, 0, 1, 0] == approx((16.0 / 255.0 - 0.4) / 0.1)
+    assert t[0, 0, 1, 1] == approx((20.0 / 255.0 - 0.4) / 0.1)
+    assert t[0, 1, 1, 1] == approx((21.0 / 255.0 - 0.5) / 0.2)
+    assert t[0, 2, 1, 1] == approx((22.0 / 255.0 - 0.6) / 0.5)
+
+
+def test_birefnet_process_mask_kat():
+    """/root/reference/test/test_segmentation.cpp:169-180 (BiRefNet.process_mask): expected values are the
+    reference's own formula uint8_t(sigmoid(x) * 255) evaluated in float."""
+    import math
+    from oracle import birefnet_oracle as B
+    values = np.array([0.0, 0.0, 0.2, -3.1, 0.0, 5.5, 0.0, 0.7, 0.0, 0.9], np.float32).reshape(2, 5)
+    mask = B.process_mask(values)
+
+    def expect(x):
+        s = np.float32(1.0) / (np.float32(1.0) + np.float32(math.exp(-float(np.float32(x)))))
+        return int(np.float32(s) * np.float32(255))
+    assert mask.dtype == np.uint8 and mask.shape == (2, 5)
+    assert mask[0, 0] == expect(0) == 127 and mask[0, 1] == expect(0)
+    assert mask[0, 2] == expect(0.2) and mask[0, 3] == expect(-3.1)
+    assert mask[1, 0] == expect(5.5) and mask[1, 2] == expect(0.7)
+
+
+def test_resize_mask_box_filter_properties():
+    """No upstream vector exists for resize_mask; these are the properties the published box (trapezoid) filter has:
+    identity at scale 1, exact 2x2 means at 1/2, pixel replication at 2x, constant images stay constant."""
+    from oracle import stb_resize as S
+    rng = np.random.default_rng(0)
+    m = rng.integers(0, 256, (16, 24), dtype=np.uint8)
+    assert np.array_equal(S.resize_mask(m, 24, 16), m)
+    half = S.resize_mask(m, 12, 8)
+    mean = m.reshape(8, 2, 12, 2).astype(np.float64).mean(axis=(1, 3))
+    assert np.abs(half.astype(np.float64) - mean).max() <= 0.5 + 1e-6
+    assert np.array_equal(S.resize_mask(m, 48, 32), np.repeat(np.repeat(m, 2, axis=0), 2, axis=1))
+    assert np.all(S.resize_mask(np.full((7, 5), 200, np.uint8), 13, 3) == 200)
