@@ -62,19 +62,19 @@ template <int BKT> DLIMG_DEVICE half8_t read_frag(const char* lds, int row, int 
     return *reinterpret_cast<const half8_t*>(lds + row * (BKT * 2) + ((chunk ^ swz<BKT>(row)) << 4));
 }
 
-// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7):
-// a third of the instructions of erff(), which matters because fc1's epilogue is as long as its
-// K loop at batch 1.
+// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7): a third of the
+// instructions of erff(), which matters because fc1's epilogue is VALU-bound (12.6 M outputs on the CUs the tiles
+// occupy).  With E = exp(-x^2/2), p = t (a1 + t (a2 + ...)), t = 1 / (1 + 0.3275911 |x| / sqrt 2):
+//   erf(|x|/sqrt 2) = 1 - p E   =>   GELU(x) = max(x, 0) - 0.5 |x| p E     (both signs; no copysign needed)
 DLIMG_DEVICE float gelu_fast(float x) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));   // 1 ulp: the IEEE division is ten instructions
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.0f));   // 1 ulp is plenty
     float p = fmaf(1.061405429f, t, -1.453152027f);
     p = fmaf(p, t, 1.421413741f);
     p = fmaf(p, t, -0.284496736f);
     p = fmaf(p, t, 0.254829592f);
-    p *= t;
-    const float e = 1.0f - p * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
-    return 0.5f * x * (1.0f + copysignf(e, x));
+    const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.4426950408889634f));
+    return fmaf(-0.5f * ax * (p * t), e, fmaxf(x, 0.0f));
 }
 
 // Epilogue flavours: compile-time, so the plain GEMM does not carry the registers of the others
