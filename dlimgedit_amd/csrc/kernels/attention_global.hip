@@ -163,9 +163,12 @@ __global__ __launch_bounds__(256, 2) void attention_global_kernel(const half_t* 
         for (int idx = tid; idx < 2 * V_TILE / 2; idx += 256) reinterpret_cast<uint32_t*>(lds_v)[idx] = 0u;
         __syncthreads();
     }
+    // head dimension 80 has no registers to spare for the second staging set (it spilled): one set, requested at the
+    // top of the iteration before the one that needs it
+    constexpr bool TWO_SETS = HD <= 64;
     load_tile(0, kregA, vregA);
     write_tile(0, kregA, vregA);
-    load_tile(1, kregB, vregB);
+    if (TWO_SETS) load_tile(1, kregB, vregB);
     __syncthreads();
 
     // transposed-read addressing (cdna_hip_programming.md T10): in each 16-lane group, lane 4q+p points
@@ -248,7 +251,13 @@ __global__ __launch_bounds__(256, 2) void attention_global_kernel(const half_t* 
         }
 
     };
-    for (int t = 0; t < NT; t += 2) {
+    for (int t = 0; !TWO_SETS && t < NT; ++t) {
+        if (t + 1 < NT && ABL != 1) load_tile(t + 1, kregA, vregA);
+        process_tile(t, t & 1);
+        if (t + 1 < NT && ABL != 1) write_tile((t + 1) & 1, kregA, vregA);
+        __syncthreads();
+    }
+    for (int t = 0; TWO_SETS && t < NT; t += 2) {
         if (t + 2 < NT && ABL != 1) load_tile(t + 2, kregA, vregA);
         process_tile(t, 0);
         if (ABL != 1) write_tile(1, kregB, vregB);      // tile t+1, requested one iteration ago
