@@ -282,3 +282,26 @@ def test_invalid_arguments_are_errors_not_crashes(api, session):
     assert api.api().get_segmentation_mask(seg._handle, pt, None, masks, acc) == 1     # null output buffer
     assert b"Assertion failed" in api.api().last_error()
     assert api.api().get_segmentation_mask(seg._handle, None, None, masks, acc) == 1    # neither point nor region
+
+
+def test_full_size_vit_b_against_committed_golden(api, model_dirs, monkeypatch):
+    """The real model size through the drop-in ABI against the committed fixtures (tests/golden/sam_vit_b.npz: samples of
+    Hugging Face SamModel's embedding / low-res logits and its 1024x1024 masks on the same seeded weights and image).
+    No oracle in the loop."""
+    from pathlib import Path
+    g = np.load(Path(__file__).resolve().parent / "golden" / "sam_vit_b.npz")
+    mdir, _, _ = model_dirs("vit_b", int(g["seed"]))
+    monkeypatch.setenv("DLIMGEDIT_SAM_MODEL", "vit_b")
+    env = api.Environment(api.Options(api.Backend.gpu, mdir))
+    img = synthetic_image(int(g["image_seed"]))
+    seg = api.Segmentation.process(api.ImageView(img, api.Channels.rgba), env)
+    emb = api.ext.get_embedding(seg).reshape(-1)[::257]
+    assert np.abs(emb - g["emb_samples"]).max() < EMB_TOL
+    for name, kw, call in (("point", dict(point=api.Point(512, 512)), lambda: seg.compute_mask(api.Point(512, 512))),
+                           ("box", dict(region=api.Region(api.Point(256, 256), api.Point(768, 768))),
+                            lambda: seg.compute_mask(api.Region(api.Point(256, 256), api.Point(768, 768))))):
+        low, iou_pred = api.ext.get_logits(seg, **kw)
+        assert np.abs(low.reshape(4, -1)[:, ::61] - g[f"{name}_low_samples"]).max() < LOGIT_TOL
+        assert np.abs(iou_pred - g[f"{name}_iou"]).max() < 0.02
+        want = np.unpackbits(g[f"{name}_mask_bits"]).reshape(1024, 1024) * 255
+        assert iou(call(), want) >= IOU_BAR
