@@ -284,14 +284,15 @@ def test_invalid_arguments_are_errors_not_crashes(api, session):
     assert api.api().get_segmentation_mask(seg._handle, None, None, masks, acc) == 1    # neither point nor region
 
 
-def test_full_size_vit_b_against_committed_golden(api, model_dirs, monkeypatch):
-    """The real model size through the drop-in ABI against the committed fixtures (tests/golden/sam_vit_b.npz: samples of
-    Hugging Face SamModel's embedding / low-res logits and its 1024x1024 masks on the same seeded weights and image).
-    No oracle in the loop."""
+@pytest.mark.parametrize("variant", ["vit_b", "vit_h"])
+def test_full_size_models_against_committed_golden(api, model_dirs, monkeypatch, variant):
+    """The real model sizes through the drop-in ABI against the committed fixtures (tests/golden/sam_<variant>.npz:
+    samples of Hugging Face SamModel's embedding / low-res logits and its 1024x1024 masks on the same seeded weights
+    and image).  No oracle in the loop."""
     from pathlib import Path
-    g = np.load(Path(__file__).resolve().parent / "golden" / "sam_vit_b.npz")
-    mdir, _, _ = model_dirs("vit_b", int(g["seed"]))
-    monkeypatch.setenv("DLIMGEDIT_SAM_MODEL", "vit_b")
+    g = np.load(Path(__file__).resolve().parent / "golden" / f"sam_{variant}.npz")
+    mdir, _, _ = model_dirs(variant, int(g["seed"]))
+    monkeypatch.setenv("DLIMGEDIT_SAM_MODEL", variant)
     env = api.Environment(api.Options(api.Backend.gpu, mdir))
     img = synthetic_image(int(g["image_seed"]))
     seg = api.Segmentation.process(api.ImageView(img, api.Channels.rgba), env)
