@@ -124,76 +124,96 @@ __global__ __launch_bounds__(256) void token_self_attention_kernel(const float* 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Tokens attend to the 4096 image positions (8 heads x 16).  One workgroup per (prompt, head);
-// every thread streams 16 keys for all 7 queries with an online softmax, then the 256 partial
-// (max, sum, output) triples are merged: butterfly inside each wave, LDS across the 4 waves.
-__global__ __launch_bounds__(256) void token_to_image_kernel(const float* __restrict__ q, const half_t* __restrict__ K,
-                                                             int ldk, const half_t* __restrict__ V, int ldv,
-                                                             float* __restrict__ out) {
+// Tokens attend to the 4096 image positions (8 heads x 16), in two steps so that the 4096 keys of a head are spread
+// over 8 workgroups (one workgroup per head streams 0.5 MB through a single CU and takes 44 us):
+//   partial: workgroup = (prompt, head, key group of 512); a thread takes 2 keys (requested up front), then query
+//            by query scores them, does the softmax against the wave's maximum (one exponential per score, no
+//            rescale) and its part of P.V; butterfly inside each wave -> per-wave (max, sum, output[16]) in `part`
+//   merge  : thread = (prompt, query, head, dim) folds the 8 x 4 wave partials in a fixed order
+constexpr int T2I_GROUPS = 8;                                  // key groups per head
+constexpr int T2I_THREADS = 256;
+constexpr int T2I_KEYS = NTOK_IMG / T2I_GROUPS / T2I_THREADS;  // keys per thread
+constexpr int T2I_WAVES = T2I_THREADS / 64;
+constexpr int T2I_PARTS = T2I_GROUPS * T2I_WAVES;              // partial triples per (prompt, head, query)
+
+__global__ __launch_bounds__(T2I_THREADS) void token_to_image_partial_kernel(const float* __restrict__ q,
+                                                                             const half_t* __restrict__ K, int ldk,
+                                                                             const half_t* __restrict__ V, int ldv,
+                                                                             float* __restrict__ part) {
     __shared__ float sq[TOK * 16];
-    __shared__ float part[4][TOK][18];
-    const int p = blockIdx.x / HEADS, h = blockIdx.x % HEADS;
+    const int grp = blockIdx.x % T2I_GROUPS, h = (blockIdx.x / T2I_GROUPS) % HEADS, p = blockIdx.x / (T2I_GROUPS * HEADS);
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     if (tid < TOK * 16) sq[tid] = q[((size_t)p * TOK + tid / 16) * INNER + h * 16 + (tid & 15)] * 0.25f;   // 16^-0.5
-    __syncthreads();
-    float m[TOK], l[TOK], o[TOK][16];
+    const size_t key0 = (size_t)p * NTOK_IMG + (size_t)grp * (NTOK_IMG / T2I_GROUPS);
+    const half_t* kb = K + key0 * ldk + h * 16;
+    const half_t* vb = V + key0 * ldv + h * 16;
+    half8_t kreg[T2I_KEYS][2], vreg[T2I_KEYS][2];
 #pragma unroll
-    for (int t = 0; t < TOK; ++t) {
-        m[t] = -INFINITY;
-        l[t] = 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
+    for (int i = 0; i < T2I_KEYS; ++i) {
+        const size_t j = (size_t)i * T2I_THREADS + tid;
+        kreg[i][0] = *reinterpret_cast<const half8_t*>(kb + j * ldk);
+        kreg[i][1] = *reinterpret_cast<const half8_t*>(kb + j * ldk + 8);
+        vreg[i][0] = *reinterpret_cast<const half8_t*>(vb + j * ldv);
+        vreg[i][1] = *reinterpret_cast<const half8_t*>(vb + j * ldv + 8);
     }
-    const half_t* kb = K + (size_t)p * NTOK_IMG * ldk + h * 16;
-    const half_t* vb = V + (size_t)p * NTOK_IMG * ldv + h * 16;
-    for (int j = tid; j < NTOK_IMG; j += 256) {
-        const half8_t k0 = *reinterpret_cast<const half8_t*>(kb + (size_t)j * ldk);
-        const half8_t k1 = *reinterpret_cast<const half8_t*>(kb + (size_t)j * ldk + 8);
-        const half8_t v0 = *reinterpret_cast<const half8_t*>(vb + (size_t)j * ldv);
-        const half8_t v1 = *reinterpret_cast<const half8_t*>(vb + (size_t)j * ldv + 8);
-        float kf[16], vf[16];
+    __syncthreads();
+    float* dst = part + ((((size_t)p * HEADS + h) * TOK) * T2I_PARTS + grp * T2I_WAVES + wave) * 18;
+#pragma unroll 1
+    for (int t = 0; t < TOK; ++t) {
+        // keep K / V as the f16 they arrived in: otherwise the conversions to float are hoisted out of the query loop
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { kf[e] = (float)k0[e]; kf[8 + e] = (float)k1[e]; vf[e] = (float)v0[e]; vf[8 + e] = (float)v1[e]; }
+        for (int i = 0; i < T2I_KEYS; ++i)
+            asm volatile("" : "+v"(kreg[i][0]), "+v"(kreg[i][1]), "+v"(vreg[i][0]), "+v"(vreg[i][1]));
+        float sc[T2I_KEYS];
 #pragma unroll
-        for (int t = 0; t < TOK; ++t) {
+        for (int i = 0; i < T2I_KEYS; ++i) {
             float s = 0.f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) s = fmaf(sq[t * 16 + e], kf[e], s);
-            const float mn = fmaxf(m[t], s);
-            const float a = __expf(m[t] - mn), pj = __expf(s - mn);
-            l[t] = l[t] * a + pj;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[t][e] = fmaf(pj, vf[e], o[t][e] * a);
-            m[t] = mn;
+            for (int e = 0; e < 16; ++e) s = fmaf(sq[t * 16 + e], (float)kreg[i][e >> 3][e & 7], s);
+            sc[i] = s;
         }
-    }
+        float m = sc[0];
 #pragma unroll
-    for (int t = 0; t < TOK; ++t) {
-        const float M = wave_max(m[t]);
-        const float w = __expf(m[t] - M);
-        const float ls = wave_sum(l[t] * w);
-        if (lane == 0) { part[wave][t][0] = M; part[wave][t][1] = ls; }
+        for (int i = 1; i < T2I_KEYS; ++i) m = fmaxf(m, sc[i]);
+        const float M = wave_max(m);
+        float l = 0.f, o[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] = 0.f;
+#pragma unroll
+        for (int i = 0; i < T2I_KEYS; ++i) {
+            const float pj = __expf(sc[i] - M);
+            l += pj;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[e] = fmaf(pj, (float)vreg[i][e >> 3][e & 7], o[e]);
+        }
+        const float ls = wave_sum(l);
+        float* d = dst + (size_t)t * T2I_PARTS * 18;
+        if (lane == 0) { d[0] = M; d[1] = ls; }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const float x = wave_sum(o[t][e] * w);
-            if (lane == 0) part[wave][t][2 + e] = x;
+            const float x = wave_sum(o[e]);
+            if (lane == 0) d[2 + e] = x;
         }
     }
-    __syncthreads();
-    if (tid < TOK * 16) {
-        const int t = tid / 16, e = tid & 15;
-        float M = part[0][t][0];
+}
+
+__global__ __launch_bounds__(256) void token_to_image_merge_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                                   int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;          // ((p * TOK + t) * HEADS + h) * 16 + e
+    if (idx >= total) return;
+    const int e = idx & 15, h = (idx >> 4) % HEADS, t = (idx / (16 * HEADS)) % TOK, p = idx / (16 * HEADS * TOK);
+    const float* src = part + ((((size_t)p * HEADS + h) * TOK + t) * T2I_PARTS) * 18;
+    float M = src[0];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) M = fmaxf(M, part[w][t][0]);
-        float ls = 0.f, os = 0.f;
+    for (int w = 1; w < T2I_PARTS; ++w) M = fmaxf(M, src[w * 18]);
+    float ls = 0.f, os = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const float f = __expf(part[w][t][0] - M);
-            ls += part[w][t][1] * f;
-            os += part[w][t][2 + e] * f;
-        }
-        out[((size_t)p * TOK + t) * INNER + h * 16 + e] = os / ls;
+    for (int w = 0; w < T2I_PARTS; ++w) {
+        const float f = __expf(src[w * 18] - M);
+        ls += src[w * 18 + 1] * f;
+        os += src[w * 18 + 2 + e] * f;
     }
+    out[((size_t)p * TOK + t) * INNER + h * 16 + e] = os / ls;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -332,13 +352,18 @@ void token_self_attention(const float* q, const float* kx, const float* v, float
     hipLaunchKernelGGL(token_self_attention_kernel, dim3(P), dim3(256), 0, s, q, kx, v, out);
 }
 
-void token_to_image_attention(const float* q, const half_t* K, int ldk, const half_t* V, int ldv, float* out, int P,
-                              hipStream_t s) {
+void token_to_image_attention(const float* q, const half_t* K, int ldk, const half_t* V, int ldv, float* scratch,
+                              float* out, int P, hipStream_t s) {
     if (P <= 0) return;
     if (ldk % 8 || ldv % 8 || (((uintptr_t)K | (uintptr_t)V) & 15))
         throw_error("token_to_image_attention: K/V rows must be 16-byte aligned");
-    hipLaunchKernelGGL(token_to_image_kernel, dim3(P * HEADS), dim3(256), 0, s, q, K, ldk, V, ldv, out);
+    hipLaunchKernelGGL(token_to_image_partial_kernel, dim3(P * HEADS * T2I_GROUPS), dim3(T2I_THREADS), 0, s, q, K, ldk, V,
+                       ldv, scratch);
+    const int total = P * TOK * INNER;
+    hipLaunchKernelGGL(token_to_image_merge_kernel, dim3((total + 255) / 256), dim3(256), 0, s, scratch, out, total);
 }
+
+size_t token_to_image_scratch_floats(int P) { return (size_t)P * HEADS * TOK * T2I_PARTS * 18; }
 
 void image_to_token_attention(const half_t* q, int ldq, const float* kt, const float* vt, half_t* out, int P,
                               hipStream_t s) {

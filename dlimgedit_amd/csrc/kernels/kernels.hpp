@@ -89,8 +89,10 @@ void token_linear(const float* X, const float* X2, const float* W, const float* 
 // multi-head attention among the 7 tokens of each prompt: q,k,v [P,7,256] -> out [P,7,256] (8 heads)
 void token_self_attention(const float* q, const float* k, const float* v, float* out, int P, hipStream_t);
 // tokens attend to the image: q [P,7,128] f32, K,V [P,4096,ld] f16 (column offsets given) -> out [P,7,128]
-void token_to_image_attention(const float* q, const half_t* K, int ldk, const half_t* V, int ldv, float* out,
-                              int P, hipStream_t);
+// scratch: token_to_image_scratch_floats(P) floats of workspace for the per-key-group partial results
+void token_to_image_attention(const float* q, const half_t* K, int ldk, const half_t* V, int ldv, float* scratch,
+                              float* out, int P, hipStream_t s);
+size_t token_to_image_scratch_floats(int P);
 // image attends to tokens: q [P,4096,ldq] f16, k,v [P,7,128] f32 -> out [P,4096,128] f16
 void image_to_token_attention(const half_t* q, int ldq, const float* k, const float* v, half_t* out, int P,
                               hipStream_t);

@@ -549,6 +549,7 @@ void SamModel::reserve_decoder(int count) {
     tk_.reserve(T * 256);
     tv_.reserve(T * 256);
     tatt_.reserve(T * 256);
+    t2i_part_.reserve(k::token_to_image_scratch_floats((int)P));
     tmlp_.reserve(T * 2048);
     prompt_pinned_.reserve(kPromptRing * P * 6 * sizeof(float));
     dec_count_ = count;
@@ -598,7 +599,7 @@ void SamModel::decode(float const* const* emb, float const* coords, float const*
         // tokens attend to the image: K = kq_h[:, :128] (or final K), V = v_h
         auto token_to_image = [&](LinearF const& wq, LinearF const& wo, half_t const* K, int ldk) {
             lin(q, qpe, wq, nullptr, tq_.get(), 0);
-            k::token_to_image_attention(tq_.get(), K, ldk, v_h_.get(), 128, tatt_.get(), P, s);
+            k::token_to_image_attention(tq_.get(), K, ldk, v_h_.get(), 128, t2i_part_.get(), tatt_.get(), P, s);
             lin(tatt_.get(), nullptr, wo, q, q, 0);
         };
 
