@@ -266,38 +266,49 @@ __global__ __launch_bounds__(256) void image_to_token_kernel(const half_t* __res
 
 // ---------------------------------------------------------------------------------------------
 // Hyper-network MLPs + IoU head.  grid (P, 5): y = 0..3 mask token MLPs (-> 32), y = 4 IoU head (-> 4).
-// One thread per output neuron, weight rows read with 16-byte loads, activations broadcast from LDS.
-DLIMG_DEVICE float neuron(const float* x /*LDS*/, const float* __restrict__ wrow, float bias) {
-    const float4_t* w4 = reinterpret_cast<const float4_t*>(wrow);
-    const float4_t* x4 = reinterpret_cast<const float4_t*>(x);
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll 8
-    for (int k4 = 0; k4 < DIM / 4; ++k4) {
-        const float4_t w = w4[k4], v = x4[k4];
-        a0 = fmaf(v[0], w[0], a0);
-        a1 = fmaf(v[1], w[1], a1);
-        a2 = fmaf(v[2], w[2], a2);
-        a3 = fmaf(v[3], w[3], a3);
+// One wave per output neuron at a time: the 64 lanes read one 1-KB weight row with a single 16-byte load each
+// (a thread per neuron reads 64 rows per instruction, one line each), multiply with the activations in LDS and fold
+// with the DPP wave sum; 16 waves share the 256 neurons of a layer.
+constexpr int HEAD_THREADS = 1024;
+static_assert(DIM == 64 * 4, "one float4 of the weight row per lane");
+
+template <int N_OUT>
+DLIMG_DEVICE void head_layer(const float* x /*LDS*/, const float* __restrict__ w, const float* __restrict__ b, int n_out,
+                             bool relu, float* y) {
+    constexpr int WAVES = HEAD_THREADS / 64, ROWS = (N_OUT + WAVES - 1) / WAVES;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const float4_t v = reinterpret_cast<const float4_t*>(x)[lane];
+    float4_t wr[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {             // every row of this wave is requested before the first is used
+        const int n = wave + r * WAVES;
+        wr[r] = float4_t{0.f, 0.f, 0.f, 0.f};
+        if (n < n_out) wr[r] = reinterpret_cast<const float4_t*>(w + (size_t)n * DIM)[lane];
     }
-    return (a0 + a1) + (a2 + a3) + bias;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int n = wave + r * WAVES;
+        const float acc = wave_sum((v[0] * wr[r][0] + v[1] * wr[r][1]) + (v[2] * wr[r][2] + v[3] * wr[r][3]));
+        if (lane == 0 && n < n_out) {
+            const float out = acc + b[n];
+            y[n] = relu ? fmaxf(out, 0.f) : out;
+        }
+    }
 }
 
-__global__ __launch_bounds__(256) void output_heads_kernel(const float* __restrict__ queries, k::HeadWeights hw,
-                                                           float* __restrict__ hyper, float* __restrict__ iou) {
+__global__ __launch_bounds__(HEAD_THREADS) void output_heads_kernel(const float* __restrict__ queries, k::HeadWeights hw,
+                                                                    float* __restrict__ hyper, float* __restrict__ iou) {
     __shared__ __attribute__((aligned(16))) float x0[DIM], x1[DIM], x2[DIM];
-    const int p = blockIdx.x, mi = blockIdx.y, n = threadIdx.x;
+    const int p = blockIdx.x, mi = blockIdx.y;
     const int tok = mi < 4 ? 1 + mi : 0;
-    x0[n] = queries[((size_t)p * TOK + tok) * DIM + n];
+    if (threadIdx.x < DIM) x0[threadIdx.x] = queries[((size_t)p * TOK + tok) * DIM + threadIdx.x];
     __syncthreads();
-    x1[n] = fmaxf(neuron(x0, hw.w[mi][0] + (size_t)n * DIM, hw.b[mi][0][n]), 0.f);
+    head_layer<DIM>(x0, hw.w[mi][0], hw.b[mi][0], DIM, true, x1);
     __syncthreads();
-    x2[n] = fmaxf(neuron(x1, hw.w[mi][1] + (size_t)n * DIM, hw.b[mi][1][n]), 0.f);
+    head_layer<DIM>(x1, hw.w[mi][1], hw.b[mi][1], DIM, true, x2);
     __syncthreads();
-    const int nout = mi < 4 ? 32 : 4;
-    if (n < nout) {
-        float* dst = mi < 4 ? hyper + ((size_t)p * 4 + mi) * 32 : iou + (size_t)p * 4;
-        dst[n] = neuron(x2, hw.w[mi][2] + (size_t)n * DIM, hw.b[mi][2][n]);
-    }
+    float* dst = mi < 4 ? hyper + ((size_t)p * 4 + mi) * 32 : iou + (size_t)p * 4;
+    head_layer<32>(x2, hw.w[mi][2], hw.b[mi][2], mi < 4 ? 32 : 4, false, dst);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -375,7 +386,7 @@ void image_to_token_attention(const half_t* q, int ldq, const float* kt, const f
 
 void output_heads(const float* queries, const HeadWeights& hw, float* hyper, float* iou, int P, hipStream_t s) {
     if (P <= 0) return;
-    hipLaunchKernelGGL(output_heads_kernel, dim3(P, 5), dim3(256), 0, s, queries, hw, hyper, iou);
+    hipLaunchKernelGGL(output_heads_kernel, dim3(P, 5), dim3(HEAD_THREADS), 0, s, queries, hw, hyper, iou);
 }
 
 void mask_logits(const float* up, const float* hyper, float* logits, int P, hipStream_t s) {
