@@ -25,12 +25,13 @@ __global__ __launch_bounds__(256) void prompt_tokens_kernel(const float* __restr
                                                             const float* __restrict__ not_a_point,
                                                             const float* __restrict__ iou_token,
                                                             const float* __restrict__ mask_tokens,
-                                                            float* __restrict__ tokens) {
+                                                            float* __restrict__ tokens, float* __restrict__ tokens_copy) {
     const int p = blockIdx.x, c = threadIdx.x;
     float* t = tokens + (size_t)p * TOK * DIM;
-    t[c] = iou_token[c];
+    float* t2 = tokens_copy + (size_t)p * TOK * DIM;      // the decoder's running queries start as a copy
+    t[c] = t2[c] = iou_token[c];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) t[(1 + m) * DIM + c] = mask_tokens[m * DIM + c];
+    for (int m = 0; m < 4; ++m) t[(1 + m) * DIM + c] = t2[(1 + m) * DIM + c] = mask_tokens[m * DIM + c];
     const int kf = c & 127;
     for (int i = 0; i < 2; ++i) {
         const float x = (coords[(p * 2 + i) * 2 + 0] + 0.5f) / 1024.0f;
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256) void prompt_tokens_kernel(const float* __restr
 #pragma unroll
         for (int k4 = 0; k4 < 4; ++k4)
             if (lab == (float)k4) e += point_embed[k4 * DIM + c];
-        t[(5 + i) * DIM + c] = e;
+        t[(5 + i) * DIM + c] = t2[(5 + i) * DIM + c] = e;
     }
 }
 
@@ -344,11 +345,11 @@ __global__ __launch_bounds__(256) void mask_logits_kernel(const float* __restric
 namespace k {
 
 void prompt_tokens(const float* coords, const float* labels, const float* gauss, const float* point_embed,
-                   const float* not_a_point, const float* iou_token, const float* mask_tokens, float* tokens, int P,
-                   hipStream_t s) {
+                   const float* not_a_point, const float* iou_token, const float* mask_tokens, float* tokens,
+                   float* tokens_copy, int P, hipStream_t s) {
     if (P <= 0) return;
     hipLaunchKernelGGL(prompt_tokens_kernel, dim3(P), dim3(256), 0, s, coords, labels, gauss, point_embed, not_a_point,
-                       iou_token, mask_tokens, tokens);
+                       iou_token, mask_tokens, tokens, tokens_copy);
 }
 
 void token_linear(const float* X, const float* X2, const float* W, const float* b, const float* R, float* Y, int rows,

@@ -82,7 +82,7 @@ void attention_global(const half_t* qkv, const float* rel_h, const float* rel_w,
 // tokens [P,7,256]: iou token, 4 mask tokens, 2 prompt tokens from (coords [P,2,2], labels [P,2])
 void prompt_tokens(const float* coords, const float* labels, const float* gauss, const float* point_embed,
                    const float* not_a_point, const float* iou_token, const float* mask_tokens, float* tokens,
-                   int P, hipStream_t);
+                   float* tokens_copy, int P, hipStream_t s);
 // Y[r,n] = act((X[r,:] + X2[r,:]) . W[n,:] + b[n]) + R[r,n]; X2/R optional; act: 0 none, 2 relu
 void token_linear(const float* X, const float* X2, const float* W, const float* b, const float* R, float* Y,
                   int rows, int K, int N, int relu, hipStream_t);

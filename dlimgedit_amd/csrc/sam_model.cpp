@@ -540,8 +540,7 @@ void SamModel::reserve_decoder(int count) {
     logits_.reserve(P * 4 * kLowRes * kLowRes);
     iou_.reserve(P * 4);
     hyper_.reserve(P * 4 * 32);
-    coords_.reserve(P * 4);
-    labels_.reserve(P * 2);
+    coords_.reserve(P * 6);              // coordinates [P][4] followed by labels [P][2]
     const size_t T = P * kDecTokens;
     tokens_.reserve(T * 256);
     queries_.reserve(T * 256);
@@ -569,14 +568,12 @@ void SamModel::decode(float const* const* emb, float const* coords, float const*
         float* pin = static_cast<float*>(prompt_pinned_.get()) + (size_t)ring * dec_count_ * 6;
         std::memcpy(pin, coords, (size_t)P * 4 * sizeof(float));
         std::memcpy(pin + (size_t)P * 4, labels, (size_t)P * 2 * sizeof(float));
-        HIP_CHECK(hipMemcpyAsync(coords_.get(), pin, (size_t)P * 4 * sizeof(float), hipMemcpyHostToDevice, s));
-        HIP_CHECK(hipMemcpyAsync(labels_.get(), pin + (size_t)P * 4, (size_t)P * 2 * sizeof(float),
-                                 hipMemcpyHostToDevice, s));
+        // one copy for coords [P][4] and labels [P][2] (coords_ holds both, labels behind the coordinates)
+        HIP_CHECK(hipMemcpyAsync(coords_.get(), pin, (size_t)P * 6 * sizeof(float), hipMemcpyHostToDevice, s));
         HIP_CHECK(hipEventRecord(prompt_done_[ring], s));
-        k::prompt_tokens(coords_.get(), labels_.get(), W.pe_gauss_.get(), W.pe_point_.get(), W.pe_not_a_point_.get(),
-                         W.iou_token_.get(), W.mask_tokens_.get(), tokens_.get(), P, s);
-        HIP_CHECK(hipMemcpyAsync(queries_.get(), tokens_.get(), (size_t)T * 256 * sizeof(float),
-                                 hipMemcpyDeviceToDevice, s));
+        k::prompt_tokens(coords_.get(), coords_.get() + (size_t)P * 4, W.pe_gauss_.get(), W.pe_point_.get(),
+                         W.pe_not_a_point_.get(), W.iou_token_.get(), W.mask_tokens_.get(), tokens_.get(), queries_.get(),
+                         P, s);
         // src = image_embedding + no_mask_embed (has_mask_input == 0, segmentation.cpp:43-45)
         for (int p = 0; p < P; ++p)
             k::add_cast(emb[p], W.pe_no_mask_.get(), 256, (size_t)kTokens * 256, keys_.get() + (size_t)p * kTokens * 256,

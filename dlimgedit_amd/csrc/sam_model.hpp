@@ -187,7 +187,7 @@ class SamModel {
     int dec_count_ = 0;
     DeviceBuffer<float> keys_, up1_f32_, up_, logits_, iou_, hyper_;
     DeviceBuffer<half_t> keys_h_, kp_h_, kq_h_, v_h_, att_img_h_, up1_h_;
-    DeviceBuffer<float> coords_, labels_, tokens_, queries_, tq_, tk_, tv_, tatt_, tmlp_, t2i_part_;
+    DeviceBuffer<float> coords_, tokens_, queries_, tq_, tk_, tv_, tatt_, tmlp_, t2i_part_;
     DeviceBuffer<uint8_t> mask_dev_;
     PinnedBuffer mask_pinned_, prompt_pinned_;
     static constexpr int kPromptRing = 8;           // pinned prompt staging slots, re-used round robin
