@@ -41,14 +41,16 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             fn()
+        t_enqueue = time.perf_counter() - t0
         ext.synchronize(env)
+        run.enqueue_ms = 1e3 * t_enqueue / steps          # host time to enqueue one step
         return steps / (time.perf_counter() - t0)
 
     for rep in range(2):
         full = run(lambda: ext.encode_and_mask(env, views, pts, [mask]))
         enc = run(lambda: ext.encode_only(env, views))
         print(f"lanes {ext.lane_count(env)}: encode+mask {full:7.1f} images/s   encode only {enc:7.1f} images/s   "
-              f"(decoder+post cost {1e3 / full - 1e3 / enc:5.3f} ms/image)", flush=True)
+              f"(decoder+post cost {1e3 / full - 1e3 / enc:5.3f} ms/image; host enqueue {run.enqueue_ms:5.3f} ms/step)", flush=True)
 
 
 if __name__ == "__main__":
