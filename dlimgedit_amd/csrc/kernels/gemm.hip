@@ -614,8 +614,11 @@ int gemm_pick_tile(const GemmArgs& a) {
     // tile's first residual row without a modulo per element
     auto wraps_inside = [&](int bm) { return a.resid && a.resid_mod % bm != 0; };
     const bool shared = g_shared_gpu.load(std::memory_order_relaxed);
+    // 256x256 workgroups use a CU about 2.5x better than 128x128 ones (LDS fill rate per FLOP); with other lanes on
+    // the remaining CUs that is worth having even when they cover a quarter of the chip (ViT-H proj / fc2: 80
+    // workgroups, +2 % images/s; at 48, ViT-B proj / fc2, the longer kernel costs more than it frees)
     if (shared && forced < 0 && a.M % 256 == 0 && a.N % 256 == 0 &&
-        (a.M / 256) * (a.N / 256) >= 128 && !wraps_inside(256))
+        (a.M / 256) * (a.N / 256) >= 64 && !wraps_inside(256))
         return 7;
     for (int i = 0; i < kNumTiles; ++i) {
         const TileCfg& t = kTiles[i];
