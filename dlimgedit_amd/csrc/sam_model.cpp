@@ -232,9 +232,19 @@ SamWeights::SamWeights(std::string const& weight_path, int device_index) : devic
     HIP_CHECK(hipStreamDestroy(stream_));
 }
 
-SamModel::SamModel(std::shared_ptr<SamWeights const> weights) : device_(weights->device), weights_(std::move(weights)) {
+SamModel::SamModel(std::shared_ptr<SamWeights const> weights, int lane_index)
+    : device_(weights->device), weights_(std::move(weights)) {
     HIP_CHECK(hipSetDevice(device_));
-    HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    {
+        // The runtime multiplexes streams of one priority onto a few hardware queues (four by default), shared with
+        // the host's other streams: a fourth lane of the same priority ends up behind another lane's kernels and
+        // costs 15 %.  Each priority level has its own queues, so the lanes are spread over the three levels; no
+        // lane is favoured for long because requests are dealt round-robin.
+        int least = 0, greatest = 0;
+        HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        const int prio = least + (greatest - least) * (lane_index % 3) / 2;
+        HIP_CHECK(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, prio));
+    }
     HIP_CHECK(hipEventCreateWithFlags(&upload_done_, hipEventDisableTiming));
     for (auto& e : prompt_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 }

@@ -105,7 +105,7 @@ class SamModel {
     // let independent images overlap on the GPU (tails and small kernels of one image hide behind the
     // large kernels of another) -- the serving counterpart of the reference's "Environment is
     // thread-safe" contract (reference: src/include/dlimgedit/dlimgedit.hpp:98-101).
-    explicit SamModel(std::shared_ptr<SamWeights const> weights);
+    explicit SamModel(std::shared_ptr<SamWeights const> weights, int lane_index = 0);
     ~SamModel();
     SamModel(SamModel const&) = delete;
     SamModel& operator=(SamModel const&) = delete;
