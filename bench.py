@@ -28,7 +28,11 @@ import tempfile
 import time
 from pathlib import Path
 
-import numpy as np
+# Hardware queues of the HIP runtime: four by default, shared by every stream of the process; the library's execution
+# lanes each want their own.  Read once when the runtime initialises, so it is set before anything can touch the GPU.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import numpy as np  # noqa: E402
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))

@@ -240,10 +240,17 @@ SamModel::SamModel(std::shared_ptr<SamWeights const> weights, int lane_index)
         // the host's other streams: a fourth lane of the same priority ends up behind another lane's kernels and
         // costs 15 %.  Each priority level has its own queues, so the lanes are spread over the three levels; no
         // lane is favoured for long because requests are dealt round-robin.
-        int least = 0, greatest = 0;
-        HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        const int prio = least + (greatest - least) * (lane_index % 3) / 2;
-        HIP_CHECK(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, prio));
+        // When the host raised the number of hardware queues itself (GPU_MAX_HW_QUEUES >= 8, read by the runtime at
+        // its initialisation; bench.py and the Python package set it) plain streams do slightly better.
+        const char* q = std::getenv("GPU_MAX_HW_QUEUES");
+        if (q && std::atoi(q) >= 8) {
+            HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+        } else {
+            int least = 0, greatest = 0;
+            HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            const int prio = least + (greatest - least) * (lane_index % 3) / 2;
+            HIP_CHECK(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, prio));
+        }
     }
     HIP_CHECK(hipEventCreateWithFlags(&upload_done_, hipEventDisableTiming));
     for (auto& e : prompt_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
