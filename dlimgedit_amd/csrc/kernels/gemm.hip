@@ -18,8 +18,10 @@
 //     (XOR-swizzled, conflict-free) and comes back row-wise, so bias / residual / outputs are
 //     all 16-byte, fully coalesced global accesses
 //   * XCD-aware workgroup remap so the tiles of one XCD share A panels in its L2
-// Epilogue (all optional, fp32): + bias[n], GELU(erf), + residual[m % resid_mod][n], store f32
-// and/or f16.
+// Epilogue (all optional, fp32; gemm_epilogue.inc): + bias[n], GELU(erf), + residual[m % resid_mod][n], store f32
+// and/or f16; the encoder's LayerNorms are folded in (EPI_STATS on the producing GEMM, EPI_NORM on the consuming one).
+// Two kernels share all of this: gemm_f16_kernel on v_mfma_f32_32x32x16_f16 (BK 64 or 32, 4 or 8 waves) and
+// gemm16_f16_kernel on v_mfma_f32_16x16x32_f16 (BK 32), whose operand fragments travel one K tile ahead in registers.
 #include "device_common.hpp"
 #include "kernels.hpp"
 
