@@ -212,16 +212,22 @@ __global__ __launch_bounds__(256, 2) void attention_global_kernel(const half_t* 
         const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c);
         const float off = (rh - m_new) * c;
         m = m_new;
-        float ps = 0.f;
+        // exponent arguments and the row sum two at a time (v_pk_fma_f32 / v_pk_add_f32); the exponentials themselves
+        // are quarter-rate scalar instructions
+        float2_t ps2 = {0.f, 0.f};
+        const float2_t c2 = {c, c}, off2 = {off, off};
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float p = ABL == 2 ? s[jt][r] : __builtin_amdgcn_exp2f(fmaf(s[jt][r], c, off));
-                s[jt][r] = p;
-                ps += p;
+            for (int r = 0; r < 16; r += 2) {
+                float2_t a = float2_t{s[jt][r], s[jt][r + 1]} * c2 + off2;
+                float2_t p = {ABL == 2 ? s[jt][r] : __builtin_amdgcn_exp2f(a[0]),
+                              ABL == 2 ? s[jt][r + 1] : __builtin_amdgcn_exp2f(a[1])};
+                s[jt][r] = p[0];
+                s[jt][r + 1] = p[1];
+                ps2 += p;
             }
-        l = l * alpha + ps;
+        l = l * alpha + (ps2[0] + ps2[1]);
         if (!__all(alpha == 1.0f)) {            // the running max moved for some query of this wave
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
