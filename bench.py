@@ -30,7 +30,10 @@ from pathlib import Path
 
 # Hardware queues of the HIP runtime: four by default, shared by every stream of the process; the library's execution
 # lanes each want their own.  Read once when the runtime initialises, so it is set before anything can touch the GPU.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# DLIMGEDIT_PLAIN_STREAMS tells the library that this host did so (it cannot see the runtime's setting itself).
+if "GPU_MAX_HW_QUEUES" not in os.environ:
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
+    os.environ.setdefault("DLIMGEDIT_PLAIN_STREAMS", "1")
 
 import numpy as np  # noqa: E402
 

@@ -369,6 +369,8 @@ class ext:
                 "dlimg_amd_encode_only": ([vp, C.POINTER(_ImageView), ci], ci),
                 "dlimg_amd_synchronize": ([vp], ci),
                 "dlimg_amd_lane_count": ([vp], ci),
+                "dlimg_amd_replica_count": ([vp], ci),
+                "dlimg_amd_segmentation_device": ([vp, C.POINTER(ci), C.POINTER(ci)], ci),
                 "dlimg_amd_set_profiling": ([vp, ci], ci),
                 "dlimg_amd_take_stage_stats": ([vp, vp, vp, vp], ci),
                 "dlimg_amd_test_preprocess": ([vp, ci, ci, ci, ci, vp], ci),
@@ -392,6 +394,7 @@ class ext:
     EXPORTS = ("dlimg_amd_device_count", "dlimg_amd_model_geometry", "dlimg_amd_get_embedding", "dlimg_amd_get_logits",
                "dlimg_amd_device_alloc", "dlimg_amd_device_free", "dlimg_amd_copy_to_device", "dlimg_amd_copy_to_host",
                "dlimg_amd_encode_and_mask", "dlimg_amd_encode_only", "dlimg_amd_synchronize", "dlimg_amd_lane_count",
+               "dlimg_amd_replica_count", "dlimg_amd_segmentation_device",
                "dlimg_amd_set_profiling",
                "dlimg_amd_take_stage_stats", "dlimg_amd_test_preprocess", "dlimg_amd_test_postprocess",
                "dlimg_amd_test_gemm", "dlimg_amd_test_gemm_ln", "dlimg_amd_test_layernorm", "dlimg_amd_test_attention", "dlimg_amd_test_resize",
@@ -471,6 +474,17 @@ class ext:
     @classmethod
     def lane_count(cls, env) -> int:
         return cls._l().dlimg_amd_lane_count(env.handle())
+
+    @classmethod
+    def replica_count(cls, env) -> int:
+        return cls._l().dlimg_amd_replica_count(env.handle())
+
+    @classmethod
+    def segmentation_device(cls, seg) -> Tuple[int, int]:
+        """(replica index in the environment's device list, HIP device index) holding the embedding."""
+        r, d = C.c_int(), C.c_int()
+        _check(cls._l().dlimg_amd_segmentation_device(seg._handle, C.byref(r), C.byref(d)))
+        return r.value, d.value
 
     @classmethod
     def set_profiling(cls, env, on: bool) -> None:

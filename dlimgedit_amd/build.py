@@ -18,6 +18,7 @@ CSRC = PKG / "csrc"
 OBJ = CSRC / "_obj"
 LIB = PKG / "lib" / "libdlimgedit.so"
 ARCH = "gfx950"
+SONAME = "libdlimgedit.so.1"
 
 SOURCES = [
     "kernels/gemm.hip",
@@ -90,10 +91,15 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         objs = list(ex.map(lambda s: _compile(s, force, hdr), SOURCES))
     if force or not LIB.exists() or LIB.stat().st_mtime < max(o.stat().st_mtime for o in objs):
         cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs),
-               "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"]
+               "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined", f"-Wl,-soname,{SONAME}", "-ldl", "-lz"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    # consumers linked against the reference's library resolve libdlimgedit.so.1 (SOVERSION 1,
+    # /root/reference/src/CMakeLists.txt:20-23)
+    link = LIB.parent / SONAME
+    if not link.is_symlink() and not link.exists():
+        link.symlink_to(LIB.name)
     if verbose:
         print(f"built {LIB} ({LIB.stat().st_size / 1e6:.1f} MB)")
     return LIB

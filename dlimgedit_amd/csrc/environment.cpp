@@ -53,9 +53,39 @@ EnvironmentImpl::EnvironmentImpl(dlimg_Options const& options) : backend(options
     if (backend != dlimg_gpu)
         throw Exception("The CPU backend is not available in the MI355X build of dlimgedit; use Backend::gpu");
     if (!is_supported(dlimg_gpu)) throw Exception("No supported GPU (gfx950) found for Backend::gpu");
-    if (const char* dev = std::getenv("DLIMGEDIT_DEVICE")) device = std::atoi(dev);
-    if (device < 0 || device >= device_count())
-        throw Exception("DLIMGEDIT_DEVICE=" + std::to_string(device) + " is out of range");
+    // Device list: DLIMGEDIT_DEVICES ("0,1,2" or "all") wins over DLIMGEDIT_DEVICE (one index); default device 0.
+    std::vector<int> devices;
+    if (const char* list = std::getenv("DLIMGEDIT_DEVICES")) {
+        std::string l(list);
+        if (l == "all") {
+            for (int i = 0; i < device_count(); ++i) devices.push_back(i);
+        } else {
+            size_t pos = 0;
+            while (pos <= l.size()) {
+                size_t end = l.find(',', pos);
+                if (end == std::string::npos) end = l.size();
+                std::string item = l.substr(pos, end - pos);
+                char* tail = nullptr;
+                long v = std::strtol(item.c_str(), &tail, 10);
+                if (item.empty() || *tail) throw Exception("DLIMGEDIT_DEVICES='" + l + "' is not a list of device indices");
+                devices.push_back(int(v));
+                pos = end + 1;
+            }
+        }
+    } else if (const char* dev = std::getenv("DLIMGEDIT_DEVICE")) {
+        devices.push_back(std::atoi(dev));
+    } else {
+        devices.push_back(0);
+    }
+    for (int d : devices) {
+        if (d < 0 || d >= device_count())
+            throw Exception("GPU index " + std::to_string(d) + " (DLIMGEDIT_DEVICE / DLIMGEDIT_DEVICES) is out of range: " +
+                            std::to_string(device_count()) + " device(s) visible");
+        auto r = std::make_unique<Replica>();
+        r->device = d;
+        r->pool = std::make_shared<EmbeddingPool>(d);
+        replicas_.push_back(std::move(r));
+    }
 }
 
 std::string EnvironmentImpl::find_sam_weights() const {
@@ -91,29 +121,70 @@ EnvironmentImpl::SamLanes::SamLanes(std::string const& weight_path, int device, 
     // images in flight per GPU, measured on MI355X: ViT-B 3 -> 4 lanes +5 % (5-8 lanes worse); ViT-H 4 lanes -6 %
     // against 3 (its kernels already cover the chip)
     if (count <= 0) count = weights->geom_.embed_dim <= 768 ? 4 : 3;
-    for (int i = 0; i < count; ++i) lanes.push_back(std::make_unique<SamModel>(weights, i));
-    k::gemm_set_shared_gpu(count > 1);
+    for (int i = 0; i < count; ++i) lanes.push_back(std::make_unique<SamModel>(weights, i, count));
 }
 
-EnvironmentImpl::SamLanes& EnvironmentImpl::lanes() {
-    return sam_.get_or_make([&] {
+EnvironmentImpl::SamLanes& EnvironmentImpl::lanes(int replica) {
+    Replica& r = *replicas_.at(replica);
+    return r.sam.get_or_make([&] {
         int n = 0;      // chosen from the model size (SamLanes); DLIMGEDIT_LANES overrides (1..8)
         if (const char* e = std::getenv("DLIMGEDIT_LANES")) {
             n = std::atoi(e);
             n = n < 1 ? 1 : (n > 8 ? 8 : n);
         }
-        return std::make_tuple(find_sam_weights(), device, n);
+        return std::make_tuple(find_sam_weights(), r.device, n);
     });
 }
 
-int EnvironmentImpl::lane_count() { return int(lanes().lanes.size()); }
+int EnvironmentImpl::lane_count(int replica) { return int(lanes(replica).lanes.size()); }
 
-SamModel& EnvironmentImpl::lane(int index) { return *lanes().lanes.at(index); }
+SamModel& EnvironmentImpl::lane(int replica, int index) { return *lanes(replica).lanes.at(index); }
 
-SamModel& EnvironmentImpl::sam_model() {
-    SamLanes& l = lanes();
+SamModel& EnvironmentImpl::next_lane(int replica) {
+    SamLanes& l = lanes(replica);
     if (single_lane_.load() || l.lanes.size() == 1) return *l.lanes[0];
-    return *l.lanes[next_lane_.fetch_add(1) % l.lanes.size()];
+    return *l.lanes[replicas_[replica]->next_lane.fetch_add(1) % l.lanes.size()];
+}
+
+float* EmbeddingPool::take() {
+    {
+        std::lock_guard<std::mutex> lock(mutex_);
+        if (!free_.empty()) {
+            float* p = free_.back();
+            free_.pop_back();
+            return p;
+        }
+    }
+    HIP_CHECK(hipSetDevice(device_));
+    float* p = nullptr;
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), (size_t)kTokens * kEmbedDim * sizeof(float)));
+    return p;
+}
+
+void EmbeddingPool::give(float* buffer) noexcept {
+    if (!buffer) return;
+    constexpr size_t kKeep = 1024;                // 4 GiB of the 288 GB at most stay parked
+    {
+        std::lock_guard<std::mutex> lock(mutex_);
+        if (free_.size() < kKeep) {
+            // Kernels that read or wrote the buffer were queued by calls that have returned, and every such call
+            // waits for its work: nothing on the device refers to the buffer any more.
+            free_.push_back(buffer);
+            return;
+        }
+    }
+    (void)hipSetDevice(device_);
+    (void)hipFree(buffer);
+}
+
+EmbeddingPool::~EmbeddingPool() {
+    if (free_.empty()) return;
+    (void)hipSetDevice(device_);
+    for (float* p : free_) (void)hipFree(p);
+}
+
+void EnvironmentImpl::load_all() {
+    for (int r = 0; r < replica_count(); ++r) (void)lanes(r);
 }
 
 }  // namespace dlimg

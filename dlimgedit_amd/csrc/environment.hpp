@@ -1,6 +1,13 @@
-// EnvironmentImpl: backend gate, model directory, lazily loaded SAM model.
+// EnvironmentImpl: backend gate, model directory, lazily loaded SAM model on one or several GPUs.
 // Counterpart of /root/reference/src/environment.{hpp,cpp}; the onnxruntime environment, provider
 // probing through dlopen(libcuda) and the thread-count knob are replaced by a HIP device probe.
+//
+// Multi-GPU (nothing like it in the reference, which appends the CUDA provider with default options = device 0,
+// /root/reference/src/session.cpp:63-66): an environment owns one REPLICA per entry of its device list
+// (DLIMGEDIT_DEVICES=0,1,...,7 | all; default: the single device DLIMGEDIT_DEVICE or 0).  A replica is a full copy
+// of the weights on that GPU plus its execution lanes.  Images are independent, so a batch is dealt image i ->
+// replica i mod G and nothing is exchanged between GPUs; every Segmentation handle remembers the replica that holds
+// its embedding and its mask queries run there.
 #pragma once
 
 #include "common.hpp"
@@ -11,16 +18,34 @@
 #include <atomic>
 #include <filesystem>
 #include <memory>
-#include <vector>
 #include <string>
+#include <vector>
 
 namespace dlimg {
+
+// Device buffers for image embeddings ([4096][256] fp32 = 4 MiB each) of one GPU, recycled: hipMalloc costs a fraction
+// of a millisecond and hipFree waits for the whole device, which would serialise the lanes once per image.  Shared by
+// the environment and its Segmentation handles, so a handle that is destroyed after its environment (the reference
+// forbids it, dlimgedit.hpp:98-100, but a garbage-collected host cannot promise the order) still has a home for its buffer.
+class EmbeddingPool {
+  public:
+    explicit EmbeddingPool(int device) : device_(device) {}
+    ~EmbeddingPool();
+    EmbeddingPool(EmbeddingPool const&) = delete;
+    EmbeddingPool& operator=(EmbeddingPool const&) = delete;
+    float* take();
+    void give(float* buffer) noexcept;
+
+  private:
+    int device_;
+    std::mutex mutex_;
+    std::vector<float*> free_;
+};
 
 class EnvironmentImpl {
   public:
     dlimg_Backend backend = dlimg_gpu;
     std::filesystem::path model_directory;
-    int device = 0;
 
     // Cheap, cached, never throws (reference: environment.cpp:103-122).
     static bool is_supported(dlimg_Backend backend) noexcept;
@@ -28,12 +53,25 @@ class EnvironmentImpl {
 
     explicit EnvironmentImpl(dlimg_Options const& options);
 
-    // Weights + execution lanes, created on first use, once per environment (reference:
-    // environment.cpp:144-146).  sam_model() hands out the lanes round-robin; lane(i) addresses one.
-    SamModel& sam_model();
-    SamModel& lane(int index);
-    int lane_count();
-    // While set, every request goes to lane 0 (per-kernel clocks must not see other lanes' kernels).
+    // Replicas: one per entry of the device list (the same GPU may be listed more than once; each entry is an
+    // independent replica with its own weights -- used by the tests to exercise the multi-device code on one GPU).
+    int replica_count() const { return int(replicas_.size()); }
+    int device_of(int replica) const { return replicas_.at(replica)->device; }
+    int first_device() const { return replicas_[0]->device; }
+
+    // Weights + execution lanes of a replica, created on first use, once per environment (reference:
+    // environment.cpp:144-146).  next_lane() hands out a replica's lanes round-robin; lane() addresses one.
+    SamModel& next_lane(int replica);
+    SamModel& lane(int replica, int index);
+    int lane_count(int replica = 0);
+    // Replica for the next independent image (round-robin over the device list).
+    int next_replica() { return replicas_.size() == 1 ? 0 : int(next_replica_.fetch_add(1) % replicas_.size()); }
+    // Loads the model on every replica (reports a missing weight file where the reference does).
+    void load_all();
+    // Device buffers for image embeddings, recycled per replica (see EmbeddingPool).
+    std::shared_ptr<EmbeddingPool> embedding_pool(int replica) const { return replicas_.at(replica)->pool; }
+
+    // While set, every request goes to lane 0 of its replica (per-kernel clocks must not see other lanes' kernels).
     void set_single_lane(bool on) { single_lane_.store(on); }
 
   private:
@@ -42,10 +80,16 @@ class EnvironmentImpl {
         std::shared_ptr<SamWeights const> weights;
         std::vector<std::unique_ptr<SamModel>> lanes;
     };
-    SamLanes& lanes();
+    struct Replica {
+        int device = 0;
+        Lazy<SamLanes> sam;
+        std::atomic<unsigned> next_lane{0};
+        std::shared_ptr<EmbeddingPool> pool;
+    };
+    SamLanes& lanes(int replica);
     std::string find_sam_weights() const;
-    Lazy<SamLanes> sam_;
-    std::atomic<unsigned> next_lane_{0};
+    std::vector<std::unique_ptr<Replica>> replicas_;
+    std::atomic<unsigned> next_replica_{0};
     std::atomic<bool> single_lane_{false};
 };
 

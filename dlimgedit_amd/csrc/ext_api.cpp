@@ -69,6 +69,17 @@ void encode_device_images(SamModel& model, dlimg_ImageView const* imgs, int coun
     model.encode(count);
 }
 
+// every lane of every replica
+template <typename F> void for_each_lane(EnvironmentImpl& e, F&& body) {
+    for (int r = 0; r < e.replica_count(); ++r)
+        for (int i = 0; i < e.lane_count(r); ++i) {
+            SamModel& m = e.lane(r, i);
+            std::lock_guard<std::mutex> lock(m.mutex());
+            HIP_CHECK(hipSetDevice(m.device()));
+            body(m);
+        }
+}
+
 }  // namespace
 }  // namespace dlimg
 
@@ -80,7 +91,7 @@ DLIMG_API int dlimg_amd_device_count(void) { return EnvironmentImpl::device_coun
 
 DLIMG_API int dlimg_amd_model_geometry(dlimg_Environment env, int* out) {
     return guarded([&] {
-        SamGeometry const& g = impl(env).lane(0).geometry();
+        SamGeometry const& g = impl(env).lane(0, 0).geometry();
         out[0] = g.embed_dim;
         out[1] = g.depth;
         out[2] = g.num_heads;
@@ -92,7 +103,7 @@ DLIMG_API int dlimg_amd_get_embedding(dlimg_Segmentation seg, float* out) {
     return guarded([&] {
         SegmentationImpl& s = impl(seg);
         DLIMG_ASSERT(s.embedding() != nullptr && out != nullptr);
-        HIP_CHECK(hipSetDevice(s.environment().device));
+        HIP_CHECK(hipSetDevice(s.environment().device_of(s.replica())));
         download(out, s.embedding(), (size_t)kTokens * kEmbedDim);      // process() has synchronised already
     });
 }
@@ -108,7 +119,7 @@ DLIMG_API int dlimg_amd_get_logits(dlimg_Segmentation seg, int const* point, int
         if (region) r = Region{Point{region[0], region[1]}, Point{region[2], region[3]}};
         float coords[4], labels[2];
         pack_prompt(s.geometry(), point ? &p : nullptr, !point && region ? &r : nullptr, coords, labels);
-        SamModel& m = s.environment().sam_model();
+        SamModel& m = s.environment().next_lane(s.replica());
         std::lock_guard<std::mutex> lock(m.mutex());
         HIP_CHECK(hipSetDevice(m.device()));
         float const* emb = s.embedding();
@@ -121,28 +132,28 @@ DLIMG_API int dlimg_amd_get_logits(dlimg_Segmentation seg, int const* point, int
 
 DLIMG_API int dlimg_amd_device_alloc(dlimg_Environment env, size_t bytes, void** out_ptr) {
     return guarded([&] {
-        HIP_CHECK(hipSetDevice(impl(env).device));
+        HIP_CHECK(hipSetDevice(impl(env).first_device()));
         HIP_CHECK(hipMalloc(out_ptr, bytes));
     });
 }
 
 DLIMG_API int dlimg_amd_device_free(dlimg_Environment env, void* ptr) {
     return guarded([&] {
-        HIP_CHECK(hipSetDevice(impl(env).device));
+        HIP_CHECK(hipSetDevice(impl(env).first_device()));
         HIP_CHECK(hipFree(ptr));
     });
 }
 
 DLIMG_API int dlimg_amd_copy_to_device(dlimg_Environment env, void* dst, void const* src, size_t bytes) {
     return guarded([&] {
-        HIP_CHECK(hipSetDevice(impl(env).device));
+        HIP_CHECK(hipSetDevice(impl(env).first_device()));
         HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
     });
 }
 
 DLIMG_API int dlimg_amd_copy_to_host(dlimg_Environment env, void* dst, void const* src, size_t bytes) {
     return guarded([&] {
-        HIP_CHECK(hipSetDevice(impl(env).device));
+        HIP_CHECK(hipSetDevice(impl(env).first_device()));
         HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     });
 }
@@ -150,7 +161,7 @@ DLIMG_API int dlimg_amd_copy_to_host(dlimg_Environment env, void* dst, void cons
 DLIMG_API int dlimg_amd_encode_only(dlimg_Environment env, dlimg_ImageView const* dev_images, int count) {
     return guarded([&] {
         DLIMG_ASSERT(dev_images != nullptr && count > 0);
-        SamModel& m = impl(env).sam_model();
+        SamModel& m = impl(env).next_lane(0);
         std::lock_guard<std::mutex> lock(m.mutex());
         HIP_CHECK(hipSetDevice(m.device()));
         encode_device_images(m, dev_images, count);
@@ -161,7 +172,7 @@ DLIMG_API int dlimg_amd_encode_and_mask(dlimg_Environment env, dlimg_ImageView c
                                         int const* points, uint8_t* const* dev_masks) {
     return guarded([&] {
         DLIMG_ASSERT(dev_images != nullptr && points != nullptr && dev_masks != nullptr && count > 0);
-        SamModel& m = impl(env).sam_model();
+        SamModel& m = impl(env).next_lane(0);
         std::lock_guard<std::mutex> lock(m.mutex());
         HIP_CHECK(hipSetDevice(m.device()));
         encode_device_images(m, dev_images, count);
@@ -186,28 +197,16 @@ DLIMG_API int dlimg_amd_encode_and_mask(dlimg_Environment env, dlimg_ImageView c
 }
 
 DLIMG_API int dlimg_amd_synchronize(dlimg_Environment env) {
-    return guarded([&] {
-        EnvironmentImpl& e = impl(env);
-        for (int i = 0; i < e.lane_count(); ++i) {
-            SamModel& m = e.lane(i);
-            std::lock_guard<std::mutex> lock(m.mutex());
-            HIP_CHECK(hipSetDevice(m.device()));
-            m.synchronize();
-        }
-    });
+    return guarded([&] { for_each_lane(impl(env), [](SamModel& m) { m.synchronize(); }); });
 }
 
 DLIMG_API int dlimg_amd_set_profiling(dlimg_Environment env, int enabled) {
     return guarded([&] {
         EnvironmentImpl& e = impl(env);
-        for (int i = 0; i < e.lane_count(); ++i) {      // drain everything, then pin requests to lane 0 while clocks run
-            SamModel& m = e.lane(i);
-            std::lock_guard<std::mutex> lock(m.mutex());
-            HIP_CHECK(hipSetDevice(m.device()));
-            m.synchronize();
-        }
+        // drain everything, then pin requests to lane 0 while the clocks run
+        for_each_lane(e, [](SamModel& m) { m.synchronize(); });
         e.set_single_lane(enabled != 0);
-        SamModel& m = e.lane(0);
+        SamModel& m = e.lane(0, 0);
         std::lock_guard<std::mutex> lock(m.mutex());
         m.set_profiling(enabled != 0);
     });
@@ -216,7 +215,7 @@ DLIMG_API int dlimg_amd_set_profiling(dlimg_Environment env, int enabled) {
 DLIMG_API int dlimg_amd_take_stage_stats(dlimg_Environment env, double* out_ms, double* out_work, long* out_launches) {
     static_assert(ST_COUNT == DLIMG_AMD_STAGE_COUNT, "stage table out of sync with the public header");
     return guarded([&] {
-        SamModel& m = impl(env).lane(0);
+        SamModel& m = impl(env).lane(0, 0);
         std::lock_guard<std::mutex> lock(m.mutex());
         HIP_CHECK(hipSetDevice(m.device()));
         StageStats s = m.take_stats();
@@ -230,8 +229,22 @@ DLIMG_API int dlimg_amd_take_stage_stats(dlimg_Environment env, double* out_ms, 
 
 DLIMG_API int dlimg_amd_lane_count(dlimg_Environment env) {
     int n = 0;
-    guarded([&] { n = impl(env).lane_count(); });
+    guarded([&] { n = impl(env).lane_count(0); });
     return n;
+}
+
+DLIMG_API int dlimg_amd_replica_count(dlimg_Environment env) {
+    int n = 0;
+    guarded([&] { n = impl(env).replica_count(); });
+    return n;
+}
+
+DLIMG_API int dlimg_amd_segmentation_device(dlimg_Segmentation seg, int* out_replica, int* out_device) {
+    return guarded([&] {
+        SegmentationImpl& s = impl(seg);
+        if (out_replica) *out_replica = s.replica();
+        if (out_device) *out_device = s.environment().device_of(s.replica());
+    });
 }
 
 // ---- single-kernel hooks ----------------------------------------------------------------------
@@ -310,7 +323,7 @@ DLIMG_API int dlimg_amd_test_gemm_ln(int M, int D, int K1, int N, uint16_t const
         g.resid = resid ? r.get() : nullptr; g.ldr = D; g.resid_mod = M;
         g.out_f32 = x.get(); g.ldc32 = D; g.out_h = xh.get(); g.ldc16 = D; g.stats_out = stats.get();
         g.M = M; g.N = D; g.K = K1;
-        const int groups = D / k::gemm_tile_columns(g);
+        const int groups = D / k::gemm_choose_tile(g);
         k::gemm(g, nullptr);
         g = k::GemmArgs{};  // consumer: LayerNorm folded in
         g.A = xh.get(); g.lda = D; g.W = wg.get(); g.ldw = D; g.bias = bias2 ? b2.get() : nullptr;

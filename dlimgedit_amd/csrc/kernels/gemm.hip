@@ -25,7 +25,7 @@
 #include "device_common.hpp"
 #include "kernels.hpp"
 
-#include <atomic>
+#include <mutex>
 #include <cstdlib>
 #include <type_traits>
 
@@ -517,14 +517,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm16_f16_kernel(k::Gem
 typedef void (*GemmKernel)(k::GemmArgs);
 
 // Picks the epilogue flavour the arguments ask for and launches; LDS above the default limit is opted into once.
-void launch_flavour(GemmKernel const (&kernels)[5], bool (&attr_set)[5], const k::GemmArgs& a, int grid, int threads,
-                    size_t lds, hipStream_t s) {
+void launch_flavour(GemmKernel const (&kernels)[5], std::once_flag (&attr_once)[5], const k::GemmArgs& a, int grid,
+                    int threads, size_t lds, hipStream_t s) {
     const int index = a.stats_out ? 4 : (a.ln_stats ? 2 : 0) + (a.act == k::ACT_GELU ? 1 : 0);
-    if (lds > 48 * 1024 && !attr_set[index]) {
-        if (hipFuncSetAttribute((const void*)kernels[index], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess)
-            throw_error("gemm: the device refuses the LDS size of this tile configuration");
-        attr_set[index] = true;
+    if (lds > 48 * 1024) {
+        bool refused = false;        // concurrent lanes launch the same kernels: opt in exactly once, under the flag
+        std::call_once(attr_once[index], [&] {
+            refused = hipFuncSetAttribute((const void*)kernels[index], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds) != hipSuccess;
+        });
+        if (refused) throw_error("gemm: the device refuses the LDS size of this tile configuration");
     }
     hipLaunchKernelGGL(kernels[index], dim3(grid), dim3(threads), lds, s, a);
 }
@@ -539,8 +541,8 @@ void launch16(const k::GemmArgs& a, hipStream_t s) {
         gemm16_f16_kernel<BM, BN, WGM, WGN, NSTAGE, MINW, k::ACT_GELU, EPI_NORM>,
         gemm16_f16_kernel<BM, BN, WGM, WGN, NSTAGE, MINW, k::ACT_NONE, EPI_STATS>,
     };
-    static bool attr_set[5] = {};
-    launch_flavour(kernels, attr_set, a, (a.M / BM) * (a.N / BN), 64 * WGM * WGN, lds, s);
+    static std::once_flag attr_once[5];
+    launch_flavour(kernels, attr_once, a, (a.M / BM) * (a.N / BN), 64 * WGM * WGN, lds, s);
 }
 
 template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE, int MINW>
@@ -556,8 +558,8 @@ void launch(const k::GemmArgs& a, hipStream_t s) {
         gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_GELU, EPI_NORM>,
         gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_NONE, EPI_STATS>,
     };
-    static bool attr_set[5] = {};
-    launch_flavour(kernels, attr_set, a, (a.M / BM) * (a.N / BN), 64 * WGM * WGN, lds, s);
+    static std::once_flag attr_once[5];
+    launch_flavour(kernels, attr_once, a, (a.M / BM) * (a.N / BN), 64 * WGM * WGN, lds, s);
 }
 
 }  // namespace
@@ -601,30 +603,30 @@ constexpr TileCfg kTiles[] = {
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
-// With several execution lanes the GPU is shared between kernels of different images: tiles that leave
-// room for a second workgroup on the CU (<= 64 KB LDS) let those kernels overlap, which is worth more
-// than the better isolated efficiency of the one-workgroup-per-CU tiles (measured: +8 % images/s).
-static std::atomic<bool> g_shared_gpu{false};
-void gemm_set_shared_gpu(bool shared) { g_shared_gpu.store(shared); }
-
+// GemmArgs::shared_gpu -- with several execution lanes the GPU is shared between kernels of different images: tiles
+// that leave room for a second workgroup on the CU (<= 64 KB LDS) let those kernels overlap, which is worth more
+// than the better isolated efficiency of the one-workgroup-per-CU tiles (measured: +8 % images/s).  It is a property
+// of the caller (SamModel knows how many lanes share its device), not process state.
 int gemm_pick_tile(const GemmArgs& a) {
-    const char* forced_env = std::getenv("DLIMGEDIT_GEMM_TILE");   // tuning/test aid, not a user knob
-    const int forced = forced_env ? std::atoi(forced_env) : -1;
+    if (a.tile >= 0) return a.tile < kNumTiles ? a.tile : -1;     // chosen earlier by the caller (pick once, use twice)
+    // tuning/test aid, not a user knob; read once
+    static const int forced = [] { const char* e = std::getenv("DLIMGEDIT_GEMM_TILE"); return e ? std::atoi(e) : -1; }();
     int best = -1;
     float best_score = -1.f;
+    const int unit = (a.unit_rows > 0 && a.M % a.unit_rows == 0) ? a.unit_rows : a.M;   // rows the choice is made for
     // a residual that wraps (row m % resid_mod) must wrap on tile boundaries: the epilogue adds row offsets to the
     // tile's first residual row without a modulo per element
     auto wraps_inside = [&](int bm) { return a.resid && a.resid_mod % bm != 0; };
-    const bool shared = g_shared_gpu.load(std::memory_order_relaxed);
+    const bool shared = a.shared_gpu;
     // 256x256 workgroups use a CU about 2.5x better than 128x128 ones (LDS fill rate per FLOP); with other lanes on
     // the remaining CUs that is worth having even when they cover a quarter of the chip (ViT-H proj / fc2: 80
     // workgroups, +2 % images/s; at 48, ViT-B proj / fc2, the longer kernel costs more than it frees)
-    if (shared && forced < 0 && a.M % 256 == 0 && a.N % 256 == 0 &&
-        (a.M / 256) * (a.N / 256) >= 64 && !wraps_inside(256))
+    if (shared && forced < 0 && unit % 256 == 0 && a.N % 256 == 0 &&
+        (unit / 256) * (a.N / 256) >= 64 && !wraps_inside(256))
         return 7;
     for (int i = 0; i < kNumTiles; ++i) {
         const TileCfg& t = kTiles[i];
-        if (a.M % t.bm || a.N % t.bn || wraps_inside(t.bm)) continue;
+        if (unit % t.bm || a.N % t.bn || wraps_inside(t.bm)) continue;
         if (i == forced) return i;
         if (shared && forced < 0) {
             // shared GPU: other lanes fill the CUs this launch leaves free, so the only question is operand
@@ -633,7 +635,7 @@ int gemm_pick_tile(const GemmArgs& a) {
             if (t.per_cu < 2) continue;
         }
         const float eff = t.eff;
-        const int blocks = (a.M / t.bm) * (a.N / t.bn);
+        const int blocks = (unit / t.bm) * (a.N / t.bn);
         const int slots = 256 * t.per_cu;
         const int rounds = (blocks + slots - 1) / slots;
         const float score = eff * (float)blocks / (float)(rounds * slots);
@@ -642,11 +644,12 @@ int gemm_pick_tile(const GemmArgs& a) {
     return best;
 }
 
-int gemm_tile_columns(const GemmArgs& a) {
+int gemm_choose_tile(GemmArgs& a) {
     if (const char* err = gemm_check(a)) throw_error(err);
-    const int tile = gemm_pick_tile(a);
-    if (tile < 0) throw_error("gemm: no tile configuration fits this shape");
-    return kTiles[tile].bn;
+    a.tile = -1;
+    a.tile = gemm_pick_tile(a);
+    if (a.tile < 0) throw_error("gemm: no tile configuration fits this shape");
+    return kTiles[a.tile].bn;
 }
 
 void gemm(const GemmArgs& a, hipStream_t s) {

@@ -27,7 +27,7 @@ struct GemmArgs {
     int M = 0, N = 0, K = 0;
     int act = ACT_NONE;
     // LayerNorm folded into the GEMMs around it (gemm.hip).  Producer: stats_out receives, per tile column block and
-    // row, the (sum, sum of squared deviations) of the fp32 result -- [N / gemm_tile_columns()][M][2].  Consumer: A is
+    // row, the (sum, sum of squared deviations) of the fp32 result -- [N / BN][M][2] (BN from gemm_choose_tile).  Consumer: A is
     // the raw, un-normalised input, W carries the LayerNorm scale (W * diag(gamma)), bias carries b + W.beta; ln_stats
     // are the producer's partials ([ln_groups][M][2], groups of K / ln_groups columns) and the epilogue applies
     // rstd_m * (acc - mean_m * ln_colsum[n]) + bias[n].
@@ -36,12 +36,18 @@ struct GemmArgs {
     int ln_groups = 0;
     const float* ln_colsum = nullptr;            // [N] sum over k of the (f16-rounded) scaled weight
     float ln_eps = 0.f;
+    // Tile selection.  shared_gpu: kernels of several execution lanes share the device (prefer tiles that can share a
+    // CU).  tile: -1 = let gemm() choose; gemm_choose_tile() fixes the choice in the arguments so that a caller who
+    // needs the tile width beforehand (stats_out layout) and the launch agree by construction.
+    bool shared_gpu = false;
+    int tile = -1;
+    // Rows of ONE independent unit (an image: 4096 tokens) when M stacks several of them.  The tile is chosen for the
+    // unit's shape, so a batch runs the same tiles -- and produces the same bits -- as its images one at a time.
+    int unit_rows = 0;
 };
 const char* gemm_check(const GemmArgs&);
-int gemm_tile_columns(const GemmArgs&);       // BN of the tile configuration gemm() will use for these arguments
+int gemm_choose_tile(GemmArgs&);              // sets a.tile; returns BN (columns per tile) of that configuration
 void gemm(const GemmArgs&, hipStream_t);
-// Tile selection hint: true when kernels of several execution lanes share the GPU.
-void gemm_set_shared_gpu(bool shared);
 
 // ---- row LayerNorm ---------------------------------------------------------------------------
 // y = (x-mean)/sqrt(var+eps)*w+b over rows of length D (<= 1280); optional GELU; f32 and/or f16 out.

@@ -1,5 +1,6 @@
 #include "sam_model.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -8,7 +9,10 @@ namespace dlimg {
 
 namespace {
 
-constexpr float kLnEps = 1e-6f;
+constexpr float kLnEps = 1e-6f;       // encoder blocks and every LayerNorm2d
+// norm1..4 of the two-way blocks and norm_final_attn: nn.LayerNorm's default in Meta's mask decoder, which the
+// reference's decoder graphs are exports of (/root/reference/script/export_models.py:29-43)
+constexpr float kDecLnEps = 1e-5f;
 
 struct Loader {
     WeightFile const& file;
@@ -232,18 +236,19 @@ SamWeights::SamWeights(std::string const& weight_path, int device_index) : devic
     HIP_CHECK(hipStreamDestroy(stream_));
 }
 
-SamModel::SamModel(std::shared_ptr<SamWeights const> weights, int lane_index)
-    : device_(weights->device), weights_(std::move(weights)) {
+SamModel::SamModel(std::shared_ptr<SamWeights const> weights, int lane_index, int lane_count)
+    : device_(weights->device), shared_gpu_(lane_count > 1), weights_(std::move(weights)) {
     HIP_CHECK(hipSetDevice(device_));
     {
         // The runtime multiplexes streams of one priority onto a few hardware queues (four by default), shared with
         // the host's other streams: a fourth lane of the same priority ends up behind another lane's kernels and
         // costs 15 %.  Each priority level has its own queues, so the lanes are spread over the three levels; no
         // lane is favoured for long because requests are dealt round-robin.
-        // When the host raised the number of hardware queues itself (GPU_MAX_HW_QUEUES >= 8, read by the runtime at
-        // its initialisation; bench.py and the Python package set it) plain streams do slightly better.
-        const char* q = std::getenv("GPU_MAX_HW_QUEUES");
-        if (q && std::atoi(q) >= 8) {
+        // A host that starts the process with GPU_MAX_HW_QUEUES >= 8 (read by the HIP runtime when IT initialises,
+        // which may be long before this library is loaded -- the library cannot tell, so it does not guess from the
+        // variable) says so with DLIMGEDIT_PLAIN_STREAMS=1: plain streams then do slightly better (+1 %).
+        static const bool plain = [] { const char* e = std::getenv("DLIMGEDIT_PLAIN_STREAMS"); return e && std::atoi(e) != 0; }();
+        if (plain) {
             HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
         } else {
             int least = 0, greatest = 0;
@@ -252,7 +257,7 @@ SamModel::SamModel(std::shared_ptr<SamWeights const> weights, int lane_index)
             HIP_CHECK(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, prio));
         }
     }
-    HIP_CHECK(hipEventCreateWithFlags(&upload_done_, hipEventDisableTiming));
+    for (auto& st : stage_) HIP_CHECK(hipEventCreateWithFlags(&st.copied, hipEventDisableTiming));
     for (auto& e : prompt_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 }
 
@@ -263,8 +268,11 @@ SamModel::~SamModel() {
         (void)hipEventDestroy(p.b);
     }
     for (auto e : event_pool_) (void)hipEventDestroy(e);
-    if (upload_done_) (void)hipEventDestroy(upload_done_);
-    if (resize_upload_done_) (void)hipEventDestroy(resize_upload_done_);
+    for (auto e : done_pool_) (void)hipEventDestroy(e);
+    for (auto& st : stage_)
+        if (st.copied) (void)hipEventDestroy(st.copied);
+    for (auto& m : mask_slots_)
+        if (m->done) (void)hipEventDestroy(m->done);
     for (auto e : prompt_done_)
         if (e) (void)hipEventDestroy(e);
     if (stream_) (void)hipStreamDestroy(stream_);
@@ -323,11 +331,37 @@ template <typename F> void SamModel::timed(Stage st, double work, F&& launch) {
     if (pending_.size() > 8192) flush_events();
 }
 
-void SamModel::gemm(k::GemmArgs const& a) {
+void SamModel::gemm(k::GemmArgs const& args) {
+    k::GemmArgs a = args;
+    a.shared_gpu = shared_gpu_;
+    a.unit_rows = kTokens;
     timed(ST_GEMM, 2.0 * a.M * a.N * a.K, [&] { k::gemm(a, stream_); });
 }
 
 void SamModel::synchronize() { HIP_CHECK(hipStreamSynchronize(stream_)); }
+
+hipEvent_t SamModel::completion() {
+    hipEvent_t e = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(done_mutex_);
+        if (!done_pool_.empty()) {
+            e = done_pool_.back();
+            done_pool_.pop_back();
+        }
+    }
+    if (!e) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(e, stream_));
+    return e;
+}
+
+void SamModel::wait_and_recycle(hipEvent_t e) {
+    const hipError_t err = hipEventSynchronize(e);
+    {
+        std::lock_guard<std::mutex> lock(done_mutex_);
+        done_pool_.push_back(e);
+    }
+    HIP_CHECK(err);
+}
 
 // ---------------------------------------------------------------------------------------------
 // encoder
@@ -362,6 +396,22 @@ void SamModel::preprocess_device_image(int slot, int batch, uint8_t const* dev_p
     });
 }
 
+// Packs `rows` rows of `row_bytes` bytes into the next entry of the pinned staging ring and returns it; *copied is the
+// event the caller records behind its copy out of the entry (the entry is not touched again before that event).
+uint8_t* SamModel::stage_rows(uint8_t const* pixels, size_t row_bytes, int rows, int stride, hipEvent_t* copied) {
+    ImageStage& st = stage_[stage_seq_++ % kStageRing];
+    HIP_CHECK(hipEventSynchronize(st.copied));       // the copy that last read this entry has run
+    st.pin.reserve(row_bytes * rows);                // (re-allocation is safe for the same reason)
+    uint8_t* pin = static_cast<uint8_t*>(st.pin.get());
+    if ((size_t)stride == row_bytes) {
+        std::memcpy(pin, pixels, row_bytes * rows);
+    } else {
+        for (int y = 0; y < rows; ++y) std::memcpy(pin + y * row_bytes, pixels + (size_t)y * stride, row_bytes);
+    }
+    *copied = st.copied;
+    return pin;
+}
+
 void SamModel::upload_image(int slot, int batch, uint8_t const* pixels, int w, int h, int stride, int channels) {
     DLIMG_ASSERT(slot >= 0 && slot < batch);
     DLIMG_ASSERT(w > 0 && h > 0 && w <= kImageSize && h <= kImageSize);
@@ -369,23 +419,25 @@ void SamModel::upload_image(int slot, int batch, uint8_t const* pixels, int w, i
     const int bytes = channels > 4 ? 4 : channels;
     const size_t row = (size_t)w * bytes;
     const size_t slot_bytes = (size_t)kImageSize * kImageSize * 4;
-    img_pinned_.reserve((size_t)batch * slot_bytes);
-    uint8_t* pin = static_cast<uint8_t*>(img_pinned_.get()) + slot * slot_bytes;
     // Rows are packed on the way (the reference's create_image_tensor assumes packed rows when no
     // resize happens, segmentation.cpp:81-106; honouring the stride is identical for packed views).
-    if (slot == 0) HIP_CHECK(hipEventSynchronize(upload_done_));     // previous batch's copies have left the staging area
-    for (int y = 0; y < h; ++y) std::memcpy(pin + y * row, pixels + (size_t)y * stride, row);
+    hipEvent_t copied = nullptr;
+    uint8_t* pin = stage_rows(pixels, row, h, stride, &copied);
     uint8_t* dev = img_dev_.get() + slot * slot_bytes;
     HIP_CHECK(hipMemcpyAsync(dev, pin, row * h, hipMemcpyHostToDevice, stream_));
-    if (slot == batch - 1) HIP_CHECK(hipEventRecord(upload_done_, stream_));
+    HIP_CHECK(hipEventRecord(copied, stream_));
     preprocess_device_image(slot, batch, dev, w, h, (int)row, channels);
 }
 
-SamModel::AxisDev const& SamModel::axis_table(int in_size, int out_size) {
-    for (auto const& a : axis_cache_)
-        if (a->in_size == in_size && a->out_size == out_size) return *a;
+std::shared_ptr<SamModel::AxisDev const> SamModel::axis_table(int in_size, int out_size) {
+    for (size_t i = 0; i < axis_cache_.size(); ++i)
+        if (axis_cache_[i]->in_size == in_size && axis_cache_[i]->out_size == out_size) {
+            // most recently used entry last; eviction takes from the front
+            std::rotate(axis_cache_.begin() + i, axis_cache_.begin() + i + 1, axis_cache_.end());
+            return axis_cache_.back();
+        }
     AxisTable t = make_axis_table(in_size, out_size);
-    auto a = std::make_unique<AxisDev>();
+    auto a = std::make_shared<AxisDev>();
     a->in_size = in_size;
     a->out_size = out_size;
     a->taps = t.taps;
@@ -395,9 +447,14 @@ SamModel::AxisDev const& SamModel::axis_table(int in_size, int out_size) {
     HIP_CHECK(hipMemcpy(a->first.get(), t.first.data(), t.first.size() * sizeof(int), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(a->count.get(), t.count.data(), t.count.size() * sizeof(int), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(a->coef.get(), t.coef.data(), t.coef.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (axis_cache_.size() >= 64) axis_cache_.erase(axis_cache_.begin());
-    axis_cache_.push_back(std::move(a));
-    return *axis_cache_.back();
+    if (axis_cache_.size() >= kAxisCacheEntries) {
+        // The entry's device tables may still be read by a resize kernel queued on this lane's stream; callers hold
+        // their own reference for the duration of the call, but the kernel outlives the call.
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        axis_cache_.erase(axis_cache_.begin());
+    }
+    axis_cache_.push_back(a);
+    return a;
 }
 
 void SamModel::upload_and_resize_image(int slot, int batch, uint8_t const* pixels, int w, int h, int stride, int channels,
@@ -414,21 +471,21 @@ void SamModel::upload_and_resize_image(int slot, int batch, uint8_t const* pixel
         srgb_encode_.reserve(104);
         HIP_CHECK(hipMemcpy(srgb_decode_.get(), lut, sizeof(lut), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(srgb_encode_.get(), kSrgbEncodeTab4, sizeof(kSrgbEncodeTab4), hipMemcpyHostToDevice));
-        HIP_CHECK(hipEventCreateWithFlags(&resize_upload_done_, hipEventDisableTiming));
     }
-    AxisDev const& ax = axis_table(w, rw);
-    AxisDev const& ay = axis_table(h, rh);
-    // the source image, its fp32 intermediate and the staging area are re-used by the next resize:
-    // everything queued on them must have run before they are touched or re-allocated
-    HIP_CHECK(hipEventSynchronize(resize_upload_done_));
+    // both tables are held by value: looking up the second axis may evict the entry of the first
+    const std::shared_ptr<AxisDev const> axp = axis_table(w, rw), ayp = axis_table(h, rh);
+    AxisDev const& ax = *axp;
+    AxisDev const& ay = *ayp;
+    // the source image and its fp32 intermediate are re-used by the next resize in stream order; growing them
+    // frees memory that queued kernels may still read, so everything queued runs first
     if (row * h > resize_src_.capacity() || (size_t)h * rw * bytes > resize_tmp_.capacity())
         HIP_CHECK(hipStreamSynchronize(stream_));
-    resize_pinned_.reserve(row * h);
     resize_src_.reserve(row * h);
     resize_tmp_.reserve((size_t)h * rw * bytes);
-    uint8_t* pin = static_cast<uint8_t*>(resize_pinned_.get());
-    for (int y = 0; y < h; ++y) std::memcpy(pin + y * row, pixels + (size_t)y * stride, row);
+    hipEvent_t copied = nullptr;
+    uint8_t* pin = stage_rows(pixels, row, h, stride, &copied);
     HIP_CHECK(hipMemcpyAsync(resize_src_.get(), pin, row * h, hipMemcpyHostToDevice, stream_));
+    HIP_CHECK(hipEventRecord(copied, stream_));
     uint8_t* dev = img_dev_.get() + (size_t)slot * kImageSize * kImageSize * 4;
     k::ResizeAxis kx{ax.first.get(), ax.count.get(), ax.coef.get(), ax.taps, rw};
     k::ResizeAxis ky{ay.first.get(), ay.count.get(), ay.coef.get(), ay.taps, rh};
@@ -436,11 +493,10 @@ void SamModel::upload_and_resize_image(int slot, int batch, uint8_t const* pixel
         k::resize_srgb(resize_src_.get(), w, h, (int)row, bytes, kx, ky, srgb_decode_.get(), srgb_encode_.get(),
                        resize_tmp_.get(), dev, stream_);
     });
-    HIP_CHECK(hipEventRecord(resize_upload_done_, stream_));
     preprocess_device_image(slot, batch, dev, rw, rh, rw * bytes, channels);
 }
 
-void SamModel::encode(int batch) {
+void SamModel::encode(int batch, float* const* emb_dst) {
     SamWeights const& W = *weights_;
     DLIMG_ASSERT(batch > 0 && batch <= enc_batch_);
     const int D = W.geom_.embed_dim, H = W.geom_.num_heads, hd = W.geom_.head_dim(), mlp = W.geom_.mlp_dim;
@@ -458,7 +514,9 @@ void SamModel::encode(int batch) {
         a.out_f32 = x_.get(); a.ldc32 = D; a.M = M; a.N = D;
         if (fused) {
             a.out_h = xn_.get(); a.ldc16 = D; a.stats_out = xstat_.get();
-            stat_groups = D / k::gemm_tile_columns(a);
+            a.shared_gpu = shared_gpu_;
+            a.unit_rows = kTokens;
+            stat_groups = D / k::gemm_choose_tile(a);    // the launch below uses exactly this tile (a.tile)
         }
     };
     auto reads_stream = [&](k::GemmArgs& a, LinearH const& lin, NormW const& norm) {
@@ -532,10 +590,18 @@ void SamModel::encode(int batch) {
     g.A = hid_.get(); g.lda = 9 * kEmbedDim; g.W = W.neck2_.w.get(); g.ldw = 9 * kEmbedDim;
     g.out_f32 = neck_f32_.get(); g.ldc32 = kEmbedDim; g.M = M; g.N = kEmbedDim; g.K = 9 * kEmbedDim;
     gemm(g);
+    // the embedding goes straight into the handle's storage when there is one image; a batch is copied out per image
+    float* direct = (emb_dst && batch == 1 && emb_dst[0]) ? emb_dst[0] : nullptr;
     timed(ST_LAYERNORM, (double)M * kEmbedDim * 8, [&] {
-        k::layernorm(neck_f32_.get(), W.neck_ln2_.w.get(), W.neck_ln2_.b.get(), kLnEps, M, kEmbedDim, k::ACT_NONE, emb_.get(),
-                     nullptr, stream_);
+        k::layernorm(neck_f32_.get(), W.neck_ln2_.w.get(), W.neck_ln2_.b.get(), kLnEps, M, kEmbedDim, k::ACT_NONE,
+                     direct ? direct : emb_.get(), nullptr, stream_);
     });
+    if (emb_dst && !direct) {
+        const size_t n = (size_t)kTokens * kEmbedDim;
+        for (int i = 0; i < batch; ++i)
+            if (emb_dst[i])
+                HIP_CHECK(hipMemcpyAsync(emb_dst[i], emb_.get() + i * n, n * sizeof(float), hipMemcpyDeviceToDevice, stream_));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -608,6 +674,8 @@ void SamModel::decode(float const* const* emb, float const* coords, float const*
             k::GemmArgs g;
             g.A = A; g.lda = K; g.W = l.w.get(); g.ldw = K; g.bias = l.b.get();
             g.out_h = out_h; g.ldc16 = ldc; g.M = M; g.N = l.out; g.K = K;
+            g.shared_gpu = shared_gpu_;
+            g.unit_rows = kTokens;
             k::gemm(g, s);
         };
         // tokens attend to the image: K = kq_h[:, :128] (or final K), V = v_h
@@ -626,17 +694,17 @@ void SamModel::decode(float const* const* emb, float const* coords, float const*
             lin(q, nullptr, L.self_attn.v, nullptr, tv_.get(), 0);
             k::token_self_attention(tq_.get(), tk_.get(), tv_.get(), tatt_.get(), P, s);
             lin(tatt_.get(), nullptr, L.self_attn.o, i == 0 ? nullptr : q, q, 0);
-            ln_tokens(L.ln1, kLnEps);
+            ln_tokens(L.ln1, kDecLnEps);
             // (2) tokens -> image
             k::add_cast(keys_.get(), W.image_pe_.get(), (size_t)kTokens * 256, (size_t)M * 256, nullptr, kp_h_.get(), s);
             img_gemm(kp_h_.get(), 256, L.img_kq, kq_h_.get(), 256);
             img_gemm(keys_h_.get(), 256, L.img_v, v_h_.get(), 128);
             token_to_image(L.t2i_q, L.t2i_o, kq_h_.get(), 256);
-            ln_tokens(L.ln2, kLnEps);
+            ln_tokens(L.ln2, kDecLnEps);
             // (3) token MLP
             lin(q, nullptr, L.mlp1, nullptr, tmlp_.get(), 1);
             lin(tmlp_.get(), nullptr, L.mlp2, q, q, 0);
-            ln_tokens(L.ln3, kLnEps);
+            ln_tokens(L.ln3, kDecLnEps);
             // (4) image -> tokens
             lin(q, qpe, L.i2t_k, nullptr, tk_.get(), 0);
             lin(q, nullptr, L.i2t_v, nullptr, tv_.get(), 0);
@@ -645,8 +713,10 @@ void SamModel::decode(float const* const* emb, float const* coords, float const*
             g.A = att_img_h_.get(); g.lda = 128; g.W = L.i2t_o.w.get(); g.ldw = 128; g.bias = L.i2t_o.b.get();
             g.resid = keys_.get(); g.ldr = 256; g.resid_mod = M; g.out_f32 = keys_.get(); g.ldc32 = 256;
             g.M = M; g.N = 256; g.K = 128;
+            g.shared_gpu = shared_gpu_;
+            g.unit_rows = kTokens;
             k::gemm(g, s);
-            k::layernorm(keys_.get(), L.ln4.w.get(), L.ln4.b.get(), kLnEps, M, 256, k::ACT_NONE, keys_.get(),
+            k::layernorm(keys_.get(), L.ln4.w.get(), L.ln4.b.get(), kDecLnEps, M, 256, k::ACT_NONE, keys_.get(),
                          keys_h_.get(), s);
         }
         // final token -> image attention
@@ -654,18 +724,22 @@ void SamModel::decode(float const* const* emb, float const* coords, float const*
         img_gemm(kp_h_.get(), 256, W.final_k_, kq_h_.get(), 128);
         img_gemm(keys_h_.get(), 256, W.final_v_, v_h_.get(), 128);
         token_to_image(W.final_q_, W.final_o_, kq_h_.get(), 128);
-        ln_tokens(W.ln_final_, 1e-5f);
+        ln_tokens(W.ln_final_, kDecLnEps);
 
         // upscaling: ConvT(256->64) -> LN2d -> GELU -> ConvT(64->32) -> GELU, sub-pixels kept in quad order
         k::GemmArgs g;
         g.A = keys_h_.get(); g.lda = 256; g.W = W.up1_.w.get(); g.ldw = 256; g.bias = W.up1_.b.get();
         g.out_f32 = up1_f32_.get(); g.ldc32 = 256; g.M = M; g.N = 256; g.K = 256;
+        g.shared_gpu = shared_gpu_;
+        g.unit_rows = kTokens;
         k::gemm(g, s);
         k::layernorm(up1_f32_.get(), W.up_ln_.w.get(), W.up_ln_.b.get(), kLnEps, M * 4, 64, k::ACT_GELU, nullptr,
                      up1_h_.get(), s);
         g = k::GemmArgs{};
         g.A = up1_h_.get(); g.lda = 64; g.W = W.up2_.w.get(); g.ldw = 64; g.bias = W.up2_.b.get(); g.act = k::ACT_GELU;
         g.out_f32 = up_.get(); g.ldc32 = 128; g.M = M * 4; g.N = 128; g.K = 64;
+        g.shared_gpu = shared_gpu_;
+        g.unit_rows = kTokens * 4;
         k::gemm(g, s);
 
         k::HeadWeights hw;
@@ -687,29 +761,78 @@ void SamModel::masks_on_device(k::PostJob const* jobs, int count) {
     timed(ST_POST, bytes, [&] { k::postprocess_masks(jobs, count, stream_); });
 }
 
-void SamModel::masks_to_host(k::PostJob const* jobs, int count) {
+SamModel::MaskSlot& SamModel::acquire_mask_slot() {
+    {
+        std::lock_guard<std::mutex> lock(done_mutex_);
+        if (!mask_free_.empty()) {
+            MaskSlot* s = mask_free_.back();
+            mask_free_.pop_back();
+            return *s;
+        }
+    }
+    // as many slots come into being as there are mask requests in flight on this lane at once
+    auto fresh = std::make_unique<MaskSlot>();
+    HIP_CHECK(hipSetDevice(device_));
+    HIP_CHECK(hipEventCreateWithFlags(&fresh->done, hipEventDisableTiming));
+    std::lock_guard<std::mutex> lock(done_mutex_);
+    mask_slots_.push_back(std::move(fresh));
+    return *mask_slots_.back();
+}
+
+void SamModel::release_mask_slot(MaskSlot& s) {
+    std::lock_guard<std::mutex> lock(done_mutex_);
+    mask_free_.push_back(&s);
+}
+
+static size_t mask_bytes(k::PostJob const& j) { return ((size_t)j.out_w * j.out_h + 255) / 256 * 256; }
+
+void SamModel::enqueue_masks(MaskSlot& slot, k::PostJob const* jobs, int count, int iou_count) {
     if (count <= 0) return;
     size_t total = 0;
-    for (int i = 0; i < count; ++i) total += ((size_t)jobs[i].out_w * jobs[i].out_h + 255) / 256 * 256;
-    mask_dev_.reserve(total);
-    mask_pinned_.reserve(total);
+    for (int i = 0; i < count; ++i) total += mask_bytes(jobs[i]);
+    slot.iou_offset = total;
+    const size_t with_iou = total + (size_t)iou_count * sizeof(float);
+    // the slot is ours, and its previous user waited for the slot's event before letting go of it
+    slot.dev.reserve(with_iou);
+    slot.pin.reserve(with_iou);
     std::vector<k::PostJob> dev_jobs(jobs, jobs + count);
     size_t off = 0;
     double bytes = 0;
     for (int i = 0; i < count; ++i) {
-        dev_jobs[i].dst = mask_dev_.get() + off;
-        off += ((size_t)jobs[i].out_w * jobs[i].out_h + 255) / 256 * 256;
+        dev_jobs[i].dst = slot.dev.get() + off;
+        off += mask_bytes(jobs[i]);
         bytes += (double)kLowRes * kLowRes * 4 + (double)jobs[i].out_w * jobs[i].out_h;
     }
     timed(ST_POST, bytes, [&] { k::postprocess_masks(dev_jobs.data(), count, stream_); });
-    HIP_CHECK(hipMemcpyAsync(mask_pinned_.get(), mask_dev_.get(), total, hipMemcpyDeviceToHost, stream_));
-    HIP_CHECK(hipStreamSynchronize(stream_));
-    off = 0;
+    if (iou_count > 0)
+        HIP_CHECK(hipMemcpyAsync(slot.dev.get() + total, iou_.get(), (size_t)iou_count * sizeof(float),
+                                 hipMemcpyDeviceToDevice, stream_));
+    HIP_CHECK(hipMemcpyAsync(slot.pin.get(), slot.dev.get(), with_iou, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipEventRecord(slot.done, stream_));
+}
+
+void SamModel::finish_masks(MaskSlot& slot, k::PostJob const* jobs, int count, float* iou_out, int iou_count) {
+    if (count <= 0) return;
+    HIP_CHECK(hipEventSynchronize(slot.done));
+    uint8_t const* pin = static_cast<uint8_t const*>(slot.pin.get());
+    size_t off = 0;
     for (int i = 0; i < count; ++i) {
-        const size_t n = (size_t)jobs[i].out_w * jobs[i].out_h;
-        std::memcpy(jobs[i].dst, static_cast<uint8_t*>(mask_pinned_.get()) + off, n);
-        off += (n + 255) / 256 * 256;
+        std::memcpy(jobs[i].dst, pin + off, (size_t)jobs[i].out_w * jobs[i].out_h);
+        off += mask_bytes(jobs[i]);
     }
+    if (iou_out && iou_count > 0) std::memcpy(iou_out, pin + slot.iou_offset, (size_t)iou_count * sizeof(float));
+}
+
+void SamModel::masks_to_host(k::PostJob const* jobs, int count) {
+    MaskSlot& slot = acquire_mask_slot();
+    try {
+        enqueue_masks(slot, jobs, count, 0);
+        finish_masks(slot, jobs, count, nullptr, 0);
+    } catch (...) {
+        release_mask_slot(slot);
+        throw;
+    }
+    release_mask_slot(slot);
 }
 
 }  // namespace dlimg

@@ -13,6 +13,7 @@
 #include "weights.hpp"
 
 #include <array>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -105,7 +106,7 @@ class SamModel {
     // let independent images overlap on the GPU (tails and small kernels of one image hide behind the
     // large kernels of another) -- the serving counterpart of the reference's "Environment is
     // thread-safe" contract (reference: src/include/dlimgedit/dlimgedit.hpp:98-101).
-    explicit SamModel(std::shared_ptr<SamWeights const> weights, int lane_index = 0);
+    explicit SamModel(std::shared_ptr<SamWeights const> weights, int lane_index = 0, int lane_count = 1);
     ~SamModel();
     SamModel(SamModel const&) = delete;
     SamModel& operator=(SamModel const&) = delete;
@@ -115,7 +116,10 @@ class SamModel {
     std::mutex& mutex() { return mutex_; }
     int device() const { return device_; }
 
-    // All methods below require mutex() to be held by the caller.
+    // All methods below require mutex() to be held by the caller, unless stated otherwise.  The mutex covers the
+    // ENQUEUE of a request (host-side state, staging areas), not its execution: workspaces are re-used in stream
+    // order, so a caller records completion(), releases the mutex and waits for its own event while the next
+    // request is already being enqueued behind it.
 
     // Host image (already at its encoder resolution: longest side 1024) -> slot `slot` of the patch
     // matrix.  Copies through pinned staging and runs the pre-processing kernel.
@@ -126,8 +130,9 @@ class SamModel {
                                  int rw, int rh);
     // Device-resident image variant (used by the batch benchmark so PCIe is outside the timed region).
     void preprocess_device_image(int slot, int batch, uint8_t const* dev_pixels, int w, int h, int stride, int channels);
-    // Runs the encoder on `batch` uploaded images; embeddings [batch][4096][256] fp32 in embeddings().
-    void encode(int batch);
+    // Runs the encoder on `batch` uploaded images; embeddings [batch][4096][256] fp32 in embeddings() and, where
+    // emb_dst[i] is given, in that device buffer too (batch 1: written there directly).
+    void encode(int batch, float* const* emb_dst = nullptr);
     float const* embeddings() const { return emb_.get(); }
 
     // Decoder for `count` prompts. emb[i]: device embedding of prompt i's image; coords [count][2][2],
@@ -136,13 +141,32 @@ class SamModel {
     float const* logits() const { return logits_.get(); }
     float const* iou() const { return iou_.get(); }
 
-    // Post-process to host masks. jobs[i].dst must be a HOST pointer of out_w*out_h bytes; the kernel
-    // writes a device staging buffer which is then copied out.
+    // Post-process to host masks in two steps so that the wait happens outside mutex():
+    //   slot = acquire_mask_slot()               no mutex needed; a free staging slot (or a new one: never blocks),
+    //                                            the caller's until release_mask_slot
+    //   enqueue_masks(slot, jobs, n, n_iou)      under mutex(): kernel -> device staging -> pinned staging (async),
+    //                                            plus the first n_iou IoU predictions of the last decode()
+    //   finish_masks(slot, jobs, n, iou_out)     no mutex: waits for the slot's event, copies into jobs[i].dst (HOST
+    //                                            pointers of out_w*out_h bytes) and iou_out
+    struct MaskSlot {
+        DeviceBuffer<uint8_t> dev;
+        PinnedBuffer pin;
+        hipEvent_t done = nullptr;
+        size_t iou_offset = 0;
+    };
+    MaskSlot& acquire_mask_slot();
+    void release_mask_slot(MaskSlot& s);
+    void enqueue_masks(MaskSlot& slot, k::PostJob const* jobs, int count, int iou_count);
+    void finish_masks(MaskSlot& slot, k::PostJob const* jobs, int count, float* iou_out, int iou_count);
+    // Blocking convenience form of the three calls above (mutex() held throughout).
     void masks_to_host(k::PostJob const* jobs, int count);
     // Same kernel, but jobs[i].dst are DEVICE pointers and nothing is copied or waited for.
     void masks_on_device(k::PostJob const* jobs, int count);
 
     void synchronize();
+    // Event recorded behind everything enqueued so far; wait for it WITHOUT mutex(), then give it back.
+    hipEvent_t completion();
+    void wait_and_recycle(hipEvent_t e);      // no mutex needed
 
     void set_profiling(bool on);
     StageStats take_stats();
@@ -155,6 +179,7 @@ class SamModel {
     void flush_events();
 
     int device_ = 0;
+    bool shared_gpu_ = false;            // other lanes run on this device too (GEMM tile choice, kernels/gemm.hip)
     hipStream_t stream_ = nullptr;
     std::mutex mutex_;
 
@@ -163,8 +188,12 @@ class SamModel {
     // ---- encoder workspace (sized for enc_batch_ images)
     int enc_batch_ = 0;
     DeviceBuffer<uint8_t> img_dev_;
-    PinnedBuffer img_pinned_;
-    hipEvent_t upload_done_ = nullptr;    // guards re-use of img_pinned_ by the next upload
+    // pinned staging for host images: a ring, each entry guarded by the event of the copy that last read it
+    static constexpr int kStageRing = 4;
+    struct ImageStage { PinnedBuffer pin; hipEvent_t copied = nullptr; };
+    ImageStage stage_[kStageRing];
+    unsigned stage_seq_ = 0;
+    uint8_t* stage_rows(uint8_t const* pixels, size_t row_bytes, int rows, int stride, hipEvent_t* copied);
     DeviceBuffer<half_t> patches_, xn_, qkv_, att_, hid_;
     DeviceBuffer<float> x_, xstat_, neck_f32_, emb_;
 
@@ -174,22 +203,22 @@ class SamModel {
         DeviceBuffer<int> first, count;
         DeviceBuffer<float> coef;
     };
-    AxisDev const& axis_table(int in_size, int out_size);
-    std::vector<std::unique_ptr<AxisDev>> axis_cache_;
+    std::shared_ptr<AxisDev const> axis_table(int in_size, int out_size);
+    static constexpr size_t kAxisCacheEntries = 64;
+    std::vector<std::shared_ptr<AxisDev const>> axis_cache_;     // least recently used first
     DeviceBuffer<float> srgb_decode_;
     DeviceBuffer<uint32_t> srgb_encode_;
     DeviceBuffer<uint8_t> resize_src_;
     DeviceBuffer<float> resize_tmp_;
-    PinnedBuffer resize_pinned_;
-    hipEvent_t resize_upload_done_ = nullptr;
 
     // ---- decoder workspace (sized for dec_count_ prompts)
     int dec_count_ = 0;
     DeviceBuffer<float> keys_, up1_f32_, up_, logits_, iou_, hyper_;
     DeviceBuffer<half_t> keys_h_, kp_h_, kq_h_, v_h_, att_img_h_, up1_h_;
     DeviceBuffer<float> coords_, tokens_, queries_, tq_, tk_, tv_, tatt_, tmlp_, t2i_part_;
-    DeviceBuffer<uint8_t> mask_dev_;
-    PinnedBuffer mask_pinned_, prompt_pinned_;
+    std::vector<std::unique_ptr<MaskSlot>> mask_slots_;     // all ever made (owned), guarded by done_mutex_
+    std::vector<MaskSlot*> mask_free_;                      // those not handed out, guarded by done_mutex_
+    PinnedBuffer prompt_pinned_;
     static constexpr int kPromptRing = 8;           // pinned prompt staging slots, re-used round robin
     hipEvent_t prompt_done_[kPromptRing] = {};
     unsigned prompt_seq_ = 0;
@@ -200,6 +229,8 @@ class SamModel {
     std::vector<Pending> pending_;
     std::vector<hipEvent_t> event_pool_;
     StageStats stats_;
+    std::mutex done_mutex_;
+    std::vector<hipEvent_t> done_pool_;   // completion() events, guarded by done_mutex_ (taken without mutex_)
 };
 
 }  // namespace dlimg

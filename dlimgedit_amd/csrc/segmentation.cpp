@@ -1,7 +1,13 @@
 #include "segmentation.hpp"
 
+#include "roctx.hpp"
+
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
+#include <exception>
+#include <thread>
 #include <vector>
 
 namespace dlimg {
@@ -45,12 +51,24 @@ void check_image(dlimg_ImageView const& image) {
 }
 
 SegmentationImpl::SegmentationImpl(EnvironmentImpl& env) : env_(env) {
-    (void)env.lane_count();     // loads the model (and reports a missing weight file) at the same point as the reference
+    env.load_all();     // loads the model (and reports a missing weight file) at the same point as the reference
 }
 
-float* SegmentationImpl::embedding_storage() {
-    embedding_.reserve((size_t)kTokens * kEmbedDim);
-    return embedding_.get();
+SegmentationImpl::~SegmentationImpl() {
+    if (pool_) pool_->give(embedding_);
+}
+
+float* SegmentationImpl::embedding_storage(int replica) {
+    if (embedding_ && replica != replica_) {
+        pool_->give(embedding_);
+        embedding_ = nullptr;
+    }
+    replica_ = replica;
+    if (!embedding_) {
+        pool_ = env_.embedding_pool(replica);
+        embedding_ = pool_->take();
+    }
+    return embedding_;
 }
 
 namespace {
@@ -66,6 +84,43 @@ void stage_image(SamModel& model, int slot, int batch, dlimg_ImageView const& im
     }
 }
 
+// Runs body(replica) for every replica in `used`: inline when there is one, on one host thread per GPU otherwise
+// (staging copies and kernel launches of different GPUs then proceed side by side).  The first exception wins.
+template <typename F> void for_each_replica(std::vector<int> const& used, F&& body) {
+    if (used.size() == 1) {
+        body(used[0]);
+        return;
+    }
+    std::vector<std::exception_ptr> errors(used.size());
+    std::vector<std::thread> workers;
+    for (size_t t = 0; t < used.size(); ++t)
+        workers.emplace_back([&, t] {
+            try {
+                body(used[t]);
+            } catch (...) {
+                errors[t] = std::current_exception();
+            }
+        });
+    for (auto& w : workers) w.join();
+    for (auto& e : errors)
+        if (e) std::rethrow_exception(e);
+}
+
+struct Waiting { SamModel* model; hipEvent_t done; };
+
+void wait_all(std::vector<Waiting>& waiting) {
+    std::exception_ptr first;
+    for (auto& w : waiting) {
+        try {
+            w.model->wait_and_recycle(w.done);
+        } catch (...) {
+            if (!first) first = std::current_exception();
+        }
+    }
+    waiting.clear();
+    if (first) std::rethrow_exception(first);
+}
+
 }  // namespace
 
 void SegmentationImpl::process(dlimg_ImageView const& image) {
@@ -73,32 +128,84 @@ void SegmentationImpl::process(dlimg_ImageView const& image) {
     process_batch(env_, &self, &image, 1);
 }
 
+// Independent images: image i goes to replica (GPU) r0 + i mod G and there to the next execution lane, as its own
+// batch-1 pass -- upload, pre-processing and encoder of one image overlap those of the others on the lanes' streams,
+// and the host copies of image i+1 run while image i is on the GPU.  Nothing is exchanged between GPUs.
 void SegmentationImpl::process_batch(EnvironmentImpl& env, SegmentationImpl* const* segs, dlimg_ImageView const* images,
                                      int count) {
     if (count <= 0) return;
-    SamModel& model = env.sam_model();
     for (int i = 0; i < count; ++i) {
         check_image(images[i]);
         segs[i]->image_size_.set(Extent{images[i].width, images[i].height});
     }
-    std::lock_guard<std::mutex> lock(model.mutex());
-    HIP_CHECK(hipSetDevice(model.device()));
-    for (int i = 0; i < count; ++i) stage_image(model, i, count, images[i], segs[i]->image_size_);
-    model.encode(count);
-    const size_t n = (size_t)kTokens * kEmbedDim;
+    const int G = env.replica_count();
+    std::vector<int> replica_of(count), used;
     for (int i = 0; i < count; ++i) {
-        HIP_CHECK(hipMemcpyAsync(segs[i]->embedding_storage(), model.embeddings() + i * n, n * sizeof(float),
-                                 hipMemcpyDeviceToDevice, model.stream()));
+        replica_of[i] = env.next_replica();
+        if (std::find(used.begin(), used.end(), replica_of[i]) == used.end()) used.push_back(replica_of[i]);
     }
-    // process() is synchronous in the reference (Ort::Session::Run returns when the result is
-    // there); errors of this call must surface in this call.
-    model.synchronize();
+    (void)G;
+    static const bool trace = std::getenv("DLIMGEDIT_TIMING") != nullptr;     // diagnostic: host time of the two phases
+    // Images per batched encoder pass.  Results do not depend on it (tiles are chosen per image, kernels/gemm.hip);
+    // throughput does: lanes that start together run the same kernels in lockstep, so a few larger passes on fewer
+    // lanes beat many single-image passes (8 images, ViT-B: 15.2 ms as 8 x 1, 12.5 ms as 2 x 4).  Default: half of the
+    // GPU's share per pass, at most 4; DLIMGEDIT_ENCODE_BATCH overrides (1..16).
+    static const int forced_chunk = [] {
+        const char* e = std::getenv("DLIMGEDIT_ENCODE_BATCH");
+        const int v = e ? std::atoi(e) : 0;
+        return v < 0 ? 0 : (v > 16 ? 16 : v);
+    }();
+    for_each_replica(used, [&](int replica) {
+        HIP_CHECK(hipSetDevice(env.device_of(replica)));
+        std::vector<Waiting> waiting;
+        const auto t0 = std::chrono::steady_clock::now();
+        try {
+            std::vector<int> mine;
+            for (int i = 0; i < count; ++i)
+                if (replica_of[i] == replica) mine.push_back(i);
+            // chunks of up to `chunk` images: one batched pass per chunk on the next lane
+            const size_t chunk = forced_chunk ? (size_t)forced_chunk : std::min<size_t>(4, (mine.size() + 1) / 2);
+            for (size_t base = 0; base < mine.size(); base += chunk) {
+                const int n = (int)std::min<size_t>(chunk, mine.size() - base);
+                std::vector<float*> emb(n);
+                for (int j = 0; j < n; ++j) emb[j] = segs[mine[base + j]]->embedding_storage(replica);
+                SamModel& model = env.next_lane(replica);
+                roctx::Range range("dlimg.process");
+                std::lock_guard<std::mutex> lock(model.mutex());
+                {
+                    roctx::Range r("dlimg.pre");
+                    for (int j = 0; j < n; ++j) {
+                        const int i = mine[base + j];
+                        stage_image(model, j, n, images[i], segs[i]->image_size_);
+                    }
+                }
+                {
+                    roctx::Range r("dlimg.encode");
+                    model.encode(n, emb.data());
+                }
+                waiting.push_back(Waiting{&model, model.completion()});
+            }
+        } catch (...) {
+            try { wait_all(waiting); } catch (...) {}
+            throw;
+        }
+        // process() is synchronous in the reference (Ort::Session::Run returns when the result is
+        // there); errors of this call must surface in this call.
+        const auto t1 = std::chrono::steady_clock::now();
+        wait_all(waiting);
+        if (trace) {
+            const auto t2 = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "process_batch replica %d: enqueue %.3f ms, wait %.3f ms\n", replica,
+                         std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                         std::chrono::duration<double, std::milli>(t2 - t1).count());
+        }
+    });
 }
 
 void SegmentationImpl::compute_mask(Point const* point, Region const* region, uint8_t* const out_masks[3],
                                     float out_accuracy[3]) const {
     DLIMG_ASSERT(point || region);
-    DLIMG_ASSERT(embedding_.get() != nullptr);
+    DLIMG_ASSERT(embedding_ != nullptr);
     float coords[4], labels[2];
     pack_prompt(image_size_, point, region, coords, labels);
     const bool is_single_mask = out_masks[1] == nullptr;
@@ -108,42 +215,57 @@ void SegmentationImpl::compute_mask(Point const* point, Region const* region, ui
         for (int i = 0; i < 3; ++i) DLIMG_ASSERT(out_masks[i] != nullptr);
     }
 
-    SamModel& model_ = env_.sam_model();
-    std::lock_guard<std::mutex> lock(model_.mutex());
-    HIP_CHECK(hipSetDevice(model_.device()));
-    float const* emb = embedding_.get();
-    model_.decode(&emb, coords, labels, 1);
-
+    HIP_CHECK(hipSetDevice(env_.device_of(replica_)));
+    SamModel& model_ = env_.next_lane(replica_);
     const Extent o = image_size_.original, r = image_size_.resized;
     k::PostJob jobs[3];
     int n_jobs = 0;
-    if (is_single_mask) {
-        // single-mask decoder: best of the four by SamOnnxModel.select_masks, chosen on the device
-        jobs[n_jobs++] = k::PostJob{model_.logits(), model_.iou(), out_masks[0], o.width, o.height, r.width, r.height};
-    } else {
-        // multi-mask decoder: outputs 1..3 (reference: segmentation.cpp:167-172)
-        for (int i = 0; i < 3; ++i)
-            jobs[n_jobs++] = k::PostJob{model_.logits() + (size_t)(i + 1) * kLowRes * kLowRes, nullptr, out_masks[i],
-                                        o.width, o.height, r.width, r.height};
+    float iou[4] = {0.f, 0.f, 0.f, 0.f};
+    SamModel::MaskSlot& slot = model_.acquire_mask_slot();
+    try {
+        {
+            roctx::Range range("dlimg.compute_mask");
+            std::lock_guard<std::mutex> lock(model_.mutex());
+            float const* emb = embedding_;
+            {
+                roctx::Range rd("dlimg.decode");
+                model_.decode(&emb, coords, labels, 1);
+            }
+            if (is_single_mask) {
+                // single-mask decoder: best of the four by SamOnnxModel.select_masks, chosen on the device
+                jobs[n_jobs++] = k::PostJob{model_.logits(), model_.iou(), out_masks[0], o.width, o.height, r.width, r.height};
+            } else {
+                // multi-mask decoder: outputs 1..3 (reference: segmentation.cpp:167-172)
+                for (int i = 0; i < 3; ++i)
+                    jobs[n_jobs++] = k::PostJob{model_.logits() + (size_t)(i + 1) * kLowRes * kLowRes, nullptr, out_masks[i],
+                                                o.width, o.height, r.width, r.height};
+            }
+            roctx::Range rp("dlimg.post");
+            model_.enqueue_masks(slot, jobs, n_jobs, is_single_mask ? 0 : 4);
+        }
+        model_.finish_masks(slot, jobs, n_jobs, iou, is_single_mask ? 0 : 4);      // waits outside the lane's mutex
+    } catch (...) {
+        model_.release_mask_slot(slot);
+        throw;
     }
-    float iou[4];
-    if (!is_single_mask)
-        HIP_CHECK(hipMemcpyAsync(iou, model_.iou(), sizeof(iou), hipMemcpyDeviceToHost, model_.stream()));
-    model_.masks_to_host(jobs, n_jobs);      // synchronises the stream
+    model_.release_mask_slot(slot);
     if (!is_single_mask)
         for (int i = 0; i < 3; ++i) out_accuracy[i] = iou[i + 1];
 }
 
+// Prompts are grouped by the replica that holds their image's embedding; on each GPU they are cut into chunks of at most
+// kPromptChunk, each chunk decoded as one batch on the next lane, its masks copied out while the next chunk runs.
 void SegmentationImpl::compute_mask_batch(SegmentationImpl const* const* segs, int count, int const* points,
                                           int const* regions, uint8_t* const* out_masks) {
     if (count <= 0) return;
     DLIMG_ASSERT((points != nullptr) != (regions != nullptr));
-    SamModel& model = segs[0]->env_.sam_model();
+    constexpr int kPromptChunk = 8;
+    EnvironmentImpl& env = segs[0]->env_;
     std::vector<float> coords((size_t)count * 4), labels((size_t)count * 2);
-    std::vector<float const*> emb(count);
+    std::vector<int> used;
     for (int i = 0; i < count; ++i) {
-        DLIMG_ASSERT(&segs[i]->env_ == &segs[0]->env_);
-        DLIMG_ASSERT(segs[i]->embedding_.get() != nullptr && out_masks[i] != nullptr);
+        DLIMG_ASSERT(&segs[i]->env_ == &env);
+        DLIMG_ASSERT(segs[i]->embedding_ != nullptr && out_masks[i] != nullptr);
         if (points) {
             Point p{points[i * 2], points[i * 2 + 1]};
             pack_prompt(segs[i]->image_size_, &p, nullptr, &coords[i * 4], &labels[i * 2]);
@@ -151,18 +273,63 @@ void SegmentationImpl::compute_mask_batch(SegmentationImpl const* const* segs, i
             Region r{Point{regions[i * 4], regions[i * 4 + 1]}, Point{regions[i * 4 + 2], regions[i * 4 + 3]}};
             pack_prompt(segs[i]->image_size_, nullptr, &r, &coords[i * 4], &labels[i * 2]);
         }
-        emb[i] = segs[i]->embedding_.get();
+        if (std::find(used.begin(), used.end(), segs[i]->replica_) == used.end()) used.push_back(segs[i]->replica_);
     }
-    std::lock_guard<std::mutex> lock(model.mutex());
-    HIP_CHECK(hipSetDevice(model.device()));
-    model.decode(emb.data(), coords.data(), labels.data(), count);
-    std::vector<k::PostJob> jobs(count);
-    for (int i = 0; i < count; ++i) {
-        const Extent o = segs[i]->image_size_.original, r = segs[i]->image_size_.resized;
-        jobs[i] = k::PostJob{model.logits() + (size_t)i * 4 * kLowRes * kLowRes, model.iou() + (size_t)i * 4,
-                             out_masks[i], o.width, o.height, r.width, r.height};
-    }
-    model.masks_to_host(jobs.data(), count);
+    for_each_replica(used, [&](int replica) {
+        HIP_CHECK(hipSetDevice(env.device_of(replica)));
+        std::vector<int> mine;
+        for (int i = 0; i < count; ++i)
+            if (segs[i]->replica_ == replica) mine.push_back(i);
+        struct Chunk { SamModel* model; SamModel::MaskSlot* slot; std::vector<k::PostJob> jobs; };
+        std::vector<Chunk> chunks;
+        auto finish = [&](Chunk& c) {
+            if (!c.slot) return;
+            SamModel::MaskSlot* slot = c.slot;
+            c.slot = nullptr;
+            try {
+                c.model->finish_masks(*slot, c.jobs.data(), (int)c.jobs.size(), nullptr, 0);
+            } catch (...) {
+                c.model->release_mask_slot(*slot);
+                throw;
+            }
+            c.model->release_mask_slot(*slot);
+        };
+        try {
+            for (size_t base = 0; base < mine.size(); base += kPromptChunk) {
+                const int n = (int)std::min<size_t>(kPromptChunk, mine.size() - base);
+                std::vector<float const*> emb(n);
+                std::vector<float> cc((size_t)n * 4), ll((size_t)n * 2);
+                for (int j = 0; j < n; ++j) {
+                    const int i = mine[base + j];
+                    emb[j] = segs[i]->embedding_;
+                    std::copy_n(&coords[(size_t)i * 4], 4, &cc[(size_t)j * 4]);
+                    std::copy_n(&labels[(size_t)i * 2], 2, &ll[(size_t)j * 2]);
+                }
+                SamModel& model = env.next_lane(replica);
+                // masks of a chunk are copied to the caller while the two chunks behind it are on the GPU
+                if (chunks.size() >= 3) finish(chunks[chunks.size() - 3]);
+                Chunk c{&model, &model.acquire_mask_slot(), std::vector<k::PostJob>(n)};
+                chunks.push_back(std::move(c));
+                Chunk& cur = chunks.back();
+                roctx::Range range("dlimg.compute_masks");
+                std::lock_guard<std::mutex> lock(model.mutex());
+                model.decode(emb.data(), cc.data(), ll.data(), n);
+                for (int j = 0; j < n; ++j) {
+                    const int i = mine[base + j];
+                    const Extent o = segs[i]->image_size_.original, r = segs[i]->image_size_.resized;
+                    cur.jobs[j] = k::PostJob{model.logits() + (size_t)j * 4 * kLowRes * kLowRes, model.iou() + (size_t)j * 4,
+                                             out_masks[i], o.width, o.height, r.width, r.height};
+                }
+                model.enqueue_masks(*cur.slot, cur.jobs.data(), n, 0);
+            }
+            for (auto& c : chunks) finish(c);
+        } catch (...) {
+            for (auto& c : chunks) {
+                try { finish(c); } catch (...) {}
+            }
+            throw;
+        }
+    });
 }
 
 }  // namespace dlimg

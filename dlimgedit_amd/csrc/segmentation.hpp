@@ -52,15 +52,21 @@ class SegmentationImpl {
 
     Extent extent() const { return image_size_.original; }
     ResizeLongestSide const& geometry() const { return image_size_; }
-    float const* embedding() const { return embedding_.get(); }
+    float const* embedding() const { return embedding_; }
+    ~SegmentationImpl();
+    SegmentationImpl(SegmentationImpl const&) = delete;
+    SegmentationImpl& operator=(SegmentationImpl const&) = delete;
     EnvironmentImpl& environment() const { return env_; }
+    int replica() const { return replica_; }      // which entry of the environment's device list holds the embedding
     void set_geometry(Extent e) { image_size_.set(e); }
-    float* embedding_storage();
+    float* embedding_storage(int replica);
 
   private:
     EnvironmentImpl& env_;
+    int replica_ = 0;
     ResizeLongestSide image_size_;
-    DeviceBuffer<float> embedding_;     // [4096][256] fp32, resident
+    float* embedding_ = nullptr;        // [4096][256] fp32, resident on the replica's GPU
+    std::shared_ptr<EmbeddingPool> pool_;   // where embedding_ came from and goes back to
 };
 
 // Validates an image view the way the entry points need it; throws on nonsense.

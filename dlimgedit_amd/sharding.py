@@ -59,17 +59,33 @@ def gather_results(local: Dict[int, np.ndarray], n_items: int, root: int = 0):
     return [merged[i] for i in range(n_items)]
 
 
-def gather_device_masks(mask_tensor, root: int = 0):
-    """RCCL gather of equally sized u8 mask tensors that live on the device (the optional
-    'all masks on one device' mode of SURVEY.md §8e).  mask_tensor: torch.uint8 [B_local, H, W] on cuda.
-    Returns [world*B_local, H, W] on every rank (all_gather; xGMI moves 1 MiB per mask)."""
+def gather_device_masks(mask_tensor, n_items: int = None):
+    """Collective gather of equally sized u8 mask tensors that live on the device (the optional 'all masks on one
+    device' mode of SURVEY.md §8e; RCCL over xGMI when the group's backend is nccl, 1 MiB per 1024x1024 mask).
+    mask_tensor: torch.uint8 [B_local, H, W]; rank r holds items r, r + world, r + 2*world, ... in that order
+    (`assign`), padded to the same B_local on every rank.  Returns [n_items, H, W] in ITEM order on every rank."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size()
-    out = torch.empty((world * mask_tensor.shape[0],) + tuple(mask_tensor.shape[1:]), dtype=mask_tensor.dtype,
+    b_local = mask_tensor.shape[0]
+    out = torch.empty((world * b_local,) + tuple(mask_tensor.shape[1:]), dtype=mask_tensor.dtype,
                       device=mask_tensor.device)
     dist.all_gather_into_tensor(out, mask_tensor.contiguous())
-    return out
+    # rank-major [r][b] -> item-major [b][r]: item index = b * world + r
+    out = out.reshape((world, b_local) + tuple(mask_tensor.shape[1:])).transpose(0, 1)
+    out = out.reshape((world * b_local,) + tuple(mask_tensor.shape[1:]))
+    return out if n_items is None else out[:n_items]
+
+
+def count_ranks(device=None) -> int:
+    """Sum-all-reduce of ones: the number of ranks that really take part in the group's collectives."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    t = torch.ones(1, dtype=torch.int32, device=device or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
 
 
 def run_sharded(n_items: int, fn: Callable[[int], np.ndarray], rank: int, world: int) -> Dict[int, np.ndarray]:

@@ -55,6 +55,11 @@ DLIMG_API int dlimg_amd_synchronize(dlimg_Environment env);
  * Successive requests are spread over the lanes round-robin so independent images overlap on the GPU. */
 DLIMG_API int dlimg_amd_lane_count(dlimg_Environment env);
 
+/* Multi-GPU: number of replicas of the environment (entries of DLIMGEDIT_DEVICES; 1 by default) and, for a
+ * segmentation handle, the replica / HIP device index that holds its embedding (either pointer may be null). */
+DLIMG_API int dlimg_amd_replica_count(dlimg_Environment env);
+DLIMG_API int dlimg_amd_segmentation_device(dlimg_Segmentation seg, int* out_replica, int* out_device);
+
 /* ---- stage clocks (HIP events on the executor's stream) -------------------------------------- */
 #define DLIMG_AMD_STAGE_COUNT 8
 /* stage ids: 0 pre, 1 gemm (all MFMA GEMMs of the encoder), 2 layernorm, 3 attention_window,

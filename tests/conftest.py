@@ -33,6 +33,19 @@ def synthetic_image(seed: int, width: int = 1024, height: int = 1024, channels: 
     return img
 
 
+def halton_points(n: int, width: int, height: int, start: int = 1):
+    """n point prompts on the Halton sequence (bases 2, 3) inside a width x height image."""
+    def radical(i, base):
+        f, r = 1.0, 0.0
+        while i > 0:
+            f /= base
+            r += f * (i % base)
+            i //= base
+        return r
+    return [(min(width - 1, int(radical(i, 2) * width)), min(height - 1, int(radical(i, 3) * height)))
+            for i in range(start, start + n)]
+
+
 @pytest.fixture(scope="session")
 def model_dirs(tmp_path_factory):
     """variant -> (model directory with seeded synthetic weights, params dict, config); built lazily."""
@@ -56,3 +69,12 @@ def iou(a: np.ndarray, b: np.ndarray) -> float:
     a, b = a > 0, b > 0
     union = np.logical_or(a, b).sum()
     return 1.0 if union == 0 else float(np.logical_and(a, b).sum()) / float(union)
+
+
+def single_mask_index(iou4) -> int:
+    """The single-mask decoder graph's choice, restated independently of the oracle: SamOnnxModel.select_masks adds
+    (num_points - 2.5) * [1000, 0, 0, 0] to the four IoU predictions and takes the argmax; dlimgedit always sends two
+    prompt tokens (src/segmentation.cpp:146-152), so token 0 is pushed down by 500 and the winner is the best of
+    tokens 1..3 (the first one on ties, as argmax does)."""
+    score = np.asarray(iou4, np.float32) + np.float32(2 - 2.5) * np.array([1000, 0, 0, 0], np.float32)
+    return int(np.argmax(score))

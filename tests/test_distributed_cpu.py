@@ -30,6 +30,15 @@ def _worker(rank, world, port, n_items, out_dir):
         local = sharding.run_sharded(n_items, fn, rank, world)
         elapsed = sharding.max_over_ranks(1.0 + rank)          # slowest rank defines the step time
         gathered = sharding.gather_results(local, n_items, root=0)
+        # the collective form (what runs over RCCL on the GPUs): equal-sized shares, padded, gathered in item order
+        import torch
+        b_local = (n_items + world - 1) // world
+        share = torch.zeros((b_local, 4, 5), dtype=torch.uint8)
+        for slot, i in enumerate(sorted(local)):
+            share[slot] = torch.from_numpy(local[i])
+        collected = sharding.gather_device_masks(share, n_items)
+        np.save(Path(out_dir) / f"collected_{rank}.npy", collected.numpy())
+        np.save(Path(out_dir) / f"ranks_{rank}.npy", np.array([sharding.count_ranks()]))
         dist.barrier()
         np.save(Path(out_dir) / f"elapsed_{rank}.npy", np.array([elapsed]))
         np.save(Path(out_dir) / f"mine_{rank}.npy", np.array(sorted(local), dtype=np.int64))
@@ -63,6 +72,9 @@ def test_two_rank_gloo_shard_and_gather(tmp_path):
     for i in range(n_items):
         rng = np.random.default_rng(i)
         assert np.array_equal(gathered[i], (rng.integers(0, 2, (4, 5)) * 255).astype(np.uint8))
+    for r in range(world):      # gather_device_masks: every rank ends up with all masks, in item order
+        assert np.array_equal(np.load(tmp_path / f"collected_{r}.npy"), gathered)
+        assert int(np.load(tmp_path / f"ranks_{r}.npy")[0]) == world
 
 
 def test_gather_detects_duplicates_and_gaps():

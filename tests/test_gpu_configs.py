@@ -1,0 +1,210 @@
+"""BASELINE.json configs 3, 4 and 5 at their full size through the drop-in ABI (batch slots 13-14), against the committed
+Hugging Face fixtures (tests/golden/sam_vit_{b,h}*.npz, no oracle in the loop) and against the one-at-a-time calls
+(bit-equal).  Prompt kinds and geometries follow the reference's integration tests (test/test_segmentation.cpp:101-150:
+a point prompt, a region prompt, truck.jpg's 1800x1200).
+
+  config 3   ViT-B, 8 images per GPU, one point prompt each
+  config 4   ViT-H, 8 images, region (box) prompts
+  config 5   ViT-H, mixed resolutions {1800x1200, 1024x768, 512x512, 640x960, 1024x1024} resized to 1024 on the device,
+             5 Halton point prompts per image on the cached embedding
+"""
+import os
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import halton_points, iou, single_mask_index, synthetic_image
+
+pytestmark = pytest.mark.gpu
+
+GOLD = Path(__file__).resolve().parent / "golden"
+EMB_TOL, LOGIT_TOL, IOU_PRED_TOL, IOU_BAR = 0.05, 0.15, 0.02, 0.98      # as tests/test_gpu_e2e.py
+EMB_STRIDE, LOW_STRIDE = 257, 61
+
+
+@pytest.fixture(scope="module")
+def api():
+    from dlimgedit_amd import api
+    return api
+
+
+@pytest.fixture(scope="module")
+def full_env(api, model_dirs):
+    """variant -> environment on the seeded full-size weights of the fixtures (kept for the module: ViT-H is 2.5 GB)."""
+    envs = {}
+
+    def get(variant):
+        if variant not in envs:
+            g = np.load(GOLD / f"sam_{variant}.npz")
+            mdir, _, _ = model_dirs(variant, int(g["seed"]))
+            saved = os.environ.get("DLIMGEDIT_SAM_MODEL")
+            os.environ["DLIMGEDIT_SAM_MODEL"] = variant
+            try:
+                env = api.Environment(api.Options(api.Backend.gpu, mdir))
+                api.ext.model_geometry(env)      # loads the weights while the variable names this variant
+            finally:
+                if saved is None:
+                    os.environ.pop("DLIMGEDIT_SAM_MODEL", None)
+                else:
+                    os.environ["DLIMGEDIT_SAM_MODEL"] = saved
+            envs[variant] = env
+        return envs[variant]
+
+    yield get
+    for e in envs.values():
+        e.close()
+
+
+def _golden_masks(g, name):
+    return np.unpackbits(g[f"{name}_masks_bits"], axis=1).reshape(3, 1024, 1024) * 255
+
+
+def _batch_of_eight(api, env, g, prompt_kind):
+    """Eight images through process_images_for_segmentation + get_segmentation_masks; image 0 is the fixture's."""
+    imgs = [synthetic_image(int(g["image_seed"]) + i) for i in range(8)]
+    views = [api.ImageView(im, api.Channels.rgba) for im in imgs]
+    segs = api.Segmentation.process_batch(views, env)
+    assert len(segs) == 8
+    if prompt_kind == "point":
+        prompt = api.Point(512, 512)
+        masks = api.Segmentation.compute_mask_batch(segs, points=[prompt] * 8)
+    else:
+        prompt = api.Region(api.Point(256, 256), api.Point(768, 768))
+        masks = api.Segmentation.compute_mask_batch(segs, regions=[prompt] * 8)
+    # image 0 against Hugging Face
+    emb = api.ext.get_embedding(segs[0])
+    assert np.abs(emb.reshape(-1)[::EMB_STRIDE] - g["emb_samples"]).max() < EMB_TOL
+    name = "point" if prompt_kind == "point" else "box"
+    best = single_mask_index(g[f"{name}_iou"])
+    assert iou(masks[0], _golden_masks(g, name)[best - 1]) >= IOU_BAR
+    # every image: the batch slots give exactly what the one-at-a-time slots give
+    for view, seg, mask in zip(views, segs, masks):
+        assert mask.shape == (1024, 1024) and set(np.unique(mask)) <= {0, 255}
+        one = api.Segmentation.process(view, env)
+        assert np.array_equal(api.ext.get_embedding(one), api.ext.get_embedding(seg))
+        assert np.array_equal(one.compute_mask(prompt), mask)
+        one.close()
+    # the eight images are different pictures: so are their masks
+    assert len({m.tobytes() for m in masks}) == 8
+    for s in segs:
+        s.close()
+
+
+def test_config3_vit_b_batch8_point_prompts(api, full_env):
+    _batch_of_eight(api, full_env("vit_b"), np.load(GOLD / "sam_vit_b.npz"), "point")
+
+
+def test_config4_vit_h_batch8_region_prompts(api, full_env):
+    _batch_of_eight(api, full_env("vit_h"), np.load(GOLD / "sam_vit_h.npz"), "region")
+
+
+def test_multi_mask_mode_full_size(api, full_env):
+    """compute_masks at full size: decoder outputs 1..3 and their IoU predictions against Hugging Face."""
+    g = np.load(GOLD / "sam_vit_b.npz")
+    env = full_env("vit_b")
+    seg = api.Segmentation.process(api.ImageView(synthetic_image(int(g["image_seed"])), api.Channels.rgba), env)
+    got = seg.compute_masks(api.Point(512, 512))
+    want = _golden_masks(g, "point")
+    for t in range(3):
+        assert iou(got[t].image, want[t]) >= IOU_BAR
+        assert abs(got[t].accuracy - float(g["point_iou"][t + 1])) < IOU_PRED_TOL
+    seg.close()
+
+
+CONFIG5_SIZES = [(1800, 1200), (1024, 768), (512, 512), (640, 960), (1024, 1024)]
+
+
+def test_config5_vit_h_mixed_resolution_five_prompts_on_cached_embedding(api, full_env):
+    env = full_env("vit_h")
+    g = np.load(GOLD / "sam_vit_h_1800x1200.npz")
+    imgs, views = [], []
+    for (w, h) in CONFIG5_SIZES:
+        im = synthetic_image(w, width=w, height=h, channels=4)
+        if (w, h) == (1800, 1200):
+            im = im[:, :, :3].copy()             # the fixture's picture: RGB like the reference's truck.jpg
+            views.append(api.ImageView(im, api.Channels.rgb))
+        else:
+            views.append(api.ImageView(im, api.Channels.rgba))
+        imgs.append(im)
+    segs = api.Segmentation.process_batch(views, env)
+    prompts = [halton_points(5, w, h) for (w, h) in CONFIG5_SIZES]
+    assert prompts[0] == [tuple(p) for p in g["points"].tolist()]
+    # 25 prompts in ONE call: every image's embedding is used five times
+    flat_segs = [s for s in segs for _ in range(5)]
+    flat_pts = [api.Point(*p) for ps in prompts for p in ps]
+    masks = api.Segmentation.compute_mask_batch(flat_segs, points=flat_pts)
+    assert len(masks) == 25
+    for k, (seg, pt, mask) in enumerate(zip(flat_segs, flat_pts, masks)):
+        w, h = CONFIG5_SIZES[k // 5]
+        assert seg.extent() == api.Extent(w, h)
+        assert mask.shape == (h, w) and set(np.unique(mask)) <= {0, 255}
+        assert np.array_equal(seg.compute_mask(pt), mask)          # batch slot == single slot, bit for bit
+    # 1800x1200 against Hugging Face (resize -> pad -> encode -> rounded prompt -> crop + second bilinear)
+    emb = api.ext.get_embedding(segs[0])
+    assert np.abs(emb.reshape(-1)[::EMB_STRIDE] - g["emb_samples"]).max() < EMB_TOL
+    want_masks = np.unpackbits(g["masks_bits"], axis=2)[:, :, :1800 * 1200].reshape(5, 3, 1200, 1800) * 255
+    for j in range(5):
+        low, iou_pred = api.ext.get_logits(segs[0], point=flat_pts[j])
+        assert np.abs(low.reshape(4, -1)[:, ::LOW_STRIDE] - g["low_samples"][j]).max() < LOGIT_TOL
+        assert np.abs(iou_pred - g["iou"][j]).max() < IOU_PRED_TOL
+        best = single_mask_index(g["iou"][j])
+        assert iou(masks[j], want_masks[j, best - 1]) >= IOU_BAR
+    for s in segs:
+        s.close()
+
+
+def test_replicas_deal_images_round_robin_and_agree(api, model_dirs, monkeypatch):
+    """DLIMGEDIT_DEVICES lists the GPUs an environment uses; the same GPU twice gives two independent replicas, which
+    exercises the multi-device paths (per-replica host threads, handles pinned to the replica that holds their
+    embedding, mask queries routed by handle) on a one-GPU box.  Results do not depend on the replica."""
+    mdir, _, _ = model_dirs("vit_test")
+    one = api.Environment(api.Options(api.Backend.gpu, mdir))
+    monkeypatch.setenv("DLIMGEDIT_DEVICES", "0,0")
+    two = api.Environment(api.Options(api.Backend.gpu, mdir))
+    monkeypatch.delenv("DLIMGEDIT_DEVICES")
+    assert api.ext.replica_count(one) == 1 and api.ext.replica_count(two) == 2
+    imgs = [synthetic_image(20 + i) for i in range(5)]
+    views = [api.ImageView(im, api.Channels.rgba) for im in imgs]
+    segs1 = api.Segmentation.process_batch(views, one)
+    segs2 = api.Segmentation.process_batch(views, two)
+    assert [api.ext.segmentation_device(s) for s in segs1] == [(0, 0)] * 5
+    placement = [api.ext.segmentation_device(s)[0] for s in segs2]
+    assert sorted(placement) == [0, 0, 0, 1, 1] or sorted(placement) == [0, 0, 1, 1, 1]
+    assert all(placement[i] != placement[i + 1] for i in range(4))       # image i -> replica i mod G
+    pts = [api.Point(100 + 150 * i, 900 - 120 * i) for i in range(5)]
+    m1 = api.Segmentation.compute_mask_batch(segs1, points=pts)
+    m2 = api.Segmentation.compute_mask_batch(segs2, points=pts)
+    for a, b, s1, s2, p in zip(m1, m2, segs1, segs2, pts):
+        assert np.array_equal(api.ext.get_embedding(s1), api.ext.get_embedding(s2))
+        assert np.array_equal(a, b)
+        assert np.array_equal(s2.compute_mask(p), b)
+    multi = segs2[1].compute_masks(pts[1])
+    ref = segs1[1].compute_masks(pts[1])
+    for x, y in zip(multi, ref):
+        assert np.array_equal(x.image, y.image) and x.accuracy == y.accuracy
+    with pytest.raises(api.Error, match="out of range"):
+        monkeypatch.setenv("DLIMGEDIT_DEVICES", "0,99")
+        api.Environment(api.Options(api.Backend.gpu, mdir))
+
+
+def test_resize_table_cache_survives_more_sizes_than_it_holds(api, model_dirs):
+    """The device-side resize keeps one contributor table per (input, output) extent of an axis, 64 per lane (LRU).  A
+    host that cycles through more sizes while one axis repeats must keep getting the same pixels (the tables of the
+    repeated axis are in use while the other axis' lookup evicts)."""
+    mdir, _, _ = model_dirs("vit_test")
+    os.environ["DLIMGEDIT_LANES"] = "1"
+    try:
+        env = api.Environment(api.Options(api.Backend.gpu, mdir))
+        h = 1000                                  # longest side: scale and the (h -> 1024) table are the same every time
+        first_img = synthetic_image(1, width=300, height=h)
+        first = api.Segmentation.process(api.ImageView(first_img, api.Channels.rgba), env)
+        want = api.ext.get_embedding(first)
+        for i in range(70):                       # 70 further (w -> rw) tables go through a cache of 64
+            w = 310 + 7 * i
+            api.Segmentation.process(api.ImageView(synthetic_image(2, width=w, height=h), api.Channels.rgba), env).close()
+        again = api.Segmentation.process(api.ImageView(first_img, api.Channels.rgba), env)
+        assert np.array_equal(api.ext.get_embedding(again), want)
+        env.close()
+    finally:
+        os.environ.pop("DLIMGEDIT_LANES", None)

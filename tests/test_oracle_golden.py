@@ -5,7 +5,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-from conftest import synthetic_image
+from conftest import single_mask_index, synthetic_image
 from dlimgedit_amd import weights as W
 from dlimgedit_amd.sam_config import get_config
 from oracle import sam_oracle as O
@@ -26,11 +26,17 @@ def _check_variant(variant):
         low, iou = seg.logits(**kw)
         assert np.abs(low.reshape(4, -1)[:, ::LOW_STRIDE] - g[f"{name}_low_samples"]).max() < 5e-4
         assert np.abs(iou - g[f"{name}_iou"]).max() < 1e-4
-        assert O.select_single(iou, 2) == int(g[f"{name}_best"])
-        mask = seg.compute_mask(**kw)
-        want = np.unpackbits(g[f"{name}_mask_bits"]).reshape(1024, 1024) * 255
+        # the rule applied to HF's own predictions picks the same token as the oracle's select_single on its own
+        best = single_mask_index(g[f"{name}_iou"])
+        assert best in (1, 2, 3) and O.select_single(iou, 2) == best
+        masks = np.unpackbits(g[f"{name}_masks_bits"], axis=1).reshape(3, 1024, 1024) * 255
         # logits agree to ~1e-5, so only pixels whose logit is within that of zero may differ
-        assert (mask != want).mean() < 2e-5
+        assert (seg.compute_mask(**kw) != masks[best - 1]).mean() < 2e-5
+        if name == "point":     # multi-mask mode: decoder outputs 1..3 with their IoU predictions
+            multi, acc = seg.compute_masks(kw["point"])
+            for t in range(3):
+                assert (multi[t] != masks[t]).mean() < 2e-5
+                assert abs(acc[t] - float(g[f"{name}_iou"][t + 1])) < 1e-4
 
 
 def test_oracle_matches_hf_reduced_variant():
