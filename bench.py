@@ -11,12 +11,23 @@ resident in HBM: pre-process -> ViT encoder -> prompt encoder + mask decoder (on
 image, single-mask mode) -> bilinear upsample + threshold, masks left in HBM.  At N = 1 the default
 workload is BASELINE.json configs[1] (ViT-B, batch 1, one point prompt).
 
+Timing: the block of K steps is timed `--repeats` times (default 21), each repeat bracketed by a barrier and
+torch.cuda.synchronize() on both sides and reduced to the MAX over ranks; `value` comes from the MEDIAN repeat
+(`ms_per_step` likewise; every repeat's time is in `repeat_ms`).
+
 Besides the contract fields the JSON line carries
-  roofline      dominant kernel (the f16 MFMA GEMM of the encoder): algorithmic FLOPs / HIP-event time
+  roofline      dominant kernel (the f16 MFMA GEMMs of the encoder): algorithmic FLOPs / the kernels' own execution
+                time (HIP events attached to each dispatch) in a profiled repeat that runs on ONE lane, i.e. every
+                kernel alone on the chip; chip_frac = all FLOPs of a step / ms_per_step / peak, the only figure that
+                sees the lanes overlap
+  abi_path      images/s through the drop-in ABI itself (host pixels in, host masks out, PCIe and host copies
+                included): slots 3-4 from one and from several host threads, slots 13-14 with 8 images per call
   cpu_baseline  the CPU oracle (oracle/sam_oracle.py, a port: the reference's onnxruntime path cannot
                 be built here) timed on this host on one image of the same workload
   mask_iou      IoU of the HIP mask against the oracle's mask for that image
-  stages        per-stage HIP-event breakdown of one profiled repeat of the timed steps
+  stages        per-stage breakdown of the profiled repeat (profile_mode says how it was taken)
+  rccl          N > 1: ranks counted by an all-reduce of ones, and the optional gather of the finished masks to
+                every rank (RCCL all_gather over xGMI, after the timed region: no collective is on the data path)
 """
 from __future__ import annotations
 
@@ -63,6 +74,8 @@ def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--repeats", type=int, default=21, help="timed repeats of the block of --steps steps (median reported)")
+    ap.add_argument("--no-abi-path", action="store_true")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--model", default="vit_b")
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
@@ -134,15 +147,20 @@ def main() -> None:
     for _ in range(args.warmup):
         step()
     sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    ext.synchronize(env)
-    torch.cuda.synchronize()
-    elapsed = sharding.max_over_ranks(time.perf_counter() - t0, device="cuda")
-    if world > 1:
-        dist.barrier()
+    repeat_s = []
+    for _ in range(max(1, args.repeats)):
+        sync_all()                               # barrier + synchronize in front of the timed steps ...
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        ext.synchronize(env)
+        torch.cuda.synchronize()                 # ... and behind them
+        repeat_s.append(sharding.max_over_ranks(time.perf_counter() - t0, device="cuda"))
+        if world > 1:
+            dist.barrier()
+    elapsed = float(np.median(repeat_s))
 
+    decoder_flops = 3.62e9                       # per prompt
     result = None
     if rank == 0:
         images = world * B * args.steps
@@ -162,7 +180,33 @@ def main() -> None:
             "config": {"workload": f"SAM {args.model} encoder + 1 point prompt, {B} image(s)/GPU/step, 1024x1024 RGBA, "
                                    "inputs and masks resident in HBM", "images_per_gpu_per_step": B, "lanes_per_gpu": ext.lane_count(env),
                        "weights": "seeded synthetic" if args.model_dir is None else "from --model-dir"},
+            "repeats": len(repeat_s),
+            "timed_total_s": float(sum(repeat_s)),
+            "repeat_ms": [round(1e3 * t, 3) for t in repeat_s],
+            "value_min_max": [images / max(repeat_s), images / min(repeat_s)],
         }
+
+    # ---- N > 1: the ranks that really take part, and the optional gather of the masks (after the timed region)
+    if world > 1:
+        ranks = sharding.count_ranks(device="cuda")
+        local_masks = torch.empty((B, 1024, 1024), dtype=torch.uint8, device="cuda")
+        for i, mp in enumerate(mask_ptrs):
+            host = np.empty((1024, 1024), np.uint8)
+            ext.copy_to_host(env, host, mp)
+            local_masks[i] = torch.from_numpy(host).cuda()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        gathered = sharding.gather_device_masks(local_masks, world * B)
+        torch.cuda.synchronize()
+        t_gather = sharding.max_over_ranks(time.perf_counter() - t0, device="cuda")
+        ok = bool(torch.equal(gathered[rank::world][:B], local_masks))     # item i = b * world + rank
+        if rank == 0:
+            result["rccl"] = {"rccl_ranks": ranks, "gather": {"masks": int(gathered.shape[0]), "bytes": int(gathered.numel()),
+                                                              "ms": 1e3 * t_gather, "own_share_intact": ok,
+                                                              "note": "all_gather_into_tensor of the u8 masks, outside the timed region"}}
+    elif rank == 0:
+        result["rccl"] = {"rccl_ranks": 1, "gather": None}
 
     # ---- profiled repeat of the same steps: HIP events around every launch on the executor's stream
     if rank == 0:
@@ -184,12 +228,17 @@ def main() -> None:
             if t:
                 traffic = t["fetch_bytes_per_launch_corrected_x2"] + t["write_bytes_per_launch"]
                 traffic_note = "bytes per launch from profiles/r01_hbm_traffic_pmc.json (separate --pmc passes)"
+        step_flops = B * (cfg.encoder_flops() + decoder_flops)
+        chip_tflops = step_flops / (result["ms_per_step"] * 1e-3) / 1e12          # per GPU (every rank runs the same step)
         result["roofline"] = {
-            "kernel": "gemm_f16_kernel (all encoder/decoder MFMA GEMM launches)",
+            "kernel": "gemm_f16_kernel / gemm16_f16_kernel (every MFMA GEMM launch of the encoder)",
             "bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
             "launches": g["launches"], "avg_launch_us": 1e3 * g["ms"] / max(1, g["launches"]),
             "flops_per_launch": g["work"] / max(1, g["launches"]),
+            "clock": "HIP events attached to each GEMM dispatch (hipExtLaunchKernelGGL): the kernel's own execution time",
+            "chip_achieved": chip_tflops, "chip_frac": chip_tflops / MFMA_F16_PEAK_TFLOPS,
+            "chip_note": "per GPU: (encoder + decoder FLOPs of a step) / ms_per_step / peak -- all lanes, every kernel, gaps included",
         }
         stages = {}
         for name, s in st.items():
@@ -204,11 +253,60 @@ def main() -> None:
                 e["frac_hbm_peak"] = e["gbs"] / HBM_PEAK_GBS
             stages[name] = e
         result["stages"] = stages
+        result["profile_mode"] = ("single lane, serial: a repeat of the timed steps with every request on lane 0, so each "
+                                  "kernel runs alone on the chip; GEMM launches are clocked by events attached to the "
+                                  "dispatch, the other stages by hipEventRecord pairs around the launch (which adds a few "
+                                  "microseconds per launch).  The stage times therefore do not add up to ms_per_step, "
+                                  "which overlaps the lanes.")
         enc_ms = sum(v["ms_per_step"] for k, v in stages.items() if k not in ("decoder", "post", "pre"))
         result["encoder"] = {"gflop_per_image": cfg.encoder_flops() / 1e9, "event_ms_per_step": enc_ms,
                              "tflops": B * cfg.encoder_flops() / (enc_ms * 1e-3) / 1e12 if enc_ms > 0 else 0.0,
                              "mfma_frac": B * cfg.encoder_flops() / (enc_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS
                              if enc_ms > 0 else 0.0}
+
+    # ---- the drop-in ABI itself: host buffers in and out (PCIe inclusive), rank 0, N = 1 only
+    if rank == 0 and world == 1 and not args.no_abi_path:
+        import threading
+        view = api.ImageView(imgs[0], api.Channels.rgba)
+
+        def one_image():
+            seg = api.Segmentation.process(view, env)
+            seg.compute_mask(api.Point(512, 512))
+            seg.close()
+            return 1
+
+        views8 = [api.ImageView(synthetic_image(100 + i), api.Channels.rgba) for i in range(8)]
+        pts8 = [api.Point(512, 512)] * 8
+
+        def batch8():
+            segs = api.Segmentation.process_batch(views8, env)
+            api.Segmentation.compute_mask_batch(segs, points=pts8)
+            for sg in segs:
+                sg.close()
+            return 8
+
+        def rate(fn, threads, seconds=1.5):
+            fn()
+            counts = [0] * threads
+            stop = time.perf_counter() + seconds
+
+            def worker(i):
+                while time.perf_counter() < stop:
+                    counts[i] += fn()
+            ts = [threading.Thread(target=worker, args=(i,)) for i in range(threads)]
+            t0 = time.perf_counter()
+            [t.start() for t in ts]
+            [t.join() for t in ts]
+            return sum(counts) / (time.perf_counter() - t0)
+
+        lanes = ext.lane_count(env)
+        result["abi_path"] = {
+            "unit": "images/s", "note": "host pixels in, host masks out through dlimg_Api; PCIe and host copies included",
+            "slots_3_4_one_thread": rate(one_image, 1),
+            f"slots_3_4_{lanes}_threads": rate(one_image, lanes),
+            "slots_13_14_batch8_one_thread": rate(batch8, 1),
+            "slots_13_14_batch8_two_threads": rate(batch8, 2),
+        }
 
     # ---- CPU baseline (oracle port) + mask IoU, rank 0, N = 1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -384,6 +384,7 @@ class ext:
                 "dlimg_amd_birefnet_process_mask": ([vp, ci, ci, vp], ci),
                 "dlimg_amd_resize_mask": ([vp, ci, ci, ci, ci, ci, vp], ci),
                 "dlimg_amd_bench_gemm": ([ci, ci, ci, ci, ci, ci, C.POINTER(C.c_double)], ci),
+                "dlimg_amd_bench_gemm_streams": ([ci, ci, ci, ci, ci, ci, ci, ci, ci, C.POINTER(C.c_double)], ci),
             }
             for name, (args, res) in sig.items():
                 fn = getattr(lib, name)
@@ -399,7 +400,7 @@ class ext:
                "dlimg_amd_take_stage_stats", "dlimg_amd_test_preprocess", "dlimg_amd_test_postprocess",
                "dlimg_amd_test_gemm", "dlimg_amd_test_gemm_ln", "dlimg_amd_test_layernorm", "dlimg_amd_test_attention", "dlimg_amd_test_resize",
                "dlimg_amd_birefnet_prepare_image", "dlimg_amd_birefnet_process_mask", "dlimg_amd_resize_mask",
-               "dlimg_amd_bench_gemm")
+               "dlimg_amd_bench_gemm", "dlimg_amd_bench_gemm_streams")
 
     @staticmethod
     def _ptr(a: Optional[np.ndarray]):
@@ -620,7 +621,9 @@ class ext:
         return out
 
     @classmethod
-    def bench_gemm(cls, M: int, N: int, K: int, act: int = 0, iters: int = 20, flavour: int = 0) -> float:
+    def bench_gemm(cls, M: int, N: int, K: int, act: int = 0, iters: int = 20, flavour: int = 0, tile: int = -1,
+                   shared: bool = False, streams: int = 1) -> float:
         ms = C.c_double()
-        _check(cls._l().dlimg_amd_bench_gemm(M, N, K, act, flavour, iters, C.byref(ms)))
+        _check(cls._l().dlimg_amd_bench_gemm_streams(M, N, K, act, flavour, tile, int(shared), streams, iters,
+                                                     C.byref(ms)))
         return ms.value

@@ -77,6 +77,11 @@ EnvironmentImpl::EnvironmentImpl(dlimg_Options const& options) : backend(options
     } else {
         devices.push_back(0);
     }
+    // DLIMGEDIT_SINGLE_LANE=1: every request runs on lane 0 of its replica (the lanes still exist, so tile choices are
+    // those of the shared-GPU configuration): a kernel trace taken this way shows each kernel alone on the chip, which
+    // is what bench.py's per-kernel clocks measure
+    if (const char* e = std::getenv("DLIMGEDIT_SINGLE_LANE")) forced_single_lane_ = std::atoi(e) != 0;
+    single_lane_.store(forced_single_lane_);
     for (int d : devices) {
         if (d < 0 || d >= device_count())
             throw Exception("GPU index " + std::to_string(d) + " (DLIMGEDIT_DEVICE / DLIMGEDIT_DEVICES) is out of range: " +

@@ -72,7 +72,7 @@ class EnvironmentImpl {
     std::shared_ptr<EmbeddingPool> embedding_pool(int replica) const { return replicas_.at(replica)->pool; }
 
     // While set, every request goes to lane 0 of its replica (per-kernel clocks must not see other lanes' kernels).
-    void set_single_lane(bool on) { single_lane_.store(on); }
+    void set_single_lane(bool on) { single_lane_.store(on || forced_single_lane_); }
 
   private:
     struct SamLanes {
@@ -91,6 +91,7 @@ class EnvironmentImpl {
     std::vector<std::unique_ptr<Replica>> replicas_;
     std::atomic<unsigned> next_replica_{0};
     std::atomic<bool> single_lane_{false};
+    bool forced_single_lane_ = false;     // DLIMGEDIT_SINGLE_LANE
 };
 
 }  // namespace dlimg

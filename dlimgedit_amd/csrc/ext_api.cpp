@@ -453,9 +453,14 @@ DLIMG_API int dlimg_amd_resize_mask(uint8_t const* mask, int width, int height, 
 }
 
 DLIMG_API int dlimg_amd_bench_gemm(int M, int N, int K, int act, int flavour, int iters, double* out_ms) {
+    return dlimg_amd_bench_gemm_streams(M, N, K, act, flavour, -1, 0, 1, iters, out_ms);
+}
+
+DLIMG_API int dlimg_amd_bench_gemm_streams(int M, int N, int K, int act, int flavour, int tile, int shared, int streams,
+                                           int iters, double* out_ms) {
     return guarded([&] {
         require_gpu();
-        DLIMG_ASSERT(M > 0 && N > 0 && K > 0 && iters > 0 && out_ms);
+        DLIMG_ASSERT(M > 0 && N > 0 && K > 0 && iters > 0 && out_ms && streams >= 1 && streams <= 8);
         std::vector<half_t> ha((size_t)M * K), hw((size_t)N * K);
         uint32_t seed = 12345u;
         auto rnd = [&] { seed = seed * 1664525u + 1013904223u; return ((seed >> 8) & 0xffff) / 32768.0f - 1.0f; };
@@ -467,7 +472,7 @@ DLIMG_API int dlimg_amd_bench_gemm(int M, int N, int K, int act, int flavour, in
         DeviceBuffer<float> o32, colsum, bias, stats;
         k::GemmArgs g;
         g.A = a.get(); g.lda = K; g.W = w.get(); g.ldw = K; g.out_h = o.get(); g.ldc16 = N;
-        g.M = M; g.N = N; g.K = K; g.act = act;
+        g.M = M; g.N = N; g.K = K; g.act = act; g.tile = tile; g.shared_gpu = shared != 0;
         // flavour 0: f16 output only; 1: LayerNorm folded in; 2: residual-stream writer (bias + fp32 residual in
         // place); 3: the same plus the f16 copy of the stream and its row statistics; 4: f16 output with bias
         DLIMG_ASSERT(flavour >= 0 && flavour <= 4);
@@ -496,22 +501,49 @@ DLIMG_API int dlimg_amd_bench_gemm(int M, int N, int K, int act, int flavour, in
                 g.out_h = o.get(); g.stats_out = stats.get();
             }
         }
-        hipStream_t s;
-        HIP_CHECK(hipStreamCreate(&s));
+        // `streams` concurrent copies of the problem (own outputs, shared operands), launched round-robin: the regime
+        // of the execution lanes, where kernels of different images share the chip
+        std::vector<hipStream_t> ss(streams);
+        std::vector<k::GemmArgs> gs(streams, g);
+        std::vector<DeviceBuffer<half_t>> outs(streams);
+        std::vector<DeviceBuffer<float>> outs32(streams), stat_bufs(streams);
+        for (int i = 0; i < streams; ++i) {
+            HIP_CHECK(hipStreamCreateWithFlags(&ss[i], hipStreamNonBlocking));
+            if (i == 0) continue;
+            if (g.out_h) { outs[i].reserve((size_t)M * N); gs[i].out_h = outs[i].get(); }
+            if (g.out_f32) {
+                outs32[i].reserve((size_t)M * N);
+                HIP_CHECK(hipMemset(outs32[i].get(), 0, (size_t)M * N * 4));
+                gs[i].out_f32 = outs32[i].get(); gs[i].resid = outs32[i].get();
+            }
+            if (g.stats_out) { stat_bufs[i].reserve((size_t)M * 24 * 2); gs[i].stats_out = stat_bufs[i].get(); }
+        }
         hipEvent_t e0, e1;
         HIP_CHECK(hipEventCreate(&e0));
         HIP_CHECK(hipEventCreate(&e1));
-        for (int i = 0; i < 3; ++i) k::gemm(g, s);
-        HIP_CHECK(hipEventRecord(e0, s));
-        for (int i = 0; i < iters; ++i) k::gemm(g, s);
-        HIP_CHECK(hipEventRecord(e1, s));
-        HIP_CHECK(hipStreamSynchronize(s));
+        for (int i = 0; i < 3 * streams; ++i) k::gemm(gs[i % streams], ss[i % streams]);
+        HIP_CHECK(hipDeviceSynchronize());
+        std::vector<hipEvent_t> fork(1), join(streams);
+        HIP_CHECK(hipEventCreateWithFlags(&fork[0], hipEventDisableTiming));
+        for (auto& e : join) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(e0, ss[0]));
+        HIP_CHECK(hipEventRecord(fork[0], ss[0]));
+        for (int i = 1; i < streams; ++i) HIP_CHECK(hipStreamWaitEvent(ss[i], fork[0], 0));
+        for (int i = 0; i < iters * streams; ++i) k::gemm(gs[i % streams], ss[i % streams]);
+        for (int i = 1; i < streams; ++i) {
+            HIP_CHECK(hipEventRecord(join[i], ss[i]));
+            HIP_CHECK(hipStreamWaitEvent(ss[0], join[i], 0));
+        }
+        HIP_CHECK(hipEventRecord(e1, ss[0]));
+        HIP_CHECK(hipDeviceSynchronize());
         float ms = 0.f;
         HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-        *out_ms = ms / iters;
+        *out_ms = ms / (iters * streams);        // per GEMM, aggregate over the streams
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
-        (void)hipStreamDestroy(s);
+        (void)hipEventDestroy(fork[0]);
+        for (auto e : join) (void)hipEventDestroy(e);
+        for (auto st : ss) (void)hipStreamDestroy(st);
     });
 }
 

@@ -25,6 +25,8 @@
 #include "device_common.hpp"
 #include "kernels.hpp"
 
+#include <hip/hip_ext.h>
+
 #include <mutex>
 #include <cstdlib>
 #include <type_traits>
@@ -517,8 +519,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm16_f16_kernel(k::Gem
 typedef void (*GemmKernel)(k::GemmArgs);
 
 // Picks the epilogue flavour the arguments ask for and launches; LDS above the default limit is opted into once.
+struct Timing { hipEvent_t start = nullptr, stop = nullptr; };
+
 void launch_flavour(GemmKernel const (&kernels)[5], std::once_flag (&attr_once)[5], const k::GemmArgs& a, int grid,
-                    int threads, size_t lds, hipStream_t s) {
+                    int threads, size_t lds, hipStream_t s, Timing t) {
     const int index = a.stats_out ? 4 : (a.ln_stats ? 2 : 0) + (a.act == k::ACT_GELU ? 1 : 0);
     if (lds > 48 * 1024) {
         bool refused = false;        // concurrent lanes launch the same kernels: opt in exactly once, under the flag
@@ -528,11 +532,14 @@ void launch_flavour(GemmKernel const (&kernels)[5], std::once_flag (&attr_once)[
         });
         if (refused) throw_error("gemm: the device refuses the LDS size of this tile configuration");
     }
-    hipLaunchKernelGGL(kernels[index], dim3(grid), dim3(threads), lds, s, a);
+    if (t.start && t.stop)
+        hipExtLaunchKernelGGL(kernels[index], dim3(grid), dim3(threads), lds, s, t.start, t.stop, 0, a);
+    else
+        hipLaunchKernelGGL(kernels[index], dim3(grid), dim3(threads), lds, s, a);
 }
 
 template <int BM, int BN, int WGM, int WGN, int NSTAGE, int MINW>
-void launch16(const k::GemmArgs& a, hipStream_t s) {
+void launch16(const k::GemmArgs& a, hipStream_t s, Timing t) {
     const size_t lds = (size_t)NSTAGE * (BM + BN) * 64 + aux_bytes(BM, BN);
     static const GemmKernel kernels[5] = {
         gemm16_f16_kernel<BM, BN, WGM, WGN, NSTAGE, MINW, k::ACT_NONE, EPI_PLAIN>,
@@ -542,11 +549,11 @@ void launch16(const k::GemmArgs& a, hipStream_t s) {
         gemm16_f16_kernel<BM, BN, WGM, WGN, NSTAGE, MINW, k::ACT_NONE, EPI_STATS>,
     };
     static std::once_flag attr_once[5];
-    launch_flavour(kernels, attr_once, a, (a.M / BM) * (a.N / BN), 64 * WGM * WGN, lds, s);
+    launch_flavour(kernels, attr_once, a, (a.M / BM) * (a.N / BN), 64 * WGM * WGN, lds, s, t);
 }
 
 template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE, int MINW>
-void launch(const k::GemmArgs& a, hipStream_t s) {
+void launch(const k::GemmArgs& a, hipStream_t s, Timing t) {
     const size_t lds = (size_t)NSTAGE * (BM + BN) * BKT * 2 + aux_bytes(BM, BN);
     static const int ablate = [] { const char* e = std::getenv("DLIMGEDIT_GEMM_ABLATE"); return e ? std::atoi(e) : 0; }();
     static const GemmKernel kernels[5] = {
@@ -559,7 +566,7 @@ void launch(const k::GemmArgs& a, hipStream_t s) {
         gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_NONE, EPI_STATS>,
     };
     static std::once_flag attr_once[5];
-    launch_flavour(kernels, attr_once, a, (a.M / BM) * (a.N / BN), 64 * WGM * WGN, lds, s);
+    launch_flavour(kernels, attr_once, a, (a.M / BM) * (a.N / BN), 64 * WGM * WGN, lds, s, t);
 }
 
 }  // namespace
@@ -652,18 +659,19 @@ int gemm_choose_tile(GemmArgs& a) {
     return kTiles[a.tile].bn;
 }
 
-void gemm(const GemmArgs& a, hipStream_t s) {
+void gemm(const GemmArgs& a, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
     if (const char* err = gemm_check(a)) throw_error(err);
+    const Timing t{start, stop};
     switch (gemm_pick_tile(a)) {
-    case 0: return launch<128, 384, 2, 2, 64, 2, 1>(a, s);
-    case 1: return launch<128, 288, 4, 1, 64, 3, 1>(a, s);
-    case 2: return launch<128, 128, 2, 2, 64, 2, 4>(a, s);
-    case 3: return launch<128, 96, 4, 1, 64, 4, 1>(a, s);
-    case 4: return launch<128, 64, 2, 2, 64, 2, 3>(a, s);
-    case 5: return launch<64, 64, 2, 2, 64, 2, 4>(a, s);
-    case 6: return launch<256, 256, 2, 4, 32, 4, 2>(a, s);
-    case 7: return launch16<256, 256, 2, 4, 4, 2>(a, s);
-    case 8: return launch16<128, 128, 2, 2, 4, 2>(a, s);
+    case 0: return launch<128, 384, 2, 2, 64, 2, 1>(a, s, t);
+    case 1: return launch<128, 288, 4, 1, 64, 3, 1>(a, s, t);
+    case 2: return launch<128, 128, 2, 2, 64, 2, 4>(a, s, t);
+    case 3: return launch<128, 96, 4, 1, 64, 4, 1>(a, s, t);
+    case 4: return launch<128, 64, 2, 2, 64, 2, 3>(a, s, t);
+    case 5: return launch<64, 64, 2, 2, 64, 2, 4>(a, s, t);
+    case 6: return launch<256, 256, 2, 4, 32, 4, 2>(a, s, t);
+    case 7: return launch16<256, 256, 2, 4, 4, 2>(a, s, t);
+    case 8: return launch16<128, 128, 2, 2, 4, 2>(a, s, t);
     default: throw_error("gemm: no tile configuration fits this shape");
     }
 }

@@ -47,7 +47,9 @@ struct GemmArgs {
 };
 const char* gemm_check(const GemmArgs&);
 int gemm_choose_tile(GemmArgs&);              // sets a.tile; returns BN (columns per tile) of that configuration
-void gemm(const GemmArgs&, hipStream_t);
+// start/stop (both or neither): events attached to the kernel's own dispatch (hipExtLaunchKernelGGL): their elapsed time
+// is the kernel's execution time as a profiler reports it, without the marker packets an hipEventRecord pair adds.
+void gemm(const GemmArgs&, hipStream_t, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 
 // ---- row LayerNorm ---------------------------------------------------------------------------
 // y = (x-mean)/sqrt(var+eps)*w+b over rows of length D (<= 1280); optional GELU; f32 and/or f16 out.

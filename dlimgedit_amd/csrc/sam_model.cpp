@@ -308,22 +308,23 @@ StageStats SamModel::take_stats() {
     return s;
 }
 
+hipEvent_t SamModel::take_event() {
+    hipEvent_t e;
+    if (!event_pool_.empty()) {
+        e = event_pool_.back();
+        event_pool_.pop_back();
+    } else {
+        HIP_CHECK(hipEventCreate(&e));
+    }
+    return e;
+}
+
 template <typename F> void SamModel::timed(Stage st, double work, F&& launch) {
     if (!profiling_) {
         launch();
         return;
     }
-    auto take = [&]() {
-        hipEvent_t e;
-        if (!event_pool_.empty()) {
-            e = event_pool_.back();
-            event_pool_.pop_back();
-        } else {
-            HIP_CHECK(hipEventCreate(&e));
-        }
-        return e;
-    };
-    Pending p{take(), take(), st, work};
+    Pending p{take_event(), take_event(), st, work};
     HIP_CHECK(hipEventRecord(p.a, stream_));
     launch();
     HIP_CHECK(hipEventRecord(p.b, stream_));
@@ -335,7 +336,15 @@ void SamModel::gemm(k::GemmArgs const& args) {
     k::GemmArgs a = args;
     a.shared_gpu = shared_gpu_;
     a.unit_rows = kTokens;
-    timed(ST_GEMM, 2.0 * a.M * a.N * a.K, [&] { k::gemm(a, stream_); });
+    if (!profiling_) {
+        k::gemm(a, stream_);
+        return;
+    }
+    // the clock of a GEMM launch is the kernel's own dispatch-to-completion time (events attached to the dispatch)
+    Pending p{take_event(), take_event(), ST_GEMM, 2.0 * a.M * a.N * a.K};
+    k::gemm(a, stream_, p.a, p.b);
+    pending_.push_back(p);
+    if (pending_.size() > 8192) flush_events();
 }
 
 void SamModel::synchronize() { HIP_CHECK(hipStreamSynchronize(stream_)); }

@@ -177,6 +177,7 @@ class SamModel {
     void gemm(k::GemmArgs const& a);
     template <typename F> void timed(Stage st, double work, F&& launch);
     void flush_events();
+    hipEvent_t take_event();
 
     int device_ = 0;
     bool shared_gpu_ = false;            // other lanes run on this device too (GEMM tile choice, kernels/gemm.hip)

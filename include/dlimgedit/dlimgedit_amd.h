@@ -117,6 +117,11 @@ DLIMG_API int dlimg_amd_resize_mask(uint8_t const* mask, int width, int height, 
  * flavour 0: f16 output; 1: LayerNorm folded in; 2: bias + fp32 residual in place; 3: 2 + f16 copy of the result + row statistics;
  * 4: f16 output with bias. */
 DLIMG_API int dlimg_amd_bench_gemm(int M, int N, int K, int act, int flavour, int iters, double* out_ms);
+/* The same with the tile configuration forced (tile >= 0, index into kernels/gemm.hip's table; -1: chosen as in the
+ * product, `shared` = the shared-GPU hint) and `streams` (1..8) concurrent copies of the problem launched round-robin;
+ * out_ms = wall time per GEMM over all streams. */
+DLIMG_API int dlimg_amd_bench_gemm_streams(int M, int N, int K, int act, int flavour, int tile, int shared, int streams,
+                                           int iters, double* out_ms);
 
 #ifdef __cplusplus
 }
