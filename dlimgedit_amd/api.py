@@ -385,6 +385,7 @@ class ext:
                 "dlimg_amd_resize_mask": ([vp, ci, ci, ci, ci, ci, vp], ci),
                 "dlimg_amd_bench_gemm": ([ci, ci, ci, ci, ci, ci, C.POINTER(C.c_double)], ci),
                 "dlimg_amd_bench_gemm_streams": ([ci, ci, ci, ci, ci, ci, ci, ci, ci, C.POINTER(C.c_double)], ci),
+                "dlimg_amd_bench_gemm_stamps": ([ci, ci, ci, ci, ci, ci, ci, ci, ci, C.POINTER(C.c_double), vp, ci], ci),
             }
             for name, (args, res) in sig.items():
                 fn = getattr(lib, name)
@@ -400,7 +401,7 @@ class ext:
                "dlimg_amd_take_stage_stats", "dlimg_amd_test_preprocess", "dlimg_amd_test_postprocess",
                "dlimg_amd_test_gemm", "dlimg_amd_test_gemm_ln", "dlimg_amd_test_layernorm", "dlimg_amd_test_attention", "dlimg_amd_test_resize",
                "dlimg_amd_birefnet_prepare_image", "dlimg_amd_birefnet_process_mask", "dlimg_amd_resize_mask",
-               "dlimg_amd_bench_gemm", "dlimg_amd_bench_gemm_streams")
+               "dlimg_amd_bench_gemm", "dlimg_amd_bench_gemm_streams", "dlimg_amd_bench_gemm_stamps")
 
     @staticmethod
     def _ptr(a: Optional[np.ndarray]):
@@ -627,3 +628,13 @@ class ext:
         _check(cls._l().dlimg_amd_bench_gemm_streams(M, N, K, act, flavour, tile, int(shared), streams, iters,
                                                      C.byref(ms)))
         return ms.value
+
+    @classmethod
+    def bench_gemm_stamps(cls, M: int, N: int, K: int, act: int = 0, iters: int = 20, flavour: int = 0, tile: int = 9,
+                          streams: int = 1, groups: int = 4096):
+        """(ms per GEMM, stamps [groups][4] u64: main-loop cycles, main-loop 100 MHz ticks, kernel cycles, kernel ticks)."""
+        ms = C.c_double()
+        st = np.zeros((groups, 4), np.uint64)
+        _check(cls._l().dlimg_amd_bench_gemm_stamps(M, N, K, act, flavour, tile, 0, streams, iters, C.byref(ms),
+                                                    st.ctypes.data, groups))
+        return ms.value, st

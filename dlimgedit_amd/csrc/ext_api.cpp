@@ -53,6 +53,15 @@ template <typename T> void download(T* host, T const* dev, size_t n) {
     if (host && n) HIP_CHECK(hipMemcpy(host, dev, n * sizeof(T), hipMemcpyDeviceToHost));
 }
 
+// Tuning / test aid (never read by the product path): DLIMGEDIT_GEMM_TILE forces a tile configuration of kernels/gemm.hip
+// in the single-kernel hooks below wherever it fits the problem.
+void apply_forced_tile(k::GemmArgs& g) {
+    const char* e = std::getenv("DLIMGEDIT_GEMM_TILE");
+    if (!e || g.tile >= 0) return;
+    const int t = std::atoi(e);
+    if (k::gemm_tile_fits(g, t)) g.tile = t;
+}
+
 void require_gpu() {
     if (!EnvironmentImpl::is_supported(dlimg_gpu)) throw Exception("No supported GPU (gfx950) found");
 }
@@ -297,6 +306,7 @@ DLIMG_API int dlimg_amd_test_gemm(int M, int N, int K, uint16_t const* A, uint16
         g.out_f32 = out_f32 ? o32.get() : nullptr; g.ldc32 = N;
         g.out_h = out_f16 ? o16.get() : nullptr; g.ldc16 = N;
         g.M = M; g.N = N; g.K = K; g.act = act;
+        apply_forced_tile(g);
         k::gemm(g, nullptr);
         HIP_CHECK(hipDeviceSynchronize());
         download(out_f32, o32.get(), out_f32 ? (size_t)M * N : 0);
@@ -323,12 +333,14 @@ DLIMG_API int dlimg_amd_test_gemm_ln(int M, int D, int K1, int N, uint16_t const
         g.resid = resid ? r.get() : nullptr; g.ldr = D; g.resid_mod = M;
         g.out_f32 = x.get(); g.ldc32 = D; g.out_h = xh.get(); g.ldc16 = D; g.stats_out = stats.get();
         g.M = M; g.N = D; g.K = K1;
+        apply_forced_tile(g);
         const int groups = D / k::gemm_choose_tile(g);
         k::gemm(g, nullptr);
         g = k::GemmArgs{};  // consumer: LayerNorm folded in
         g.A = xh.get(); g.lda = D; g.W = wg.get(); g.ldw = D; g.bias = bias2 ? b2.get() : nullptr;
         g.ln_stats = stats.get(); g.ln_groups = groups; g.ln_colsum = cs.get(); g.ln_eps = eps;
         g.out_f32 = y.get(); g.ldc32 = N; g.M = M; g.N = N; g.K = D; g.act = act;
+        apply_forced_tile(g);
         k::gemm(g, nullptr);
         HIP_CHECK(hipDeviceSynchronize());
         download(out_x, x.get(), (size_t)M * D);
@@ -458,6 +470,11 @@ DLIMG_API int dlimg_amd_bench_gemm(int M, int N, int K, int act, int flavour, in
 
 DLIMG_API int dlimg_amd_bench_gemm_streams(int M, int N, int K, int act, int flavour, int tile, int shared, int streams,
                                            int iters, double* out_ms) {
+    return dlimg_amd_bench_gemm_stamps(M, N, K, act, flavour, tile, shared, streams, iters, out_ms, nullptr, 0);
+}
+
+DLIMG_API int dlimg_amd_bench_gemm_stamps(int M, int N, int K, int act, int flavour, int tile, int shared, int streams,
+                                          int iters, double* out_ms, unsigned long long* out_stamps, int max_groups) {
     return guarded([&] {
         require_gpu();
         DLIMG_ASSERT(M > 0 && N > 0 && K > 0 && iters > 0 && out_ms && streams >= 1 && streams <= 8);
@@ -473,6 +490,7 @@ DLIMG_API int dlimg_amd_bench_gemm_streams(int M, int N, int K, int act, int fla
         k::GemmArgs g;
         g.A = a.get(); g.lda = K; g.W = w.get(); g.ldw = K; g.out_h = o.get(); g.ldc16 = N;
         g.M = M; g.N = N; g.K = K; g.act = act; g.tile = tile; g.shared_gpu = shared != 0;
+        apply_forced_tile(g);
         // flavour 0: f16 output only; 1: LayerNorm folded in; 2: residual-stream writer (bias + fp32 residual in
         // place); 3: the same plus the f16 copy of the stream and its row statistics; 4: f16 output with bias
         DLIMG_ASSERT(flavour >= 0 && flavour <= 4);
@@ -503,8 +521,15 @@ DLIMG_API int dlimg_amd_bench_gemm_streams(int M, int N, int K, int act, int fla
         }
         // `streams` concurrent copies of the problem (own outputs, shared operands), launched round-robin: the regime
         // of the execution lanes, where kernels of different images share the chip
+        DeviceBuffer<unsigned long long> stamps;
+        if (out_stamps && max_groups > 0) {
+            stamps.reserve((size_t)max_groups * 4);
+            HIP_CHECK(hipMemset(stamps.get(), 0, (size_t)max_groups * 4 * sizeof(unsigned long long)));
+            g.stamps = stamps.get();             // stream 0's kernels; the last launch's values remain
+        }
         std::vector<hipStream_t> ss(streams);
         std::vector<k::GemmArgs> gs(streams, g);
+        for (int i = 1; i < streams; ++i) gs[i].stamps = nullptr;
         std::vector<DeviceBuffer<half_t>> outs(streams);
         std::vector<DeviceBuffer<float>> outs32(streams), stat_bufs(streams);
         for (int i = 0; i < streams; ++i) {
@@ -539,6 +564,8 @@ DLIMG_API int dlimg_amd_bench_gemm_streams(int M, int N, int K, int act, int fla
         float ms = 0.f;
         HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
         *out_ms = ms / (iters * streams);        // per GEMM, aggregate over the streams
+        if (out_stamps && max_groups > 0)
+            HIP_CHECK(hipMemcpy(out_stamps, stamps.get(), (size_t)max_groups * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
         (void)hipEventDestroy(fork[0]);

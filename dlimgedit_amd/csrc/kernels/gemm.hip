@@ -66,20 +66,34 @@ template <int BKT> DLIMG_DEVICE half8_t read_frag(const char* lds, int row, int 
     return *reinterpret_cast<const half8_t*>(lds + row * (BKT * 2) + ((chunk ^ swz<BKT>(row)) << 4));
 }
 
-// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7): a third of the
-// instructions of erff(), which matters because fc1's epilogue is VALU-bound (12.6 M outputs on the CUs the tiles
-// occupy).  With E = exp(-x^2/2), p = t (a1 + t (a2 + ...)), t = 1 / (1 + 0.3275911 |x| / sqrt 2):
-//   erf(|x|/sqrt 2) = 1 - p E   =>   GELU(x) = max(x, 0) - 0.5 |x| p E     (both signs; no copysign needed)
-DLIMG_DEVICE float gelu_fast(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.0f));   // 1 ulp is plenty
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.4426950408889634f));
-    return fmaf(-0.5f * ax * (p * t), e, fmaxf(x, 0.0f));
+// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz-Stegun 7.1.28:
+//   erf(z) = 1 - 1 / (1 + a1 z + ... + a6 z^6)^16,  z >= 0,  |err| <= 3e-7
+// so with q = 1 / P(|x|)^16 (sqrt 2 folded into the coefficients):  GELU(x) = max(x, 0) - 0.5 |x| q  (both signs).
+// One reciprocal and no exponential per value, and everything else on two values at a time (v_pk_fma_f32 /
+// v_pk_mul_f32): fc1's epilogue is VALU-bound (12.6 M outputs on the CUs its tiles occupy; the 7.1.26 form with
+// exp2 + rcp on single values cost 6.7 k of the tile's 11 k epilogue cycles).  Against the fp64 erf form the fp32
+// evaluation is within 7.1e-7 absolute over |x| <= 12; P^16 overflowing to inf for |x| > ~25 gives q = 0, the limit.
+DLIMG_DEVICE float2_t gelu_pair(float2_t x) {
+    const float2_t ax = {fabsf(x[0]), fabsf(x[1])};
+    float2_t p = ax * 5.38297500e-6f + 4.88906359e-5f;       // a6 / 8, a5 / (4 sqrt 2)
+    p = p * ax + 3.80035750e-5f;                               // a4 / 4
+    p = p * ax + 3.27762634e-3f;                               // a3 / (2 sqrt 2)
+    p = p * ax + 2.11410062e-2f;                               // a2 / 2
+    p = p * ax + 4.98673463e-2f;                               // a1 / sqrt 2
+    p = p * ax + 1.0f;
+    p = p * p;
+    p = p * p;
+    p = p * p;
+    p = p * p;
+    const float2_t q = {__builtin_amdgcn_rcpf(p[0]), __builtin_amdgcn_rcpf(p[1])};       // 1 ulp is plenty
+    const float2_t pos = {fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f)};
+    return pos - (ax * 0.5f) * q;
 }
+DLIMG_DEVICE float4_t gelu4(float4_t v) {
+    const float2_t lo = gelu_pair(float2_t{v[0], v[1]}), hi = gelu_pair(float2_t{v[2], v[3]});
+    return float4_t{lo[0], lo[1], hi[0], hi[1]};
+}
+DLIMG_DEVICE float gelu_fast(float x) { return gelu_pair(float2_t{x, x})[0]; }
 
 // Epilogue flavours: compile-time, so the plain GEMM does not carry the registers of the others
 // (the shared epilogue code is in gemm_epilogue.inc).
@@ -516,6 +530,530 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm16_f16_kernel(k::Gem
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// 256 x 256 x 64 "ping-pong" kernel on v_mfma_f32_16x16x32_f16 (cdna_hip_programming.md, "The 256^2 8-phase template").
+//
+// Eight waves, 2 (M) x 4 (N), each owning 128 x 64 of the tile (8 x 4 accumulator tiles of 16 x 16).  The four waves
+// with wr = 0 and the four with wr = 1 are two GROUPS, one wave of each per SIMD, that run the same program ONE
+// BARRIER APART: per K tile of 64 a wave goes through four phases, each { L: fragment reads from LDS + two DMA
+// requests; barrier; M: 16 MFMAs (one 64 x 32 quadrant of its accumulators over the whole K tile); barrier }, and while
+// one group is in an M segment the other is in an L segment -- the matrix pipe of every SIMD always has a wave feeding
+// it, and LDS reads / DMA issue never sit in front of MFMAs of the same wave.
+//
+// LDS: 2 buffers (K tile parity) x 4 half-tiles of 16 KB: A rows 0-127, A rows 128-255, W rows 0-127, W rows 128-255
+// (128 rows x 64 halves, lane-linear DMA image, chunk ^= (row >> 1) & 7 on the source address and on the read).
+// All eight waves stage every half-tile (2 DMA wave-instructions each).  Half-tile life cycle, in slots (= intervals
+// between barriers; group 0 has L(t,q) in slot 8t+2q and M(t,q) in 8t+2q+1, group 1 one slot later):
+//   phase            reads (group's own A half; W half by wave column)       stages
+//   0 (mh0, nh0)     A rows mh0 (8 x b128), W cols nh0 (4)                   A0 of tile t+1
+//   1 (mh0, nh1)     W cols nh1 (4)                                          A1 of tile t+1
+//   2 (mh1, nh1)     A rows mh1 (8)                                          W0 of tile t+2
+//   3 (mh1, nh0)     -- (W fragments of phase 0 are still in registers)      W1 of tile t+2, then wait: tile t+1 landed
+// WAR: every L segment ends with lgkmcnt(0) BEFORE its barrier, so a half-tile is overwritten only in a later slot
+// than its last read (A0/A1 of the other buffer were last read in phase 2 of tile t-1; W of this buffer in phase 1 of
+// this tile by the later group, slot 8t+3, restaged from slot 8t+4 on).  RAW: the vmcnt wait of phase 3 (4 newer
+// requests may stay in flight) is passed by every wave before the barrier that ends slot 8t+7; tile t+1 is first read
+// in slot 8t+8.
+constexpr int kPPHalfBytes = 128 * 128;
+constexpr int kPPBufBytes = 4 * kPPHalfBytes;
+constexpr int kPPAuxBytes = 256 * 8 + 2 * 256 * 4 + 256 * 4 * 8;      // rowstat, colvec[2], rowpart [256][4]
+constexpr int kPPLds = 2 * kPPBufBytes + kPPAuxBytes;
+
+// L segment's end: fragment reads of this wave have returned, then the workgroup barrier.  One statement with a memory
+// clobber: the compiler moves no LDS access across it.
+DLIMG_DEVICE void pp_barrier_after_reads() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+DLIMG_DEVICE void pp_barrier() {
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Epilogue of the ping-pong kernels: the wave's (NI * 16) x 64 part of the tile, rows row_base .. of the workgroup's tile.
+// PRE: the residual of the whole wave tile was requested before the main loop (pre[band][kk]; only where the
+// registers allow it) -- the epilogue is bound by the CU's memory pipe (~30 B/clk: 320 KB per 128 x 256 tile of a
+// stream writer), so every byte moved earlier comes off it.
+template <int NI, int ACT, int EPI, bool PRE = false>
+DLIMG_DEVICE void pp_epilogue(const k::GemmArgs& a, float4v (&acc)[NI][4], char* smem, const float* rowstat, const float* colvec,
+                              float2_t* rowpart, int m0, int n0, int row_base, int wc, int wave, int lane,
+                              float4_t (*pre)[4] = nullptr) {
+    // ---- epilogue.  A lane owns 4 consecutive columns of one row per accumulator tile (row = l15, columns 4 * quad ..):
+    // storing that directly touches 16 cache lines per wave-instruction with 32 or 64 bytes each, and the store path
+    // pays per line touched (measured: 16-22 k cycles for the tile).  So the wave's 16 x 64 band goes through a private
+    // LDS slab (the operand buffers are dead: every wave is past the last barrier) and leaves in whole 128-byte lines.
+    //   f16 output only (qkv, fc1): bias / LayerNorm / GELU in registers, f16 slab rows of 128 B, 8 lanes per row
+    //   fp32 output (residual stream writers): fp32 slab rows of 256 B, 16 lanes per row; residual, both outputs and
+    //   the row statistics after the read-back, where a row's 64 columns sit in 16 adjacent lanes (DPP row)
+    constexpr int BN = 256;
+    const int l15 = lane & 15, quad = lane >> 4;
+    const int col_base = wc * 64 + quad * 4;
+    float4_t bias4[4], csum4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        bias4[j] = *reinterpret_cast<const float4_t*>(colvec + col_base + j * 16);
+        if (EPI == EPI_NORM) csum4[j] = *reinterpret_cast<const float4_t*>(colvec + BN + col_base + j * 16);
+    }
+    char* slab = smem + wave * 8192;             // two slabs of 4 KB per wave, used alternately
+    const int resid_row0 = a.resid ? m0 % a.resid_mod : 0;
+    if (a.out_f32 == nullptr) {
+        // ---- f16 rows: slot = 8-byte piece (j*4 + quad) of a 128-byte row, XORed with (row & 7) << 1 (pairs stay adjacent)
+        const int rd_row = lane >> 3, rd_chunk = lane & 7;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            char* sl = slab + (i & 1) * 4096;
+            float2_t st = float2_t{0.f, 1.f};
+            if (EPI == EPI_NORM) st = reinterpret_cast<const float2_t*>(rowstat)[row_base + i * 16 + l15];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float4_t v = float4_t{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (EPI == EPI_NORM) v = (v - csum4[j] * st[0]) * st[1];
+                v += bias4[j];
+                if (ACT == k::ACT_GELU) v = gelu4(v);
+                const half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                // piece index (j*4 + quad) ^ ((l15&7)<<1): j*4 occupies bits 2-3, the XOR mask bits 1-3
+                const int piece = (j * 4 + quad) ^ ((l15 & 7) << 1);
+                *reinterpret_cast<half4_t*>(sl + l15 * 128 + piece * 8) = h;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int r = kk * 8 + rd_row;
+                const float4_t piece16 = *reinterpret_cast<const float4_t*>(sl + r * 128 + ((rd_chunk ^ (r & 7)) << 4));
+                const size_t m = (size_t)(m0 + row_base + i * 16 + r);
+                *reinterpret_cast<float4_t*>(a.out_h + m * a.ldc16 + n0 + wc * 64 + rd_chunk * 8) = piece16;
+            }
+        }
+    } else {
+        // The residual / f16-copy options are compile-time inside the band loop: a run-time test per load makes the
+        // compiler branch around each one and drain the memory counter at every join (cdna_hip_programming.md, "Three
+        // .s-level traps" (c)): 11-12 k cycles for four bands instead of 3 k.
+        auto fp32_bands = [&](auto resid_tag, auto h_tag) {
+            constexpr bool HAS_RESID = decltype(resid_tag)::value;
+            constexpr bool HAS_H = decltype(h_tag)::value;
+            // ---- fp32 rows of 64 floats: 16-byte slot (j*4 + quad) ^ (row & 7)
+            const int rd_row = lane >> 4, rd_slot = lane & 15;
+            // the band's residual in whole lines, requested one band ahead of its use (its latency would otherwise be
+            // paid once per band: 3.5 k cycles per band measured)
+            float4_t rv[2][4];
+            auto request_residual = [&](int i, float4_t (&dst)[4]) {
+    #pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    dst[kk] = float4_t{0.f, 0.f, 0.f, 0.f};
+                    const int r = kk * 4 + rd_row;
+                    if (HAS_RESID)
+                        dst[kk] = *reinterpret_cast<const float4_t*>(a.resid + (size_t)(resid_row0 + row_base + i * 16 + r) * a.ldr +
+                                                                     n0 + wc * 64 + rd_slot * 4);
+                }
+            };
+            if (!PRE) request_residual(0, rv[0]);
+    #pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                char* sl = slab + (i & 1) * 4096;
+                float2_t st = float2_t{0.f, 1.f};
+                if (EPI == EPI_NORM) st = reinterpret_cast<const float2_t*>(rowstat)[row_base + i * 16 + l15];
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float4_t v = float4_t{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    if (EPI == EPI_NORM) v = (v - csum4[j] * st[0]) * st[1];
+                    v += bias4[j];
+                    if (ACT == k::ACT_GELU) v = gelu4(v);
+                    *reinterpret_cast<float4_t*>(sl + l15 * 256 + (((j * 4 + quad) ^ (l15 & 7)) << 4)) = v;
+                }
+                if (!PRE && i + 1 < NI) request_residual(i + 1, rv[(i + 1) & 1]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    #pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int r = kk * 4 + rd_row;
+                    float4_t v = *reinterpret_cast<const float4_t*>(sl + r * 256 + ((rd_slot ^ (r & 7)) << 4));
+                    v += PRE ? pre[i][kk] : rv[i & 1][kk];
+                    const size_t m = (size_t)(m0 + row_base + i * 16 + r);
+                    const int col = n0 + wc * 64 + rd_slot * 4;
+                    *reinterpret_cast<float4_t*>(a.out_f32 + m * a.ldc32 + col) = v;
+                    if (HAS_H) {
+                        const half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                        *reinterpret_cast<half4_t*>(a.out_h + m * a.ldc16 + col) = h;
+                    }
+                    if (EPI == EPI_STATS) {
+                        // the row's 64 columns of this wave are in the 16 lanes of one DPP row: (sum, squared deviations)
+                        float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+                        s1 += dpp_move<0xB1>(s1);        // quad_perm [1,0,3,2]
+                        s1 += dpp_move<0x4E>(s1);        // quad_perm [2,3,0,1]
+                        s1 += dpp_move<0x141>(s1);       // row_half_mirror
+                        s1 += dpp_move<0x140>(s1);       // row_mirror
+                        const float4_t d = v - s1 * (1.0f / 64.0f);
+                        float m2 = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+                        m2 += dpp_move<0xB1>(m2);
+                        m2 += dpp_move<0x4E>(m2);
+                        m2 += dpp_move<0x141>(m2);
+                        m2 += dpp_move<0x140>(m2);
+                        if (rd_slot == 0) rowpart[(row_base + i * 16 + r) * 4 + wc] = float2_t{s1, m2};
+                    }
+                }
+            }
+    
+        };
+        if (a.resid) {
+            if (a.out_h) fp32_bands(std::true_type{}, std::true_type{});
+            else fp32_bands(std::true_type{}, std::false_type{});
+        } else {
+            if (a.out_h) fp32_bands(std::false_type{}, std::true_type{});
+            else fp32_bands(std::false_type{}, std::false_type{});
+        }
+    }
+    if (EPI == EPI_STATS) {
+        __syncthreads();
+        for (int r = threadIdx.x; r < NI * 32; r += 512) {
+            float s1 = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) s1 += rowpart[r * 4 + g][0];
+            const float mean = s1 * (1.0f / (float)BN);
+            float m2 = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float dm = rowpart[r * 4 + g][0] * (1.0f / 64.0f) - mean;
+                m2 += rowpart[r * 4 + g][1] + 64.0f * dm * dm;
+            }
+            reinterpret_cast<float2_t*>(a.stats_out)[(size_t)(n0 / BN) * a.M + m0 + r] = float2_t{s1, m2};
+        }
+    }
+}
+
+template <int ACT, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(k::GemmArgs a) {
+    constexpr int BM = 256, BN = 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = lane_id();
+    const int wave = wave_id();
+    const int wr = wave >> 2, wc = wave & 3;
+    const int l15 = lane & 15, quad = lane >> 4;
+
+    const int ntn = a.N / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / ntn) * BM;
+    const int n0 = (tile % ntn) * BN;
+    const int nk = a.K / 64;
+
+    float* rowstat = reinterpret_cast<float*>(smem + 2 * kPPBufBytes);
+    float* colvec = rowstat + 2 * BM;
+    float2_t* rowpart = reinterpret_cast<float2_t*>(colvec + 2 * BN);
+
+    float4v acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+
+    // ---- DMA sources: piece p = 2*wave + q of a half-tile = rows 8p .. 8p+7, lane -> (row, swizzled chunk)
+    const half_t* src_a[2];
+    const half_t* src_w[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = (wave * 2 + q) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        src_a[q] = a.A + (size_t)(m0 + row) * a.lda + chunk * 8;
+        src_w[q] = a.W + (size_t)(n0 + row) * a.ldw + chunk * 8;
+    }
+    const size_t a_half = (size_t)128 * a.lda, w_half = (size_t)128 * a.ldw;
+    // H: 0 = A rows 0-127, 1 = A rows 128-255, 2 = W rows 0-127, 3 = W rows 128-255
+    auto stage = [&](int t, int H) {
+        char* dst = smem + (t & 1) * kPPBufBytes + H * kPPHalfBytes + wave * 2048;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const half_t* g = (H < 2 ? src_a[q] + (H & 1) * a_half : src_w[q] + (H & 1) * w_half) + (size_t)t * 64;
+            glds16(g, dst + q * 1024);
+        }
+    };
+
+    // ---- fragment addresses: row l15 of a 16-row tile, chunk 4*ks + quad, swizzle (l15 >> 1) & 7 (tile bases are
+    // multiples of 16 rows and do not touch the swizzle bits)
+    const int sw = (l15 >> 1) & 7;
+    const int off0 = l15 * 128 + ((quad ^ sw) << 4);
+    const int off1 = l15 * 128 + (((quad ^ sw) ^ 4) << 4);
+    const char* a_base = smem + wr * kPPHalfBytes;                                     // + buffer + (mh*64 + i*16) * 128
+    const char* w_base = smem + (2 + (wc >> 1)) * kPPHalfBytes + (wc & 1) * 64 * 128;  // + buffer + (nh*32 + j*16) * 128
+    auto frag = [&](const char* p) { return *reinterpret_cast<const half8_t*>(p); };
+
+    const unsigned long long t_start = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long r_start = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    ColumnVectors<BM, BN, 512, EPI> column_vectors;
+    RowStats<BM, 512, EPI> row_stats;
+    column_vectors.issue(a, n0);                 // ordinary loads first: they are the oldest entries of the vm counter
+    row_stats.issue(a, m0);
+    stage(0, 0); stage(0, 1); stage(0, 2); stage(0, 3);
+    if (nk > 1) { stage(1, 2); stage(1, 3); }
+    column_vectors.store(colvec);
+    row_stats.finish(a, rowstat);
+    if (nk > 1) wait_dma<4>(); else wait_dma<0>();
+    pp_barrier();                                // tile 0 is visible to every wave
+    if (wr == 1) pp_barrier();                   // group 1 runs one slot behind group 0
+
+    half8_t fa[4][2], fw[2][2][2];               // A: [i][ks]; W: [nh][j][ks]
+    auto mfma_quadrant = [&](int mh, int nh) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[mh * 4 + i][nh * 2 + j] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[nh][j][ks], fa[i][ks], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto read_a = [&](int buf, int mh) {
+        const char* p = a_base + buf * kPPBufBytes + mh * 64 * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[i][0] = frag(p + i * 2048 + off0);
+            fa[i][1] = frag(p + i * 2048 + off1);
+        }
+    };
+    auto read_w = [&](int buf, int nh) {
+        const char* p = w_base + buf * kPPBufBytes + nh * 32 * 128;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            fw[nh][j][0] = frag(p + j * 2048 + off0);
+            fw[nh][j][1] = frag(p + j * 2048 + off1);
+        }
+    };
+    // One K tile.  STEADY: tiles t+1 and t+2 exist, nothing is conditional (one basic block: the compiler's own wait
+    // counts stay exact).
+    auto step = [&](int t, auto buf_tag, auto steady_tag) {
+        constexpr int buf = decltype(buf_tag)::value;
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        // phase 0
+        read_w(buf, 0);
+        read_a(buf, 0);
+        if (STEADY || t + 1 < nk) stage(t + 1, 0);
+        pp_barrier_after_reads();
+        mfma_quadrant(0, 0);
+        pp_barrier();
+        // phase 1
+        read_w(buf, 1);
+        if (STEADY || t + 1 < nk) stage(t + 1, 1);
+        pp_barrier_after_reads();
+        mfma_quadrant(0, 1);
+        pp_barrier();
+        // phase 2
+        read_a(buf, 1);
+        if (STEADY || t + 2 < nk) stage(t + 2, 2);
+        pp_barrier_after_reads();
+        mfma_quadrant(1, 1);
+        pp_barrier();
+        // phase 3
+        if (STEADY || t + 2 < nk) {
+            stage(t + 2, 3);
+            wait_dma<4>();                       // everything older than W(t+2) has landed: tile t+1 is complete
+        } else {
+            wait_dma<0>();
+        }
+        pp_barrier();
+        mfma_quadrant(1, 0);
+        pp_barrier();
+    };
+    using Even = std::integral_constant<int, 0>;
+    using Odd = std::integral_constant<int, 1>;
+    const unsigned long long t_loop = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long r_loop = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    int t = 0;
+    for (; t + 3 < nk; t += 2) {
+        step(t, Even{}, std::true_type{});
+        step(t + 1, Odd{}, std::true_type{});
+    }
+    for (; t < nk; t += 2) {
+        step(t, Even{}, std::false_type{});
+        if (t + 1 < nk) step(t + 1, Odd{}, std::false_type{});
+    }
+    if (wr == 0) pp_barrier();                   // group 0 waits for group 1's last M segment: barrier counts match
+    const unsigned long long t_loop_end = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long r_loop_end = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+
+    pp_epilogue<8, ACT, EPI>(a, acc, smem, rowstat, colvec, rowpart, m0, n0, wr * 128, wc, wave, lane);
+    if (a.stamps && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the wave's own stores have left
+        unsigned long long* d = a.stamps + (size_t)blockIdx.x * 4;
+        d[0] = t_loop_end - t_loop;
+        d[1] = r_loop_end - r_loop;
+        d[2] = ((t_loop - t_start) << 32) | ((__builtin_amdgcn_s_memtime() - t_loop_end) & 0xffffffffull);   // prologue | epilogue cycles
+        d[3] = __builtin_amdgcn_s_memrealtime() - r_start;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// 128 x 256 x 64 variant of the ping-pong kernel, for the GEMMs whose N gives too few 256 x 256 tiles (proj / fc2 of
+// ViT-B: N = 768 -> 96 workgroups instead of 48).  Same two wave groups one barrier apart; a wave owns 64 x 64 (4 x 4
+// accumulator tiles), group g the A rows 64g .. 64g+63, and a K tile takes TWO phases of 16 MFMAs:
+//   phase           reads                                              stages
+//   0 (cols nh0)    A rows of the group (8 x b128), W cols nh0 (4)     W0, W1 of tile t+2
+//   1 (cols nh1)    W cols nh1 (4)                                     A of tile t+2, then wait: tile t+1 landed
+// LDS: A in 2 buffers of 16 KB (128 rows), W in 3 buffers of 2 x 16 KB: A(t) is last read in slot 4t+1 (group 1, phase
+// 0) and restaged from slot 4t+2 on; W(t) is last read in slot 4t+3 and its buffer is next written for tile t+3 in
+// slot 4t+4 (the third W buffer is what puts 7 slots between a request and its first read instead of 3).
+// vmcnt(6): the A/W requests of tiles t+2 issued in this tile may stay in flight, everything older has landed.
+constexpr int kPP128WBase = 2 * kPPHalfBytes;                        // A buffers first
+constexpr int kPP128Operands = 2 * kPPHalfBytes + 3 * 2 * kPPHalfBytes;   // 128 KB
+constexpr int kPP128Aux = 128 * 8 + 2 * 256 * 4 + 128 * 4 * 8;
+constexpr int kPP128Lds = kPP128Operands + kPP128Aux;
+
+template <int ACT, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(k::GemmArgs a) {
+    constexpr int BM = 128, BN = 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = lane_id();
+    const int wave = wave_id();
+    const int wr = wave >> 2, wc = wave & 3;
+    const int l15 = lane & 15, quad = lane >> 4;
+
+    const int ntn = a.N / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / ntn) * BM;
+    const int n0 = (tile % ntn) * BN;
+    const int nk = a.K / 64;
+
+    float* rowstat = reinterpret_cast<float*>(smem + kPP128Operands);
+    float* colvec = rowstat + 2 * BM;
+    float2_t* rowpart = reinterpret_cast<float2_t*>(colvec + 2 * BN);
+
+    float4v acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+
+    const half_t* src_a[2];
+    const half_t* src_w[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = (wave * 2 + q) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        src_a[q] = a.A + (size_t)(m0 + row) * a.lda + chunk * 8;
+        src_w[q] = a.W + (size_t)(n0 + row) * a.ldw + chunk * 8;
+    }
+    const size_t w_half = (size_t)128 * a.ldw;
+    auto stage_a = [&](int t) {
+        char* dst = smem + (t & 1) * kPPHalfBytes + wave * 2048;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) glds16(src_a[q] + (size_t)t * 64, dst + q * 1024);
+    };
+    auto stage_w = [&](int t, int wbuf, int h) {
+        char* dst = smem + kPP128WBase + (wbuf * 2 + h) * kPPHalfBytes + wave * 2048;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) glds16(src_w[q] + h * w_half + (size_t)t * 64, dst + q * 1024);
+    };
+
+    const int sw = (l15 >> 1) & 7;
+    const int off0 = l15 * 128 + ((quad ^ sw) << 4);
+    const int off1 = l15 * 128 + (((quad ^ sw) ^ 4) << 4);
+    const char* a_base = smem + wr * 64 * 128;                                               // + A buffer + i * 2048
+    const char* w_base = smem + kPP128WBase + (wc >> 1) * kPPHalfBytes + (wc & 1) * 64 * 128;  // + W buffer + (nh*32 + j*16)*128
+    auto frag = [&](const char* p) { return *reinterpret_cast<const half8_t*>(p); };
+
+    ColumnVectors<BM, BN, 512, EPI> column_vectors;
+    RowStats<BM, 512, EPI> row_stats;
+    column_vectors.issue(a, n0);
+    row_stats.issue(a, m0);
+    // tiles 0 and 1 (tile t lives in A buffer t & 1 and W buffer t % 3)
+    stage_a(0); stage_w(0, 0, 0); stage_w(0, 0, 1);
+    if (nk > 1) { stage_a(1); stage_w(1, 1, 0); stage_w(1, 1, 1); }
+    column_vectors.store(colvec);
+    row_stats.finish(a, rowstat);
+    if (nk > 1) wait_dma<6>(); else wait_dma<0>();
+    // Stream writers: the residual of the wave's 64 x 64 part (64 registers, which this tile can afford) is requested
+    // now and used in the epilogue.  These requests are younger than everything the main loop's counted waits must
+    // see landed, and in-order completion means they can only make those waits stricter while they are in flight.
+    constexpr bool PRE = EPI == EPI_STATS;
+    float4_t rpre[4][4];
+    if (PRE) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) rpre[i][kk] = float4_t{0.f, 0.f, 0.f, 0.f};
+        if (a.resid) {                           // one uniform branch around all sixteen requests
+            const int resid_row0 = m0 % a.resid_mod;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    rpre[i][kk] = *reinterpret_cast<const float4_t*>(
+                        a.resid + (size_t)(resid_row0 + wr * 64 + i * 16 + kk * 4 + (lane >> 4)) * a.ldr + n0 + wc * 64 + (lane & 15) * 4);
+        }
+    }
+    pp_barrier();
+    if (wr == 1) pp_barrier();
+
+    half8_t fa[4][2], fw[2][2];                  // A: [i][ks]; W of the current column half: [j][ks]
+    auto mfma_half = [&](int nh) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][nh * 2 + j] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[j][ks], fa[i][ks], acc[i][nh * 2 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto read_w = [&](const char* wb, int nh) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            fw[j][0] = frag(wb + (nh * 32 + j * 16) * 128 + off0);
+            fw[j][1] = frag(wb + (nh * 32 + j * 16) * 128 + off1);
+        }
+    };
+    int wbuf = 0;                                // t % 3
+    auto step = [&](int t, auto steady_tag) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        const char* ab = a_base + (t & 1) * kPPHalfBytes;
+        const char* wb = w_base + wbuf * 2 * kPPHalfBytes;
+        const int wbuf2 = wbuf == 0 ? 2 : wbuf - 1;      // (t + 2) % 3
+        // phase 0
+        read_w(wb, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[i][0] = frag(ab + i * 2048 + off0);
+            fa[i][1] = frag(ab + i * 2048 + off1);
+        }
+        if (STEADY || t + 2 < nk) { stage_w(t + 2, wbuf2, 0); stage_w(t + 2, wbuf2, 1); }
+        pp_barrier_after_reads();
+        mfma_half(0);
+        pp_barrier();
+        // phase 1
+        read_w(wb, 1);
+        if (STEADY || t + 2 < nk) {
+            stage_a(t + 2);
+            asm volatile("s_waitcnt lgkmcnt(0) vmcnt(6)\n\ts_barrier" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(1);
+        pp_barrier();
+        wbuf = wbuf == 2 ? 0 : wbuf + 1;
+    };
+    const unsigned long long t_loop = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long r_loop = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    int t = 0;
+    for (; t + 2 < nk; ++t) step(t, std::true_type{});
+    for (; t < nk; ++t) step(t, std::false_type{});
+    if (wr == 0) pp_barrier();
+    const unsigned long long t_loop_end = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long r_loop_end = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+
+    pp_epilogue<4, ACT, EPI, PRE>(a, acc, smem, rowstat, colvec, rowpart, m0, n0, wr * 64, wc, wave, lane, PRE ? rpre : nullptr);
+    if (a.stamps && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* d = a.stamps + (size_t)blockIdx.x * 4;
+        d[0] = t_loop_end - t_loop;
+        d[1] = r_loop_end - r_loop;
+        d[2] = (__builtin_amdgcn_s_memtime() - t_loop_end) & 0xffffffffull;
+        d[3] = 0;
+    }
+}
+
 typedef void (*GemmKernel)(k::GemmArgs);
 
 // Picks the epilogue flavour the arguments ask for and launches; LDS above the default limit is opted into once.
@@ -569,6 +1107,25 @@ void launch(const k::GemmArgs& a, hipStream_t s, Timing t) {
     launch_flavour(kernels, attr_once, a, (a.M / BM) * (a.N / BN), 64 * WGM * WGN, lds, s, t);
 }
 
+void launch_pp(const k::GemmArgs& a, hipStream_t s, Timing t) {
+    static const GemmKernel kernels[5] = {
+        gemm_pp_kernel<k::ACT_NONE, EPI_PLAIN>, gemm_pp_kernel<k::ACT_GELU, EPI_PLAIN>, gemm_pp_kernel<k::ACT_NONE, EPI_NORM>,
+        gemm_pp_kernel<k::ACT_GELU, EPI_NORM>,  gemm_pp_kernel<k::ACT_NONE, EPI_STATS>,
+    };
+    static std::once_flag attr_once[5];
+    launch_flavour(kernels, attr_once, a, (a.M / 256) * (a.N / 256), 512, kPPLds, s, t);
+}
+
+void launch_pp128(const k::GemmArgs& a, hipStream_t s, Timing t) {
+    static const GemmKernel kernels[5] = {
+        gemm_pp128_kernel<k::ACT_NONE, EPI_PLAIN>, gemm_pp128_kernel<k::ACT_GELU, EPI_PLAIN>,
+        gemm_pp128_kernel<k::ACT_NONE, EPI_NORM>,  gemm_pp128_kernel<k::ACT_GELU, EPI_NORM>,
+        gemm_pp128_kernel<k::ACT_NONE, EPI_STATS>,
+    };
+    static std::once_flag attr_once[5];
+    launch_flavour(kernels, attr_once, a, (a.M / 128) * (a.N / 256), 512, kPP128Lds, s, t);
+}
+
 }  // namespace
 
 namespace k {
@@ -605,8 +1162,11 @@ constexpr TileCfg kTiles[] = {
     {128, 64, 3, 0.55f},    // 4: 2x2 waves, BK 64, 2 stages, 48 KB LDS
     {64, 64, 4, 0.40f},     // 5: 2x2 waves, BK 64, 2 stages, 32 KB LDS
     {256, 256, 1, 0.00f},   // 6: 8 waves 2x4 (128x64 each), BK 32, 4 stages, 128 KB LDS (shared-GPU mode or forced)
-    {256, 256, 1, 1.45f},   // 7: as 6 on v_mfma_f32_16x16x32_f16, fragments one K tile ahead (4096^3: 1010 TFLOP/s)
+    {256, 256, 1, 0.00f},   // 7: as 6 on v_mfma_f32_16x16x32_f16, fragments one K tile ahead (4096^3: 1010 TFLOP/s); forced only
     {128, 128, 2, 0.00f},   // 8: 2x2 waves on 16x16x32, BK 32, 4 stages, 64 KB LDS (forced only until measured)
+    {256, 256, 1, 1.60f},   // 9: ping-pong kernel (gemm_pp_kernel): 8 waves in two groups one barrier apart, BK 64
+                            //    (4096^3: 1110-1160 TFLOP/s at the 1.3-1.6 GHz the chip holds under that load)
+    {128, 256, 1, 0.00f},   // 10: 128 x 256 ping-pong kernel (gemm_pp128_kernel), two phases per K tile
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -614,10 +1174,15 @@ constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 // that leave room for a second workgroup on the CU (<= 64 KB LDS) let those kernels overlap, which is worth more
 // than the better isolated efficiency of the one-workgroup-per-CU tiles (measured: +8 % images/s).  It is a property
 // of the caller (SamModel knows how many lanes share its device), not process state.
+bool gemm_tile_fits(const GemmArgs& a, int tile) {
+    if (tile < 0 || tile >= kNumTiles) return false;
+    const TileCfg& t = kTiles[tile];
+    return a.M % t.bm == 0 && a.N % t.bn == 0 && !(a.resid && a.resid_mod % t.bm != 0);
+}
+
 int gemm_pick_tile(const GemmArgs& a) {
-    if (a.tile >= 0) return a.tile < kNumTiles ? a.tile : -1;     // chosen earlier by the caller (pick once, use twice)
-    // tuning/test aid, not a user knob; read once
-    static const int forced = [] { const char* e = std::getenv("DLIMGEDIT_GEMM_TILE"); return e ? std::atoi(e) : -1; }();
+    if (a.tile >= 0) return gemm_tile_fits(a, a.tile) ? a.tile : -1;     // chosen earlier (pick once, use twice) or forced
+    const int forced = -1;
     int best = -1;
     float best_score = -1.f;
     const int unit = (a.unit_rows > 0 && a.M % a.unit_rows == 0) ? a.unit_rows : a.M;   // rows the choice is made for
@@ -630,7 +1195,12 @@ int gemm_pick_tile(const GemmArgs& a) {
     // workgroups, +2 % images/s; at 48, ViT-B proj / fc2, the longer kernel costs more than it frees)
     if (shared && forced < 0 && unit % 256 == 0 && a.N % 256 == 0 &&
         (unit / 256) * (a.N / 256) >= 64 && !wraps_inside(256))
-        return 7;
+        return 9;
+    // too few 256 x 256 tiles (ViT-B proj / fc2: 48): the 128 x 256 ping-pong kernel doubles them
+    static const bool use_pp128 = [] { const char* e = std::getenv("DLIMGEDIT_GEMM_PP128"); return !e || std::atoi(e) != 0; }();
+    if (use_pp128 && shared && forced < 0 && unit % 128 == 0 && a.N % 256 == 0 && (unit / 128) * (a.N / 256) >= 64 &&
+        !wraps_inside(128))
+        return 10;
     for (int i = 0; i < kNumTiles; ++i) {
         const TileCfg& t = kTiles[i];
         if (unit % t.bm || a.N % t.bn || wraps_inside(t.bm)) continue;
@@ -653,7 +1223,7 @@ int gemm_pick_tile(const GemmArgs& a) {
 
 int gemm_choose_tile(GemmArgs& a) {
     if (const char* err = gemm_check(a)) throw_error(err);
-    a.tile = -1;
+    if (!gemm_tile_fits(a, a.tile)) a.tile = -1;      // a tile set beforehand (test hooks) stays if it can run the problem
     a.tile = gemm_pick_tile(a);
     if (a.tile < 0) throw_error("gemm: no tile configuration fits this shape");
     return kTiles[a.tile].bn;
@@ -672,6 +1242,8 @@ void gemm(const GemmArgs& a, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
     case 6: return launch<256, 256, 2, 4, 32, 4, 2>(a, s, t);
     case 7: return launch16<256, 256, 2, 4, 4, 2>(a, s, t);
     case 8: return launch16<128, 128, 2, 2, 4, 2>(a, s, t);
+    case 9: return launch_pp(a, s, t);
+    case 10: return launch_pp128(a, s, t);
     default: throw_error("gemm: no tile configuration fits this shape");
     }
 }

@@ -44,8 +44,12 @@ struct GemmArgs {
     // Rows of ONE independent unit (an image: 4096 tokens) when M stacks several of them.  The tile is chosen for the
     // unit's shape, so a batch runs the same tiles -- and produces the same bits -- as its images one at a time.
     int unit_rows = 0;
+    // Diagnostics (tuning builds of the benchmark hook only; null in the product): per workgroup 4 x u64 =
+    // { shader cycles, 100 MHz ticks } of the main loop and of the whole kernel, written by wave 0.
+    unsigned long long* stamps = nullptr;
 };
 const char* gemm_check(const GemmArgs&);
+bool gemm_tile_fits(const GemmArgs&, int tile);   // may `tile` (index into gemm.hip's table) run this problem?
 int gemm_choose_tile(GemmArgs&);              // sets a.tile; returns BN (columns per tile) of that configuration
 // start/stop (both or neither): events attached to the kernel's own dispatch (hipExtLaunchKernelGGL): their elapsed time
 // is the kernel's execution time as a profiler reports it, without the marker packets an hipEventRecord pair adds.

@@ -123,6 +123,12 @@ DLIMG_API int dlimg_amd_bench_gemm(int M, int N, int K, int act, int flavour, in
 DLIMG_API int dlimg_amd_bench_gemm_streams(int M, int N, int K, int act, int flavour, int tile, int shared, int streams,
                                            int iters, double* out_ms);
 
+/* The same; additionally returns in-kernel time stamps of the LAST launch on stream 0 for kernels that record them
+ * (the ping-pong GEMM): per workgroup 4 x u64 = {shader cycles, 100 MHz ticks} of the main loop and of the whole
+ * kernel.  max_groups must be >= the grid size. */
+DLIMG_API int dlimg_amd_bench_gemm_stamps(int M, int N, int K, int act, int flavour, int tile, int shared, int streams,
+                                          int iters, double* out_ms, unsigned long long* out_stamps, int max_groups);
+
 #ifdef __cplusplus
 }
 #endif

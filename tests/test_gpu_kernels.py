@@ -155,7 +155,11 @@ def test_gemm_parity(ext, M, N, K, act, with_bias, resid_rows):
 
 @pytest.mark.parametrize("tile,M,N,K", [(0, 256, 768, 192), (1, 256, 576, 256), (2, 256, 256, 128), (3, 256, 192, 320),
                                         (4, 256, 128, 64), (5, 128, 64, 128), (6, 512, 512, 192), (6, 256, 256, 64),
-                                        (7, 512, 512, 192), (7, 256, 256, 64), (8, 256, 384, 320)])
+                                        (7, 512, 512, 192), (7, 256, 256, 64), (8, 256, 384, 320),
+                                        (9, 512, 512, 192), (9, 256, 256, 64), (9, 256, 512, 128), (9, 512, 256, 448),
+                                        (9, 768, 512, 1024),
+                                        (10, 256, 512, 192), (10, 128, 256, 64), (10, 384, 256, 448), (10, 256, 768, 1024),
+                                        (10, 128, 256, 128)])
 def test_gemm_every_tile_configuration(ext, monkeypatch, tile, M, N, K):
     """Each tile configuration (waves layout, K-tile, pipeline depth) against the fp32 product, incl. K tails
     shorter than the pipeline depth."""
@@ -188,6 +192,10 @@ def test_gemm_identity_layout(ext):
     (4096, 320, 320, 1280, 1, None),       # head_dim-80 test width
     (512, 1024, 256, 512, 0, 6),           # 32x32x16 256x256 tile on both sides
     (512, 1024, 256, 512, 1, 7),           # 16x16x32 256x256 tile on both sides
+    (512, 1024, 256, 512, 1, 9),           # ping-pong 256x256 kernel on both sides
+    (4096, 768, 768, 2304, 0, 9),          # ... at ViT-B's proj -> LN1 -> qkv
+    (512, 1024, 256, 512, 1, 10),          # 128x256 ping-pong kernel on both sides
+    (4096, 768, 3072, 768, 0, 10),         # ... as ViT-B's fc2 (producer of the stream and its statistics)
     (256, 256, 128, 256, 0, 2),
     (256, 256, 128, 384, 0, 8),
 ])
