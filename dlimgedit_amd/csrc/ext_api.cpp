@@ -380,7 +380,11 @@ DLIMG_API int dlimg_amd_test_attention(int global, uint16_t const* qkv, float co
         DeviceBuffer<half_t> o(rows * D);
         HIP_CHECK(hipMemset(o.get(), 0, rows * D * sizeof(half_t)));
         if (global) {
-            k::attention_global(dq.get(), dh.get(), dw.get(), o.get(), batch, heads, hd, nullptr);
+            const size_t n = (size_t)(2 * span - 1) * hd;
+            DeviceBuffer<half_t> dh16(n), dw16(n);
+            k::cast_f16(dh.get(), dh16.get(), n, nullptr);
+            k::cast_f16(dw.get(), dw16.get(), n, nullptr);
+            k::attention_global(dq.get(), dh16.get(), dw16.get(), o.get(), batch, heads, hd, nullptr);
         } else {
             DLIMG_ASSERT(qkv_bias != nullptr);
             k::attention_window(dq.get(), db.get(), dh.get(), dw.get(), o.get(), batch, heads, hd, nullptr);

@@ -563,10 +563,12 @@ constexpr int kPPLds = 2 * kPPBufBytes + kPPAuxBytes;
 // L segment's end: fragment reads of this wave have returned, then the workgroup barrier.  One statement with a memory
 // clobber: the compiler moves no LDS access across it.
 DLIMG_DEVICE void pp_barrier_after_reads() {
+    __builtin_amdgcn_sched_barrier(0);           // nothing (MFMAs included) moves across the segment boundary
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
 DLIMG_DEVICE void pp_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -1025,8 +1027,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(k::GemmArgs a) {
         read_w(wb, 1);
         if (STEADY || t + 2 < nk) {
             stage_a(t + 2);
+            __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(0) vmcnt(6)\n\ts_barrier" ::: "memory");
         } else {
+            __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)\n\ts_barrier" ::: "memory");
         }
         __builtin_amdgcn_sched_barrier(0);

@@ -84,10 +84,10 @@ void cast_f16(const float* in, half_t* out, size_t n, hipStream_t);
 // ---- encoder attention -----------------------------------------------------------------------
 // qkv: [B*4096, 3*D] f16 token-major (q | k | v, head-major inside each), out: [B*4096, D] f16.
 // qkv_bias: f32 [3*D] (keys/values of zero-padded window tokens equal the bias).
-// rel_h/rel_w: f32 [2*S-1, hd] with S = 14 (windowed) or 64 (global).
+// rel_h/rel_w: [2*S-1, hd] with S = 14 (windowed, f32) or 64 (global, f16: converted once when the weights are loaded).
 void attention_window(const half_t* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w,
                       half_t* out, int B, int heads, int hd, hipStream_t);
-void attention_global(const half_t* qkv, const float* rel_h, const float* rel_w, half_t* out, int B,
+void attention_global(const half_t* qkv, const half_t* rel_h, const half_t* rel_w, half_t* out, int B,
                       int heads, int hd, hipStream_t);
 
 // ---- mask decoder (token side is tiny: fp32 VALU kernels) ------------------------------------

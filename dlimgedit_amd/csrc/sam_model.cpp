@@ -158,8 +158,15 @@ SamWeights::SamWeights(std::string const& weight_path, int device_index) : devic
             ld.linear_h(p + ".qkv", 3 * D, D, true, L.qkv);
             ld.linear_h(p + ".fc1", geom_.mlp_dim, D, true, L.fc1);
         }
-        ld.f32(p + ".rel_h", {2 * span - 1, hd}, L.rel_h);
-        ld.f32(p + ".rel_w", {2 * span - 1, hd}, L.rel_w);
+        if (L.global) {
+            HostTensor const& rh = file.get(p + ".rel_h", {2 * span - 1, hd});
+            HostTensor const& rw = file.get(p + ".rel_w", {2 * span - 1, hd});
+            ld.f16_host(rh.data, rh.numel(), L.rel_h16);
+            ld.f16_host(rw.data, rw.numel(), L.rel_w16);
+        } else {
+            ld.f32(p + ".rel_h", {2 * span - 1, hd}, L.rel_h);
+            ld.f32(p + ".rel_w", {2 * span - 1, hd}, L.rel_w);
+        }
         ld.linear_h(p + ".proj", D, D, true, L.proj);
         ld.linear_h(p + ".fc2", D, geom_.mlp_dim, true, L.fc2);
     }
@@ -553,7 +560,7 @@ void SamModel::encode(int batch, float* const* emb_dst) {
         if (L.global) {
             const double fl = (double)batch * (4.0 * kTokens * (double)kTokens * D + 4.0 * kTokens * 64.0 * hd * H);
             timed(ST_ATTN_GLOBAL, fl, [&] {
-                k::attention_global(qkv_.get(), L.rel_h.get(), L.rel_w.get(), att_.get(), batch, H, hd, stream_);
+                k::attention_global(qkv_.get(), L.rel_h16.get(), L.rel_w16.get(), att_.get(), batch, H, hd, stream_);
             });
         } else {
             const double fl = (double)batch * 25.0 * (4.0 * 196.0 * 196.0 * D + 4.0 * 196.0 * 14.0 * hd * H);

@@ -155,6 +155,34 @@ def synthetic_weights(cfg: SamConfig, seed: int = 0) -> Dict[str, np.ndarray]:
     return out
 
 
+def trained_like_weights(cfg: SamConfig, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Seeded synthetic weights with the activation statistics trained ViTs show and the uniform initialisation above
+    does not: (1) a handful of "massive activation" channels of the residual stream, 50-300x the magnitude of the others
+    and growing with depth (here: offsets in the patch-embedding bias plus contributions of every block's fc2 bias);
+    (2) LayerNorm scales spread over two orders of magnitude (0.05 .. 5, log-uniform), with small scales on the
+    massive channels as trained models learn them; (3) LayerNorm shifts of order one.  The folded-LayerNorm path
+    (f16 copy of the raw stream, `acc - mean * colsum` in the consuming GEMM) is what this stresses."""
+    p = synthetic_weights(cfg, seed)
+    rng = np.random.default_rng(seed + 12345)
+    D = cfg.embed_dim
+    massive = rng.choice(D, size=4, replace=False)
+    sign = rng.choice([-1.0, 1.0], size=4)
+    # typical stream magnitude with these weights is ~1; the massive channels start at 50-120 and grow to 150-300
+    p["enc.patch.b"] = p["enc.patch.b"].copy()
+    p["enc.patch.b"][massive] += (sign * rng.uniform(50.0, 120.0, 4)).astype(np.float32)
+    for i in range(cfg.depth):
+        pre = f"enc.L{i}"
+        b = p[pre + ".fc2.b"].copy()
+        b[massive] += (sign * rng.uniform(5.0, 15.0, 4)).astype(np.float32)
+        p[pre + ".fc2.b"] = b
+        for ln in (".ln1", ".ln2"):
+            g = np.exp(rng.uniform(np.log(0.05), np.log(5.0), D)).astype(np.float32)
+            g[massive] = rng.uniform(0.02, 0.1, 4).astype(np.float32)
+            p[pre + ln + ".w"] = g
+            p[pre + ln + ".b"] = rng.uniform(-1.0, 1.0, D).astype(np.float32)
+    return p
+
+
 # ---------------------------------------------------------------------------------------------
 # file format
 

@@ -308,3 +308,36 @@ def test_full_size_models_against_committed_golden(api, model_dirs, monkeypatch,
         best = single_mask_index(g[f"{name}_iou"])
         want = np.unpackbits(g[f"{name}_masks_bits"], axis=1).reshape(3, 1024, 1024)[best - 1] * 255
         assert iou(call(), want) >= IOU_BAR
+
+
+@pytest.mark.parametrize("variant", ["vit_test", "vit_b"])
+def test_trained_like_activation_statistics(api, tmp_path_factory, monkeypatch, variant):
+    """Weights with the activation statistics of trained ViTs (four "massive" residual channels at 150-250x the
+    rest, LayerNorm scales over 0.05..5; dlimgedit_amd.weights.trained_like_weights) through the whole path: the
+    folded-LayerNorm encoder (f16 copy of the RAW stream, mean correction in the consuming GEMM's epilogue) must stay
+    inside the same tolerances as on the uniform synthetic weights, and so must the separate-LayerNorm build."""
+    from dlimgedit_amd import weights as W
+    from dlimgedit_amd.sam_config import get_config
+    from oracle import sam_oracle as O
+    cfg = get_config(variant)
+    d = tmp_path_factory.mktemp(f"trained_like_{variant}")
+    params = W.trained_like_weights(cfg, seed=3)
+    W.save_weights(d / "segmentation" / W.weight_file_name(cfg), cfg, params)
+    monkeypatch.setenv("DLIMGEDIT_SAM_MODEL", variant)
+    img = synthetic_image(5)
+    ora = O.OracleSegmentation(params, cfg).process(img, O.CH_RGBA)
+    want = ora.compute_mask(point=(512, 512))
+    errs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("DLIMGEDIT_FUSED_LN", fused)
+        env = api.Environment(api.Options(api.Backend.gpu, str(d)))
+        seg = api.Segmentation.process(api.ImageView(img, api.Channels.rgba), env)
+        errs[fused] = float(np.abs(api.ext.get_embedding(seg) - ora.embedding).max())
+        assert errs[fused] < EMB_TOL, (fused, errs)
+        assert iou(seg.compute_mask(api.Point(512, 512)), want) >= IOU_BAR
+        got_box = seg.compute_mask(api.Region(api.Point(256, 256), api.Point(768, 768)))
+        assert iou(got_box, ora.compute_mask(region=(256, 256, 768, 768))) >= IOU_BAR
+        seg.close()
+        env.close()
+    # folding the LayerNorm in must not cost more than a small multiple of the separate kernels' own f16 error
+    assert errs["1"] <= 3.0 * errs["0"] + 5e-3, errs

@@ -1,0 +1,38 @@
+"""Runs the global (or windowed) attention kernel alone a few times: target of rocprofv3 --pmc / --kernel-trace runs.
+python tools/attn_probe.py [global|window] [heads] [hd] [reps]"""
+import sys
+from pathlib import Path
+import numpy as np
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from dlimgedit_amd import api
+
+kind = sys.argv[1] if len(sys.argv) > 1 else "global"
+heads = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+hd = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+rng = np.random.default_rng(0)
+D = heads * hd
+qkv = (rng.standard_normal((4096, 3 * D)) * 0.5).astype(np.float16)
+span = 64 if kind == "global" else 14
+rel_h = (rng.standard_normal((2 * span - 1, hd)) * 0.1).astype(np.float32)
+rel_w = (rng.standard_normal((2 * span - 1, hd)) * 0.1).astype(np.float32)
+bias = (rng.standard_normal(3 * D) * 0.1).astype(np.float32)
+for _ in range(reps):
+    out = api.ext.test_attention(kind == "global", qkv, bias, rel_h, rel_w, 1, heads, hd)
+print("ok", float(np.abs(out.astype(np.float32)).mean()))
+
+import os
+if os.environ.get("DLIMGEDIT_ATTN_PP_ABLATE") == "4":
+    o = np.ascontiguousarray(out)                      # [4096][D] f16
+    rows = []
+    for b in range(0, heads * 16, 3):                  # blocks with blockIdx % 3 == 0: (qblk, head) = (b % 16, b // 16)
+        qblk, head = b % 16, b // 16
+        r0 = o[qblk * 256, head * hd:head * hd + 32].view(np.uint64).astype(np.float64)      # A: tm tmb tx txb, B: ...
+        r1 = o[qblk * 256 + 1, head * hd:head * hd + 16].view(np.uint64).astype(np.float64)
+        rows.append(np.concatenate([r0, r1]))
+    raw = np.array(rows)
+    cyc, ticks, pro = np.median(raw[:, 8]), np.median(raw[:, 9]), np.median(raw[:, 10])
+    print(f"loop: {cyc:.0f} cycles = {cyc / 64:.0f} per tile, {ticks * 0.01:.1f} us, clock {cyc / ticks * 0.1:.2f} GHz; prologue {pro:.0f} cycles")
+    for g, name in ((0, "group A"), (1, "group B")):
+        tm, tmb, tx, txb = (np.median(raw[:, g * 4 + i]) / 64.0 for i in range(4))
+        print(f"{name}: per tile  M work {tm:6.0f} cyc + barrier wait {tmb:6.0f} | X work {tx:6.0f} cyc + barrier wait {txb:6.0f}  (sum {tm+tmb+tx+txb:6.0f})")
