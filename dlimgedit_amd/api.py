@@ -197,7 +197,9 @@ class Image:
         ch = C.c_int()
         px = C.c_void_p()
         _check(api().load_image(str(filepath).encode(), ext, C.byref(ch), C.byref(px)))
-        raise Error("load_image returned success unexpectedly")   # pragma: no cover (not part of this build)
+        img = Image.__new__(Image)               # adopt the library's allocation (freed by destroy_image)
+        img._extent, img._channels, img._ptr = Extent(ext[0], ext[1]), Channels(ch.value), px.value
+        return img
 
     @staticmethod
     def save(img: ImageView, filepath) -> None:

@@ -30,6 +30,7 @@ SOURCES = [
     "kernels/resize.hip",
     "kernels/objects.hip",
     "resize_tables.cpp",
+    "image_io.cpp",
     "weights.cpp",
     "sam_model.cpp",
     "environment.cpp",

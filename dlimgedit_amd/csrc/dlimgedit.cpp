@@ -9,6 +9,11 @@
 #include <vector>
 
 namespace dlimg {
+
+// image_io.cpp (host-side PNG reader / writer behind slots 8 and 9)
+uint8_t* load_image_file(char const* filepath, int* out_extent, int* out_channels);
+void save_image_file(dlimg_ImageView const& img, char const* filepath);
+
 namespace {
 
 // Per-thread so concurrent callers do not trample each other's message
@@ -88,12 +93,18 @@ dlimg_Result segment_objects(dlimg_ImageView const*, uint8_t*, dlimg_Environment
     return fail("segment_objects (BiRefNet) is not part of the MI355X build of dlimgedit");
 }
 
-dlimg_Result load_image(char const*, int*, int*, uint8_t**) {
-    return fail("Image file decoding is not part of the MI355X build of dlimgedit; pass pixels through ImageView");
+dlimg_Result load_image(char const* filepath, int* out_extent, int* out_channels, uint8_t** out_pixels) {
+    return guarded([&] {
+        DLIMG_ASSERT(filepath != nullptr && out_extent != nullptr && out_channels != nullptr && out_pixels != nullptr);
+        *out_pixels = load_image_file(filepath, out_extent, out_channels);
+    });
 }
 
-dlimg_Result save_image(dlimg_ImageView const*, char const*) {
-    return fail("Image file encoding is not part of the MI355X build of dlimgedit");
+dlimg_Result save_image(dlimg_ImageView const* image, char const* filepath) {
+    return guarded([&] {
+        DLIMG_ASSERT(image != nullptr && filepath != nullptr);
+        save_image_file(*image, filepath);
+    });
 }
 
 uint8_t* create_image(int w, int h, int channels) {
