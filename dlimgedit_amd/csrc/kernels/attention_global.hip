@@ -676,6 +676,7 @@ __global__ __launch_bounds__(512, 2) void attention_global_pp_kernel(const half_
     }
 }
 
+
 template <int HD>
 void launch_global(const half_t* qkv, const half_t* rel_h, const half_t* rel_w, half_t* out, int B, int heads,
                    hipStream_t s) {
