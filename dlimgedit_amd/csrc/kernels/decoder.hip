@@ -6,6 +6,8 @@
 #include "device_common.hpp"
 #include "kernels.hpp"
 
+#include <mutex>
+
 namespace dlimg {
 namespace {
 
@@ -135,13 +137,14 @@ constexpr int T2I_GROUPS = 8;                                  // key groups per
 constexpr int T2I_THREADS = 256;
 constexpr int T2I_KEYS = NTOK_IMG / T2I_GROUPS / T2I_THREADS;  // keys per thread
 constexpr int T2I_WAVES = T2I_THREADS / 64;
-constexpr int T2I_PARTS = T2I_GROUPS * T2I_WAVES;              // partial triples per (prompt, head, query)
+constexpr int T2I_PARTS = T2I_GROUPS;                          // partial triples per (prompt, head, query)
 
 __global__ __launch_bounds__(T2I_THREADS) void token_to_image_partial_kernel(const float* __restrict__ q,
                                                                              const half_t* __restrict__ K, int ldk,
                                                                              const half_t* __restrict__ V, int ldv,
                                                                              float* __restrict__ part) {
     __shared__ float sq[TOK * 16];
+    __shared__ float wpart[TOK][T2I_WAVES][18];
     const int grp = blockIdx.x % T2I_GROUPS, h = (blockIdx.x / T2I_GROUPS) % HEADS, p = blockIdx.x / (T2I_GROUPS * HEADS);
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     if (tid < TOK * 16) sq[tid] = q[((size_t)p * TOK + tid / 16) * INNER + h * 16 + (tid & 15)] * 0.25f;   // 16^-0.5
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(T2I_THREADS) void token_to_image_partial_kernel(con
         vreg[i][1] = *reinterpret_cast<const half8_t*>(vb + j * ldv + 8);
     }
     __syncthreads();
-    float* dst = part + ((((size_t)p * HEADS + h) * TOK) * T2I_PARTS + grp * T2I_WAVES + wave) * 18;
+    float* dst = part + ((((size_t)p * HEADS + h) * TOK) * T2I_PARTS + grp) * 18;
 #pragma unroll 1
     for (int t = 0; t < TOK; ++t) {
         // keep K / V as the f16 they arrived in: otherwise the conversions to float are hoisted out of the query loop
@@ -188,13 +191,25 @@ __global__ __launch_bounds__(T2I_THREADS) void token_to_image_partial_kernel(con
             for (int e = 0; e < 16; ++e) o[e] = fmaf(pj, (float)vreg[i][e >> 3][e & 7], o[e]);
         }
         const float ls = wave_sum(l);
-        float* d = dst + (size_t)t * T2I_PARTS * 18;
+        float* d = wpart[t][wave];
         if (lane == 0) { d[0] = M; d[1] = ls; }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const float x = wave_sum(o[e]);
             if (lane == 0) d[2 + e] = x;
         }
+    }
+    // the four waves' partials of every query are folded here, in wave order: one triple per workgroup leaves
+    __syncthreads();
+    if (tid < TOK * 18) {
+        const int t = tid / 18, e = tid % 18;
+        float M = wpart[t][0][0];
+#pragma unroll
+        for (int w = 1; w < T2I_WAVES; ++w) M = fmaxf(M, wpart[t][w][0]);
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < T2I_WAVES; ++w) acc += (e == 0 ? 0.f : wpart[t][w][e]) * __expf(wpart[t][w][0] - M);
+        dst[(size_t)t * T2I_PARTS * 18 + e] = e == 0 ? M : acc;
     }
 }
 
@@ -297,12 +312,27 @@ DLIMG_DEVICE void head_layer(const float* x /*LDS*/, const float* __restrict__ w
     }
 }
 
-__global__ __launch_bounds__(HEAD_THREADS) void output_heads_kernel(const float* __restrict__ queries, k::HeadWeights hw,
+__global__ __launch_bounds__(HEAD_THREADS) void output_heads_kernel(k::TokenRows queries, k::HeadWeights hw,
                                                                     float* __restrict__ hyper, float* __restrict__ iou) {
     __shared__ __attribute__((aligned(16))) float x0[DIM], x1[DIM], x2[DIM];
+    __shared__ float2_t stat[1];
     const int p = blockIdx.x, mi = blockIdx.y;
     const int tok = mi < 4 ? 1 + mi : 0;
-    if (threadIdx.x < DIM) x0[threadIdx.x] = queries[((size_t)p * TOK + tok) * DIM + threadIdx.x];
+    const size_t row = (size_t)p * TOK + tok;
+    // the token after norm_final_attn: statistics of its row by wave 0, normalised while it is staged
+    if (queries.ln_w && threadIdx.x < 64) {
+        const float4_t v = reinterpret_cast<const float4_t*>(queries.x + row * DIM)[threadIdx.x];
+        const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / DIM);
+        const float4_t d = v - mean;
+        const float var = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / DIM);
+        if (threadIdx.x == 0) stat[0] = float2_t{mean, 1.0f / sqrtf(var + queries.eps)};
+    }
+    __syncthreads();
+    if (threadIdx.x < DIM) {
+        float v = queries.x[row * DIM + threadIdx.x];
+        if (queries.ln_w) v = (v - stat[0][0]) * stat[0][1] * queries.ln_w[threadIdx.x] + queries.ln_b[threadIdx.x];
+        x0[threadIdx.x] = v;
+    }
     __syncthreads();
     head_layer<DIM>(x0, hw.w[mi][0], hw.b[mi][0], DIM, true, x1);
     __syncthreads();
@@ -338,6 +368,225 @@ __global__ __launch_bounds__(256) void mask_logits_kernel(const float* __restric
     }
 #pragma unroll
     for (int m = 0; m < 4; ++m) logits[(((size_t)p * 4 + m) * 256 + Y) * 256 + X] = acc[m];
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Token-side linear layers, several per launch, with the LayerNorm in front of them applied on the fly.
+//
+// The token side is a chain of tiny dependent steps (7 tokens per prompt); each launch costs 5-9 us whatever it computes
+// (dispatch + a cold weight row per wave), so what matters is how few launches the chain takes.  Every LayerNorm of the
+// two-way blocks is therefore evaluated by its CONSUMERS: a linear layer (or a residual read) names the un-normalised
+// rows and the LayerNorm's parameters, every workgroup computes the rows' statistics itself (two-pass, fp32, as
+// layernorm_vec_kernel) and normalises while it reads.  Layers that consume the same step run in one launch (q / k / v).
+// (A lane-per-row form with the rows staged in LDS and wave-uniform weight loads was built as well: 18.8 us per launch
+// at one prompt against 9.4 us for this one, 27 against 35 us at five prompts -- scalar weight loads and LDS reads
+// share one counter and serialise.  Not kept.)
+constexpr int TL_MAX_ROWS = 112;              // 16 prompts x 7 tokens per launch
+constexpr int TL_MAX_OPS = 3;
+
+struct LinJob { k::TokenLinear op[TL_MAX_OPS]; int count; int rows; };
+
+// (mean, rstd) of every row of a TokenRows matrix with a LayerNorm: rows dealt to the four waves
+DLIMG_DEVICE void token_row_stats(const k::TokenRows& m, int rows, float2_t* stat /*LDS [rows]*/) {
+    const int lane = lane_id(), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int r = wave; r < rows; r += nw) {
+        const float4_t v = reinterpret_cast<const float4_t*>(m.x + (size_t)r * DIM)[lane];
+        const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / DIM);
+        const float4_t d = v - mean;
+        const float var = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / DIM);
+        if (lane == 0) stat[r] = float2_t{mean, 1.0f / sqrtf(var + m.eps)};
+    }
+}
+// 4 consecutive columns (4 * c4 ..) of row r
+DLIMG_DEVICE float4_t token_row_load4(const k::TokenRows& m, const float2_t* stat, int r, int c4) {
+    float4_t v = reinterpret_cast<const float4_t*>(m.x + (size_t)r * DIM)[c4];
+    if (m.ln_w) {
+        const float2_t st = stat[r];
+        v = (v - st[0]) * st[1] * reinterpret_cast<const float4_t*>(m.ln_w)[c4] + reinterpret_cast<const float4_t*>(m.ln_b)[c4];
+    }
+    if (m.add) v += reinterpret_cast<const float4_t*>(m.add + (size_t)r * DIM)[c4];
+    return v;
+}
+DLIMG_DEVICE float token_row_load1(const k::TokenRows& m, const float2_t* stat, int r, int c) {
+    float v = m.x[(size_t)r * DIM + c];
+    if (m.ln_w) v = (v - stat[r][0]) * stat[r][1] * m.ln_w[c] + m.ln_b[c];
+    if (m.add) v += m.add[(size_t)r * DIM + c];
+    return v;
+}
+
+// One output column per wave: Y[r][n] = act(in[r] . W[n] + b[n]) + resid[r][n] for all rows.
+// lds_in: rows of the input already in LDS ([rows][K] fp32; K <= 256) or null (then `op.in` is read from memory)
+// w_first: the wave's first 64 float4 of its weight row, requested by the caller before its own prologue (the row is
+// cold in the caches: its latency then runs behind the statistics / attention work instead of after it)
+DLIMG_DEVICE float4_t token_weight_prefetch(const k::TokenLinear& op, int first_col) {
+    const int lane = lane_id();
+    const int n = first_col + (threadIdx.x >> 6);
+    if (n >= op.N || lane >= (op.K >> 2)) return float4_t{0.f, 0.f, 0.f, 0.f};
+    return reinterpret_cast<const float4_t*>(op.W + (size_t)n * op.K)[lane];
+}
+DLIMG_DEVICE void token_linear_columns(const k::TokenLinear& op, int rows, int first_col, const float* lds_in,
+                                       const float2_t* stat_in, const float2_t* stat_res, float4_t w_first) {
+    const int lane = lane_id();
+    const int n = first_col + (threadIdx.x >> 6);
+    if (n >= op.N) return;
+    const int K4 = op.K >> 2;
+    const float4_t* wr = reinterpret_cast<const float4_t*>(op.W + (size_t)n * op.K);
+    for (int r0 = 0; r0 < rows; r0 += RCHUNK) {
+        float acc[RCHUNK];
+#pragma unroll
+        for (int r = 0; r < RCHUNK; ++r) acc[r] = 0.f;
+        for (int k4 = lane; k4 < K4; k4 += 64) {
+            const float4_t w = k4 == lane ? w_first : wr[k4];
+#pragma unroll
+            for (int r = 0; r < RCHUNK; ++r) {
+                if (r0 + r < rows) {
+                    float4_t x;
+                    if (lds_in) x = reinterpret_cast<const float4_t*>(lds_in + (size_t)(r0 + r) * op.K)[k4];
+                    else if (op.K == DIM) x = token_row_load4(op.in, stat_in, r0 + r, k4);
+                    else x = reinterpret_cast<const float4_t*>(op.in.x + (size_t)(r0 + r) * op.K)[k4];
+                    acc[r] = fmaf(x[0], w[0], fmaf(x[1], w[1], fmaf(x[2], w[2], fmaf(x[3], w[3], acc[r]))));
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RCHUNK; ++r) {
+            float v = wave_sum(acc[r]);
+            if (lane == 0 && r0 + r < rows) {
+                v += op.b ? op.b[n] : 0.f;
+                if (op.relu) v = fmaxf(v, 0.f);
+                if (op.resid.x) v += token_row_load1(op.resid, stat_res, r0 + r, n);
+                op.Y[(size_t)(r0 + r) * op.N + n] = v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void token_linears_kernel(LinJob job) {
+    __shared__ float2_t stat_in[TL_MAX_ROWS], stat_res[TL_MAX_ROWS];
+    int o = 0, first = blockIdx.x * 4;
+    while (o + 1 < job.count && first >= job.op[o].N) { first -= job.op[o].N; ++o; }      // N is a multiple of 4
+    const k::TokenLinear& op = job.op[o];
+    const float4_t w_first = token_weight_prefetch(op, first);
+    const bool ln_in = op.in.ln_w && op.K == DIM, ln_res = op.resid.x && op.resid.ln_w;
+    if (ln_in) token_row_stats(op.in, job.rows, stat_in);
+    if (ln_res) token_row_stats(op.resid, job.rows, stat_res);
+    if (ln_in || ln_res) __syncthreads();
+    token_linear_columns(op, job.rows, first, nullptr, stat_in, stat_res, w_first);
+}
+
+// Self-attention among the 7 tokens of every prompt (8 heads x 32), recomputed by every workgroup into LDS, followed by
+// the output projection (one column per wave) with bias and residual: one launch instead of two.
+__global__ __launch_bounds__(256) void token_self_attn_out_kernel(const float* __restrict__ q, const float* __restrict__ kx,
+                                                                  const float* __restrict__ v, k::TokenLinear op, int P) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* att = lds;                                   // [P * 7][256]
+    float* sq = att + (size_t)P * TOK * DIM;            // [7][256] x 3, one prompt at a time
+    float* sk = sq + TOK * DIM;
+    float* sv = sk + TOK * DIM;
+    float2_t* stat_res = reinterpret_cast<float2_t*>(sv + TOK * DIM);        // [P * 7]
+    const float4_t w_first = token_weight_prefetch(op, blockIdx.x * 4);
+    const int c = threadIdx.x;
+    const int h0 = (c >> 5) * 32;
+    const float scale = 0.17677669529663687f;           // 32^-0.5
+    for (int p = 0; p < P; ++p) {
+        __syncthreads();
+        for (int t = 0; t < TOK; ++t) {
+            sq[t * DIM + c] = q[((size_t)p * TOK + t) * DIM + c];
+            sk[t * DIM + c] = kx[((size_t)p * TOK + t) * DIM + c];
+            sv[t * DIM + c] = v[((size_t)p * TOK + t) * DIM + c];
+        }
+        __syncthreads();
+        for (int t = 0; t < TOK; ++t) {
+            float s[TOK];
+            float m = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < TOK; ++j) {
+                float d = 0.f;
+                for (int e = 0; e < 32; ++e) d = fmaf(sq[t * DIM + h0 + e], sk[j * DIM + h0 + e], d);
+                s[j] = d * scale;
+                m = fmaxf(m, s[j]);
+            }
+            float l = 0.f, o = 0.f;
+#pragma unroll
+            for (int j = 0; j < TOK; ++j) {
+                const float pj = expf(s[j] - m);
+                l += pj;
+                o = fmaf(pj, sv[j * DIM + c], o);
+            }
+            att[((size_t)p * TOK + t) * DIM + c] = o / l;
+        }
+    }
+    if (op.resid.x && op.resid.ln_w) token_row_stats(op.resid, P * TOK, stat_res);
+    __syncthreads();
+    token_linear_columns(op, P * TOK, blockIdx.x * 4, att, nullptr, stat_res, w_first);
+}
+
+// The per-key-group partials of the token-to-image attention folded (fixed order) by every workgroup into LDS, followed
+// by the output projection (K = 128) with bias and residual.
+__global__ __launch_bounds__(256) void token_merge_out_kernel(const float* __restrict__ part, k::TokenLinear op, int P) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* att = lds;                                   // [P * 7][128]
+    float2_t* stat_res = reinterpret_cast<float2_t*>(att + (size_t)P * TOK * INNER);
+    const float4_t w_first = token_weight_prefetch(op, blockIdx.x * 4);
+    const int total = P * TOK * INNER;
+    for (int idx = threadIdx.x; idx < total; idx += 256) {       // ((p * TOK + t) * HEADS + h) * 16 + e
+        const int e = idx & 15, h = (idx >> 4) % HEADS, t = (idx / (16 * HEADS)) % TOK, p = idx / (16 * HEADS * TOK);
+        const float* src = part + ((((size_t)p * HEADS + h) * TOK + t) * T2I_PARTS) * 18;
+        float M = src[0];
+#pragma unroll
+        for (int w = 1; w < T2I_PARTS; ++w) M = fmaxf(M, src[w * 18]);
+        float ls = 0.f, os = 0.f;
+#pragma unroll
+        for (int w = 0; w < T2I_PARTS; ++w) {
+            const float f = __expf(src[w * 18] - M);
+            ls += src[w * 18 + 1] * f;
+            os += src[w * 18 + 2 + e] * f;
+        }
+        att[idx] = os / ls;
+    }
+    if (op.resid.x && op.resid.ln_w) token_row_stats(op.resid, P * TOK, stat_res);
+    __syncthreads();
+    token_linear_columns(op, P * TOK, blockIdx.x * 4, att, nullptr, stat_res, w_first);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Image side, start of a decode: keys = embedding + no_mask_embed (has_mask_input == 0, segmentation.cpp:43-45) as fp32
+// and f16, and keys + dense positional encoding as f16 (the A operand of the k / q projections), for all prompts.
+__global__ __launch_bounds__(256) void decoder_keys_init_kernel(const float* const* __restrict__ emb,
+                                                                const float* __restrict__ no_mask,
+                                                                const float* __restrict__ pos, float* __restrict__ keys,
+                                                                half_t* __restrict__ keys_h, half_t* __restrict__ kp_h,
+                                                                size_t n4_per_prompt, int P) {
+    const size_t total = n4_per_prompt * P;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / n4_per_prompt, j = i % n4_per_prompt;
+        float4_t v = reinterpret_cast<const float4_t*>(emb[p])[j];
+        v += reinterpret_cast<const float4_t*>(no_mask)[j % (DIM / 4)];
+        const float4_t kp = v + reinterpret_cast<const float4_t*>(pos)[j];
+        reinterpret_cast<float4_t*>(keys)[i] = v;
+        reinterpret_cast<half4_t*>(keys_h)[i] = half4_t{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        reinterpret_cast<half4_t*>(kp_h)[i] = half4_t{(half_t)kp[0], (half_t)kp[1], (half_t)kp[2], (half_t)kp[3]};
+    }
+}
+
+// LayerNorm of the keys (norm4 of a two-way block) in place, with both f16 forms the next step consumes.
+__global__ __launch_bounds__(256) void decoder_keys_norm_kernel(float* __restrict__ keys, const float* __restrict__ w,
+                                                                const float* __restrict__ b, float eps,
+                                                                const float* __restrict__ pos, half_t* __restrict__ keys_h,
+                                                                half_t* __restrict__ kp_h, int rows) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = lane_id();
+    float4_t v = reinterpret_cast<const float4_t*>(keys + (size_t)row * DIM)[lane];
+    const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) / (float)DIM;
+    v -= mean;
+    const float rstd = 1.0f / sqrtf(wave_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) / (float)DIM + eps);
+    const float4_t y = v * rstd * reinterpret_cast<const float4_t*>(w)[lane] + reinterpret_cast<const float4_t*>(b)[lane];
+    const float4_t kp = y + reinterpret_cast<const float4_t*>(pos + (size_t)(row % NTOK_IMG) * DIM)[lane];
+    reinterpret_cast<float4_t*>(keys + (size_t)row * DIM)[lane] = y;
+    reinterpret_cast<half4_t*>(keys_h + (size_t)row * DIM)[lane] = half4_t{(half_t)y[0], (half_t)y[1], (half_t)y[2], (half_t)y[3]};
+    reinterpret_cast<half4_t*>(kp_h + (size_t)row * DIM)[lane] = half4_t{(half_t)kp[0], (half_t)kp[1], (half_t)kp[2], (half_t)kp[3]};
 }
 
 }  // namespace
@@ -385,7 +634,72 @@ void image_to_token_attention(const half_t* q, int ldq, const float* kt, const f
     hipLaunchKernelGGL(image_to_token_kernel, dim3(P * NTOK_IMG * HEADS / 256), dim3(256), 0, s, q, ldq, kt, vt, out);
 }
 
-void output_heads(const float* queries, const HeadWeights& hw, float* hyper, float* iou, int P, hipStream_t s) {
+void token_linears(const TokenLinear* ops, int count, int rows, hipStream_t s) {
+    if (count <= 0 || rows <= 0) return;
+    if (count > TL_MAX_OPS || rows > TL_MAX_ROWS) throw_error("token_linears: too many layers or rows for one launch");
+    LinJob job;
+    job.count = count;
+    job.rows = rows;
+    int blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        if (ops[i].K <= 0 || ops[i].K % 4 || ops[i].N <= 0 || ops[i].N % 4)
+            throw_error("token_linears: K and N must be positive multiples of 4");
+        if ((ops[i].in.ln_w || ops[i].in.add) && ops[i].K != DIM)
+            throw_error("token_linears: on-the-fly LayerNorm / addition needs 256-wide input rows");
+        job.op[i] = ops[i];
+        blocks += ops[i].N / 4;
+    }
+    hipLaunchKernelGGL(token_linears_kernel, dim3(blocks), dim3(256), 0, s, job);
+}
+
+void token_self_attention_out(const float* q, const float* kx, const float* v, const TokenLinear& out, int P, hipStream_t s) {
+    if (P <= 0) return;
+    if (P * TOK > TL_MAX_ROWS || out.K != DIM || out.N % 4) throw_error("token_self_attention_out: unsupported shape");
+    const size_t lds = ((size_t)P * TOK * DIM + 3 * TOK * DIM) * 4 + (size_t)P * TOK * 8;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute((const void*)token_self_attn_out_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    hipLaunchKernelGGL(token_self_attn_out_kernel, dim3(out.N / 4), dim3(256), lds, s, q, kx, v, out, P);
+}
+
+void token_merge_out(const float* scratch, const TokenLinear& out, int P, hipStream_t s) {
+    if (P <= 0) return;
+    if (P * TOK > TL_MAX_ROWS || out.K != INNER || out.N % 4) throw_error("token_merge_out: unsupported shape");
+    const size_t lds = (size_t)P * TOK * INNER * 4 + (size_t)P * TOK * 8;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute((const void*)token_merge_out_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    hipLaunchKernelGGL(token_merge_out_kernel, dim3(out.N / 4), dim3(256), lds, s, scratch, out, P);
+}
+
+void token_to_image_partials(const float* q, const half_t* K, int ldk, const half_t* V, int ldv, float* scratch, int P,
+                             hipStream_t s) {
+    if (P <= 0) return;
+    if (ldk % 8 || ldv % 8 || (((uintptr_t)K | (uintptr_t)V) & 15))
+        throw_error("token_to_image_attention: K/V rows must be 16-byte aligned");
+    hipLaunchKernelGGL(token_to_image_partial_kernel, dim3(P * HEADS * T2I_GROUPS), dim3(T2I_THREADS), 0, s, q, K, ldk, V,
+                       ldv, scratch);
+}
+
+void decoder_keys_init(const float* const* emb_dev, const float* no_mask, const float* pos, float* keys, half_t* keys_h,
+                       half_t* kp_h, int P, hipStream_t s) {
+    if (P <= 0) return;
+    const size_t n4 = (size_t)NTOK_IMG * DIM / 4;
+    const size_t total = n4 * P;
+    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(decoder_keys_init_kernel, dim3(grid), dim3(256), 0, s, emb_dev, no_mask, pos, keys, keys_h, kp_h, n4, P);
+}
+
+void decoder_keys_norm(float* keys, const float* w, const float* b, float eps, const float* pos, half_t* keys_h,
+                       half_t* kp_h, int P, hipStream_t s) {
+    if (P <= 0) return;
+    const int rows = P * NTOK_IMG;
+    hipLaunchKernelGGL(decoder_keys_norm_kernel, dim3(rows / 4), dim3(256), 0, s, keys, w, b, eps, pos, keys_h, kp_h, rows);
+}
+
+void output_heads(const TokenRows& queries, const HeadWeights& hw, float* hyper, float* iou, int P, hipStream_t s) {
     if (P <= 0) return;
     hipLaunchKernelGGL(output_heads_kernel, dim3(P, 5), dim3(HEAD_THREADS), 0, s, queries, hw, hyper, iou);
 }

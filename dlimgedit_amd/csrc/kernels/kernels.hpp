@@ -108,9 +108,44 @@ size_t token_to_image_scratch_floats(int P);
 // image attends to tokens: q [P,4096,ldq] f16, k,v [P,7,128] f32 -> out [P,4096,128] f16
 void image_to_token_attention(const half_t* q, int ldq, const float* k, const float* v, half_t* out, int P,
                               hipStream_t);
+// A [rows][256] fp32 token matrix as a consumer sees it: optionally LayerNorm'ed (over the 256 columns) and with another
+// matrix added behind the LayerNorm (the query positional encoding), both applied while the rows are read.
+struct TokenRows {
+    const float* x = nullptr;
+    const float* ln_w = nullptr;
+    const float* ln_b = nullptr;
+    float eps = 0.f;
+    const float* add = nullptr;
+};
+// Y[r][n] = act(in[r] . W[n] + b[n]) + resid[r][n]; W is [N][K] fp32.  K = 256: `in` with TokenRows semantics; any other
+// K: in.x is a plain [rows][K] matrix.  resid.x == nullptr: no residual.
+struct TokenLinear {
+    TokenRows in;
+    int K = 0;
+    const float* W = nullptr;
+    const float* b = nullptr;
+    TokenRows resid;
+    float* Y = nullptr;
+    int N = 0;
+    int relu = 0;
+};
+// up to 3 layers over the same rows (<= 112) in one launch
+void token_linears(const TokenLinear* ops, int count, int rows, hipStream_t);
+// self-attention among the 7 tokens of each prompt + its output projection `out` (K = 256) in one launch
+void token_self_attention_out(const float* q, const float* k, const float* v, const TokenLinear& out, int P, hipStream_t);
+// token-to-image attention in two launches: per-key-group partials, then their fold + the output projection (K = 128)
+void token_to_image_partials(const float* q, const half_t* K, int ldk, const half_t* V, int ldv, float* scratch, int P,
+                             hipStream_t);
+void token_merge_out(const float* scratch, const TokenLinear& out, int P, hipStream_t);
+// image side: keys = emb[p] + no_mask (fp32 + f16) and f16(keys + pos) for all prompts; emb_dev: DEVICE array of P pointers
+void decoder_keys_init(const float* const* emb_dev, const float* no_mask, const float* pos, float* keys, half_t* keys_h,
+                       half_t* kp_h, int P, hipStream_t);
+// keys = LayerNorm(keys) in place + f16(keys) + f16(keys + pos)
+void decoder_keys_norm(float* keys, const float* w, const float* b, float eps, const float* pos, half_t* keys_h,
+                       half_t* kp_h, int P, hipStream_t);
 // hyper-network MLPs (4 x 256->256->256->32) and IoU head (256->256->256->4) on the output tokens
 struct HeadWeights { const float* w[5][3]; const float* b[5][3]; };
-void output_heads(const float* queries /*[P,7,256]*/, const HeadWeights& hw, float* hyper /*[P,4,32]*/,
+void output_heads(const TokenRows& queries /*[P,7,256]*/, const HeadWeights& hw, float* hyper /*[P,4,32]*/,
                   float* iou /*[P,4]*/, int P, hipStream_t);
 // low-res logits [P,4,256,256] from the upscaled embedding in quad order and the hyper vectors.
 // up: [P*65536, 32] f32, row = ((y*64+x)*4 + dy1*2+dx1)*4 + dy2*2+dx2  (pixel Y = 4y+2dy1+dy2, X likewise)

@@ -639,7 +639,7 @@ void SamModel::reserve_decoder(int count) {
     logits_.reserve(P * 4 * kLowRes * kLowRes);
     iou_.reserve(P * 4);
     hyper_.reserve(P * 4 * 32);
-    coords_.reserve(P * 6);              // coordinates [P][4] followed by labels [P][2]
+    coords_.reserve(P * 8);              // coordinates [P][4], labels [P][2], embedding pointers [P] (8 bytes each)
     const size_t T = P * kDecTokens;
     tokens_.reserve(T * 256);
     queries_.reserve(T * 256);
@@ -647,44 +647,63 @@ void SamModel::reserve_decoder(int count) {
     tk_.reserve(T * 256);
     tv_.reserve(T * 256);
     tatt_.reserve(T * 256);
+    tsa_.reserve(T * 256);
+    tt2i_.reserve(T * 256);
     t2i_part_.reserve(k::token_to_image_scratch_floats((int)P));
     tmlp_.reserve(T * 2048);
-    prompt_pinned_.reserve(kPromptRing * P * 6 * sizeof(float));
+    prompt_pinned_.reserve(kPromptRing * P * 8 * sizeof(float));
     dec_count_ = count;
 }
 
 void SamModel::decode(float const* const* emb, float const* coords, float const* labels, int count) {
-    SamWeights const& W = *weights_;
     DLIMG_ASSERT(count > 0);
     reserve_decoder(count);
+    // the token-side kernels take at most 16 prompts (112 rows) per launch: larger requests run in chunks that share
+    // the workspaces (stream order) and write their own part of logits() / iou()
+    constexpr int kChunk = 16;
+    for (int c0 = 0; c0 < count; c0 += kChunk)
+        decode_chunk(emb + c0, coords + (size_t)c0 * 4, labels + (size_t)c0 * 2, std::min(kChunk, count - c0), c0);
+}
+
+void SamModel::decode_chunk(float const* const* emb, float const* coords, float const* labels, int count, int first) {
+    SamWeights const& W = *weights_;
     const int P = count, M = P * kTokens, T = P * kDecTokens;
     hipStream_t s = stream_;
+    float* logits_out = logits_.get() + (size_t)first * 4 * kLowRes * kLowRes;
+    float* iou_out = iou_.get() + (size_t)first * 4;
 
     auto body = [&] {
-        // prompt -> device (through pinned memory so the copy is stream-ordered)
+        // prompt -> device (through pinned memory so the copy is stream-ordered): coords [P][4], labels [P][2] and the
+        // P embedding pointers in one copy
         const unsigned ring = prompt_seq_++ % kPromptRing;
         HIP_CHECK(hipEventSynchronize(prompt_done_[ring]));     // the copy issued kPromptRing decodes ago has run
-        float* pin = static_cast<float*>(prompt_pinned_.get()) + (size_t)ring * dec_count_ * 6;
+        float* pin = static_cast<float*>(prompt_pinned_.get()) + (size_t)ring * dec_count_ * 8;
         std::memcpy(pin, coords, (size_t)P * 4 * sizeof(float));
         std::memcpy(pin + (size_t)P * 4, labels, (size_t)P * 2 * sizeof(float));
-        // one copy for coords [P][4] and labels [P][2] (coords_ holds both, labels behind the coordinates)
-        HIP_CHECK(hipMemcpyAsync(coords_.get(), pin, (size_t)P * 6 * sizeof(float), hipMemcpyHostToDevice, s));
+        std::memcpy(pin + (size_t)P * 6, emb, (size_t)P * sizeof(float const*));
+        HIP_CHECK(hipMemcpyAsync(coords_.get(), pin, (size_t)P * 8 * sizeof(float), hipMemcpyHostToDevice, s));
         HIP_CHECK(hipEventRecord(prompt_done_[ring], s));
+        float const* const* emb_dev = reinterpret_cast<float const* const*>(coords_.get() + (size_t)P * 6);
         k::prompt_tokens(coords_.get(), coords_.get() + (size_t)P * 4, W.pe_gauss_.get(), W.pe_point_.get(),
                          W.pe_not_a_point_.get(), W.iou_token_.get(), W.mask_tokens_.get(), tokens_.get(), queries_.get(),
                          P, s);
-        // src = image_embedding + no_mask_embed (has_mask_input == 0, segmentation.cpp:43-45)
-        for (int p = 0; p < P; ++p)
-            k::add_cast(emb[p], W.pe_no_mask_.get(), 256, (size_t)kTokens * 256, keys_.get() + (size_t)p * kTokens * 256,
-                        keys_h_.get() + (size_t)p * kTokens * 256, s);
+        // keys = image_embedding + no_mask_embed (has_mask_input == 0, segmentation.cpp:43-45), + positional encoding
+        k::decoder_keys_init(emb_dev, W.pe_no_mask_.get(), W.image_pe_.get(), keys_.get(), keys_h_.get(), kp_h_.get(), P, s);
 
-        float* q = queries_.get();
+        // Token side.  `cur` is the running token matrix as its consumers read it: un-normalised rows plus the
+        // LayerNorm that belongs in front of them (applied on the fly by whoever reads, kernels/decoder.hip).
         float const* qpe = tokens_.get();
-        auto lin = [&](float const* X, float const* X2, LinearF const& l, float const* R, float* Y, int relu) {
-            k::token_linear(X, X2, l.w.get(), l.b.get(), R, Y, T, l.in, l.out, relu, s);
+        k::TokenRows cur;
+        cur.x = queries_.get();
+        auto rows_of = [&](k::TokenRows r, bool with_pe) { if (with_pe) r.add = qpe; return r; };
+        auto lin = [&](k::TokenRows in, int K, LinearF const& l, k::TokenRows resid, float* Y, int relu) {
+            k::TokenLinear op;
+            op.in = in; op.K = K; op.W = l.w.get(); op.b = l.b.get(); op.resid = resid; op.Y = Y; op.N = l.out; op.relu = relu;
+            return op;
         };
-        auto ln_tokens = [&](NormW const& n, float eps) {
-            k::layernorm(q, n.w.get(), n.b.get(), eps, T, 256, k::ACT_NONE, q, nullptr, s);
+        auto plain = [&](float const* x) { k::TokenRows r; r.x = x; return r; };
+        auto normed = [&](float const* x, NormW const& n) {
+            k::TokenRows r; r.x = x; r.ln_w = n.w.get(); r.ln_b = n.b.get(); r.eps = kDecLnEps; return r;
         };
         auto img_gemm = [&](half_t const* A, int K, LinearH const& l, half_t* out_h, int ldc) {
             k::GemmArgs g;
@@ -694,36 +713,35 @@ void SamModel::decode(float const* const* emb, float const* coords, float const*
             g.unit_rows = kTokens;
             k::gemm(g, s);
         };
-        // tokens attend to the image: K = kq_h[:, :128] (or final K), V = v_h
-        auto token_to_image = [&](LinearF const& wq, LinearF const& wo, half_t const* K, int ldk) {
-            lin(q, qpe, wq, nullptr, tq_.get(), 0);
-            k::token_to_image_attention(tq_.get(), K, ldk, v_h_.get(), 128, t2i_part_.get(), tatt_.get(), P, s);
-            lin(tatt_.get(), nullptr, wo, q, q, 0);
-        };
 
         for (int i = 0; i < 2; ++i) {
             DecoderLayer const& L = W.dec_[i];
             // (1) self attention of the tokens; the first layer has no PE and no residual
-            float const* pe = i == 0 ? nullptr : qpe;
-            lin(q, pe, L.self_attn.q, nullptr, tq_.get(), 0);
-            lin(q, pe, L.self_attn.k, nullptr, tk_.get(), 0);
-            lin(q, nullptr, L.self_attn.v, nullptr, tv_.get(), 0);
-            k::token_self_attention(tq_.get(), tk_.get(), tv_.get(), tatt_.get(), P, s);
-            lin(tatt_.get(), nullptr, L.self_attn.o, i == 0 ? nullptr : q, q, 0);
-            ln_tokens(L.ln1, kDecLnEps);
-            // (2) tokens -> image
-            k::add_cast(keys_.get(), W.image_pe_.get(), (size_t)kTokens * 256, (size_t)M * 256, nullptr, kp_h_.get(), s);
+            k::TokenLinear qkv[3] = {lin(rows_of(cur, i != 0), 256, L.self_attn.q, {}, tq_.get(), 0),
+                                     lin(rows_of(cur, i != 0), 256, L.self_attn.k, {}, tk_.get(), 0),
+                                     lin(cur, 256, L.self_attn.v, {}, tv_.get(), 0)};
+            k::token_linears(qkv, 3, T, s);
+            k::token_self_attention_out(tq_.get(), tk_.get(), tv_.get(),
+                                        lin({}, 256, L.self_attn.o, i == 0 ? k::TokenRows{} : cur, tsa_.get(), 0), P, s);
+            const k::TokenRows q1 = normed(tsa_.get(), L.ln1);
+            // (2) tokens -> image: K = (keys + pos) Wk, V = keys Wv (image side, MFMA GEMMs)
             img_gemm(kp_h_.get(), 256, L.img_kq, kq_h_.get(), 256);
             img_gemm(keys_h_.get(), 256, L.img_v, v_h_.get(), 128);
-            token_to_image(L.t2i_q, L.t2i_o, kq_h_.get(), 256);
-            ln_tokens(L.ln2, kDecLnEps);
+            k::TokenLinear tq = lin(rows_of(q1, true), 256, L.t2i_q, {}, tq_.get(), 0);
+            k::token_linears(&tq, 1, T, s);
+            k::token_to_image_partials(tq_.get(), kq_h_.get(), 256, v_h_.get(), 128, t2i_part_.get(), P, s);
+            k::token_merge_out(t2i_part_.get(), lin({}, 128, L.t2i_o, q1, tt2i_.get(), 0), P, s);
+            const k::TokenRows q2 = normed(tt2i_.get(), L.ln2);
             // (3) token MLP
-            lin(q, nullptr, L.mlp1, nullptr, tmlp_.get(), 1);
-            lin(tmlp_.get(), nullptr, L.mlp2, q, q, 0);
-            ln_tokens(L.ln3, kDecLnEps);
+            k::TokenLinear m1 = lin(q2, 256, L.mlp1, {}, tmlp_.get(), 1);
+            k::token_linears(&m1, 1, T, s);
+            k::TokenLinear m2 = lin(plain(tmlp_.get()), 2048, L.mlp2, q2, queries_.get(), 0);
+            k::token_linears(&m2, 1, T, s);
+            const k::TokenRows q3 = normed(queries_.get(), L.ln3);
             // (4) image -> tokens
-            lin(q, qpe, L.i2t_k, nullptr, tk_.get(), 0);
-            lin(q, nullptr, L.i2t_v, nullptr, tv_.get(), 0);
+            k::TokenLinear kv[2] = {lin(rows_of(q3, true), 256, L.i2t_k, {}, tk_.get(), 0),
+                                    lin(q3, 256, L.i2t_v, {}, tv_.get(), 0)};
+            k::token_linears(kv, 2, T, s);
             k::image_to_token_attention(kq_h_.get() + 128, 256, tk_.get(), tv_.get(), att_img_h_.get(), P, s);
             k::GemmArgs g;
             g.A = att_img_h_.get(); g.lda = 128; g.W = L.i2t_o.w.get(); g.ldw = 128; g.bias = L.i2t_o.b.get();
@@ -732,15 +750,18 @@ void SamModel::decode(float const* const* emb, float const* coords, float const*
             g.shared_gpu = shared_gpu_;
             g.unit_rows = kTokens;
             k::gemm(g, s);
-            k::layernorm(keys_.get(), L.ln4.w.get(), L.ln4.b.get(), kDecLnEps, M, 256, k::ACT_NONE, keys_.get(),
-                         keys_h_.get(), s);
+            k::decoder_keys_norm(keys_.get(), L.ln4.w.get(), L.ln4.b.get(), kDecLnEps, W.image_pe_.get(), keys_h_.get(),
+                                 kp_h_.get(), P, s);
+            cur = q3;
         }
         // final token -> image attention
-        k::add_cast(keys_.get(), W.image_pe_.get(), (size_t)kTokens * 256, (size_t)M * 256, nullptr, kp_h_.get(), s);
         img_gemm(kp_h_.get(), 256, W.final_k_, kq_h_.get(), 128);
         img_gemm(keys_h_.get(), 256, W.final_v_, v_h_.get(), 128);
-        token_to_image(W.final_q_, W.final_o_, kq_h_.get(), 128);
-        ln_tokens(W.ln_final_, kDecLnEps);
+        k::TokenLinear fq = lin(rows_of(cur, true), 256, W.final_q_, {}, tq_.get(), 0);
+        k::token_linears(&fq, 1, T, s);
+        k::token_to_image_partials(tq_.get(), kq_h_.get(), 128, v_h_.get(), 128, t2i_part_.get(), P, s);
+        k::token_merge_out(t2i_part_.get(), lin({}, 128, W.final_o_, cur, tsa_.get(), 0), P, s);
+        const k::TokenRows qf = normed(tsa_.get(), W.ln_final_);
 
         // upscaling: ConvT(256->64) -> LN2d -> GELU -> ConvT(64->32) -> GELU, sub-pixels kept in quad order
         k::GemmArgs g;
@@ -764,8 +785,8 @@ void SamModel::decode(float const* const* emb, float const* coords, float const*
                 hw.w[m][j] = W.heads_[m][j].w.get();
                 hw.b[m][j] = W.heads_[m][j].b.get();
             }
-        k::output_heads(q, hw, hyper_.get(), iou_.get(), P, s);
-        k::mask_logits(up_.get(), hyper_.get(), logits_.get(), P, s);
+        k::output_heads(qf, hw, hyper_.get(), iou_out, P, s);
+        k::mask_logits(up_.get(), hyper_.get(), logits_out, P, s);
     };
     timed(ST_DECODER, 3.62e9 * P, body);
 }

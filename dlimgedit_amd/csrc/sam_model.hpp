@@ -175,6 +175,7 @@ class SamModel {
   private:
     void reserve_encoder(int batch);
     void reserve_decoder(int count);
+    void decode_chunk(float const* const* emb, float const* coords, float const* labels, int count, int first);
     void gemm(k::GemmArgs const& a);
     template <typename F> void timed(Stage st, double work, F&& launch);
     void flush_events();
@@ -217,7 +218,7 @@ class SamModel {
     int dec_count_ = 0;
     DeviceBuffer<float> keys_, up1_f32_, up_, logits_, iou_, hyper_;
     DeviceBuffer<half_t> keys_h_, kp_h_, kq_h_, v_h_, att_img_h_, up1_h_;
-    DeviceBuffer<float> coords_, tokens_, queries_, tq_, tk_, tv_, tatt_, tmlp_, t2i_part_;
+    DeviceBuffer<float> coords_, tokens_, queries_, tq_, tk_, tv_, tatt_, tsa_, tt2i_, tmlp_, t2i_part_;
     std::vector<std::unique_ptr<MaskSlot>> mask_slots_;     // all ever made (owned), guarded by done_mutex_
     std::vector<MaskSlot*> mask_free_;                      // those not handed out, guarded by done_mutex_
     PinnedBuffer prompt_pinned_;
