@@ -384,13 +384,15 @@ __global__ __launch_bounds__(256) void mask_logits_kernel(const float* __restric
 // share one counter and serialise.  Not kept.)
 constexpr int TL_MAX_ROWS = 112;              // 16 prompts x 7 tokens per launch
 constexpr int TL_MAX_OPS = 3;
+constexpr int TL_PROMPT_SLICE = 2;           // prompts per workgroup of the fused attention-output kernels
+constexpr int TL_ROW_SLICE = 14;            // rows per workgroup of token_linears_kernel (two prompts)
 
 struct LinJob { k::TokenLinear op[TL_MAX_OPS]; int count; int rows; };
 
 // (mean, rstd) of every row of a TokenRows matrix with a LayerNorm: rows dealt to the four waves
-DLIMG_DEVICE void token_row_stats(const k::TokenRows& m, int rows, float2_t* stat /*LDS [rows]*/) {
+DLIMG_DEVICE void token_row_stats(const k::TokenRows& m, int rows, float2_t* stat /*LDS [rows]*/, int row0 = 0) {
     const int lane = lane_id(), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int r = wave; r < rows; r += nw) {
+    for (int r = row0 + wave; r < rows; r += nw) {
         const float4_t v = reinterpret_cast<const float4_t*>(m.x + (size_t)r * DIM)[lane];
         const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / DIM);
         const float4_t d = v - mean;
@@ -426,13 +428,13 @@ DLIMG_DEVICE float4_t token_weight_prefetch(const k::TokenLinear& op, int first_
     return reinterpret_cast<const float4_t*>(op.W + (size_t)n * op.K)[lane];
 }
 DLIMG_DEVICE void token_linear_columns(const k::TokenLinear& op, int rows, int first_col, const float* lds_in,
-                                       const float2_t* stat_in, const float2_t* stat_res, float4_t w_first) {
+                                       const float2_t* stat_in, const float2_t* stat_res, float4_t w_first, int row0 = 0) {
     const int lane = lane_id();
     const int n = first_col + (threadIdx.x >> 6);
     if (n >= op.N) return;
     const int K4 = op.K >> 2;
     const float4_t* wr = reinterpret_cast<const float4_t*>(op.W + (size_t)n * op.K);
-    for (int r0 = 0; r0 < rows; r0 += RCHUNK) {
+    for (int r0 = row0; r0 < rows; r0 += RCHUNK) {
         float acc[RCHUNK];
 #pragma unroll
         for (int r = 0; r < RCHUNK; ++r) acc[r] = 0.f;
@@ -442,7 +444,7 @@ DLIMG_DEVICE void token_linear_columns(const k::TokenLinear& op, int rows, int f
             for (int r = 0; r < RCHUNK; ++r) {
                 if (r0 + r < rows) {
                     float4_t x;
-                    if (lds_in) x = reinterpret_cast<const float4_t*>(lds_in + (size_t)(r0 + r) * op.K)[k4];
+                    if (lds_in) x = reinterpret_cast<const float4_t*>(lds_in + (size_t)(r0 + r - row0) * op.K)[k4];
                     else if (op.K == DIM) x = token_row_load4(op.in, stat_in, r0 + r, k4);
                     else x = reinterpret_cast<const float4_t*>(op.in.x + (size_t)(r0 + r) * op.K)[k4];
                     acc[r] = fmaf(x[0], w[0], fmaf(x[1], w[1], fmaf(x[2], w[2], fmaf(x[3], w[3], acc[r]))));
@@ -468,11 +470,13 @@ __global__ __launch_bounds__(256) void token_linears_kernel(LinJob job) {
     while (o + 1 < job.count && first >= job.op[o].N) { first -= job.op[o].N; ++o; }      // N is a multiple of 4
     const k::TokenLinear& op = job.op[o];
     const float4_t w_first = token_weight_prefetch(op, first);
+    // rows are dealt to blockIdx.y in slices of TL_ROW_SLICE: more prompts are more workgroups, not longer ones
+    const int row0 = blockIdx.y * TL_ROW_SLICE, row1 = min(job.rows, row0 + TL_ROW_SLICE);
     const bool ln_in = op.in.ln_w && op.K == DIM, ln_res = op.resid.x && op.resid.ln_w;
-    if (ln_in) token_row_stats(op.in, job.rows, stat_in);
-    if (ln_res) token_row_stats(op.resid, job.rows, stat_res);
+    if (ln_in) token_row_stats(op.in, row1, stat_in, row0);
+    if (ln_res) token_row_stats(op.resid, row1, stat_res, row0);
     if (ln_in || ln_res) __syncthreads();
-    token_linear_columns(op, job.rows, first, nullptr, stat_in, stat_res, w_first);
+    token_linear_columns(op, row1, first, nullptr, stat_in, stat_res, w_first, row0);
 }
 
 // Self-attention among the 7 tokens of every prompt (8 heads x 32), recomputed by every workgroup into LDS, followed by
@@ -489,7 +493,10 @@ __global__ __launch_bounds__(256) void token_self_attn_out_kernel(const float* _
     const int c = threadIdx.x;
     const int h0 = (c >> 5) * 32;
     const float scale = 0.17677669529663687f;           // 32^-0.5
-    for (int p = 0; p < P; ++p) {
+    // prompts are dealt to blockIdx.y in pairs (rows row0 .. row1 of the token matrix; LDS rows are local)
+    const int p0 = blockIdx.y * TL_PROMPT_SLICE, p1 = min(P, p0 + TL_PROMPT_SLICE);
+    const int row0 = p0 * TOK, row1 = p1 * TOK;
+    for (int p = p0; p < p1; ++p) {
         __syncthreads();
         for (int t = 0; t < TOK; ++t) {
             sq[t * DIM + c] = q[((size_t)p * TOK + t) * DIM + c];
@@ -514,12 +521,12 @@ __global__ __launch_bounds__(256) void token_self_attn_out_kernel(const float* _
                 l += pj;
                 o = fmaf(pj, sv[j * DIM + c], o);
             }
-            att[((size_t)p * TOK + t) * DIM + c] = o / l;
+            att[((size_t)(p - p0) * TOK + t) * DIM + c] = o / l;
         }
     }
-    if (op.resid.x && op.resid.ln_w) token_row_stats(op.resid, P * TOK, stat_res);
+    if (op.resid.x && op.resid.ln_w) token_row_stats(op.resid, row1, stat_res, row0);
     __syncthreads();
-    token_linear_columns(op, P * TOK, blockIdx.x * 4, att, nullptr, stat_res, w_first);
+    token_linear_columns(op, row1, blockIdx.x * 4, att, nullptr, stat_res, w_first, row0);
 }
 
 // The per-key-group partials of the token-to-image attention folded (fixed order) by every workgroup into LDS, followed
@@ -529,9 +536,11 @@ __global__ __launch_bounds__(256) void token_merge_out_kernel(const float* __res
     float* att = lds;                                   // [P * 7][128]
     float2_t* stat_res = reinterpret_cast<float2_t*>(att + (size_t)P * TOK * INNER);
     const float4_t w_first = token_weight_prefetch(op, blockIdx.x * 4);
-    const int total = P * TOK * INNER;
-    for (int idx = threadIdx.x; idx < total; idx += 256) {       // ((p * TOK + t) * HEADS + h) * 16 + e
-        const int e = idx & 15, h = (idx >> 4) % HEADS, t = (idx / (16 * HEADS)) % TOK, p = idx / (16 * HEADS * TOK);
+    const int p0 = blockIdx.y * TL_PROMPT_SLICE, p1 = min(P, p0 + TL_PROMPT_SLICE);
+    const int row0 = p0 * TOK, row1 = p1 * TOK;
+    const int total = (p1 - p0) * TOK * INNER;
+    for (int idx = threadIdx.x; idx < total; idx += 256) {       // ((p * TOK + t) * HEADS + h) * 16 + e, p local
+        const int e = idx & 15, h = (idx >> 4) % HEADS, t = (idx / (16 * HEADS)) % TOK, p = p0 + idx / (16 * HEADS * TOK);
         const float* src = part + ((((size_t)p * HEADS + h) * TOK + t) * T2I_PARTS) * 18;
         float M = src[0];
 #pragma unroll
@@ -545,9 +554,9 @@ __global__ __launch_bounds__(256) void token_merge_out_kernel(const float* __res
         }
         att[idx] = os / ls;
     }
-    if (op.resid.x && op.resid.ln_w) token_row_stats(op.resid, P * TOK, stat_res);
+    if (op.resid.x && op.resid.ln_w) token_row_stats(op.resid, row1, stat_res, row0);
     __syncthreads();
-    token_linear_columns(op, P * TOK, blockIdx.x * 4, att, nullptr, stat_res, w_first);
+    token_linear_columns(op, row1, blockIdx.x * 4, att, nullptr, stat_res, w_first, row0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -649,7 +658,7 @@ void token_linears(const TokenLinear* ops, int count, int rows, hipStream_t s) {
         job.op[i] = ops[i];
         blocks += ops[i].N / 4;
     }
-    hipLaunchKernelGGL(token_linears_kernel, dim3(blocks), dim3(256), 0, s, job);
+    hipLaunchKernelGGL(token_linears_kernel, dim3(blocks, (rows + TL_ROW_SLICE - 1) / TL_ROW_SLICE), dim3(256), 0, s, job);
 }
 
 void token_self_attention_out(const float* q, const float* kx, const float* v, const TokenLinear& out, int P, hipStream_t s) {
@@ -660,7 +669,8 @@ void token_self_attention_out(const float* q, const float* kx, const float* v, c
     std::call_once(once, [] {
         (void)hipFuncSetAttribute((const void*)token_self_attn_out_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
-    hipLaunchKernelGGL(token_self_attn_out_kernel, dim3(out.N / 4), dim3(256), lds, s, q, kx, v, out, P);
+    hipLaunchKernelGGL(token_self_attn_out_kernel, dim3(out.N / 4, (P + TL_PROMPT_SLICE - 1) / TL_PROMPT_SLICE), dim3(256), lds, s, q, kx,
+                       v, out, P);
 }
 
 void token_merge_out(const float* scratch, const TokenLinear& out, int P, hipStream_t s) {
@@ -671,7 +681,8 @@ void token_merge_out(const float* scratch, const TokenLinear& out, int P, hipStr
     std::call_once(once, [] {
         (void)hipFuncSetAttribute((const void*)token_merge_out_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
-    hipLaunchKernelGGL(token_merge_out_kernel, dim3(out.N / 4), dim3(256), lds, s, scratch, out, P);
+    hipLaunchKernelGGL(token_merge_out_kernel, dim3(out.N / 4, (P + TL_PROMPT_SLICE - 1) / TL_PROMPT_SLICE), dim3(256), lds, s, scratch, out,
+                       P);
 }
 
 void token_to_image_partials(const float* q, const half_t* K, int ldk, const half_t* V, int ldv, float* scratch, int P,
