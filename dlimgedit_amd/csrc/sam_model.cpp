@@ -618,6 +618,7 @@ void SamModel::encode(int batch, float* const* emb_dst) {
             if (emb_dst[i])
                 HIP_CHECK(hipMemcpyAsync(emb_dst[i], emb_.get() + i * n, n * sizeof(float), hipMemcpyDeviceToDevice, stream_));
     }
+    HIP_CHECK(hipGetLastError());     // a refused launch (bad grid, LDS size) is reported here, not at a later sync
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -789,6 +790,7 @@ void SamModel::decode_chunk(float const* const* emb, float const* coords, float 
         k::mask_logits(up_.get(), hyper_.get(), logits_out, P, s);
     };
     timed(ST_DECODER, 3.62e9 * P, body);
+    HIP_CHECK(hipGetLastError());
 }
 
 void SamModel::masks_on_device(k::PostJob const* jobs, int count) {

@@ -11,8 +11,8 @@ import json
 import sqlite3
 import sys
 
-GROUPS = [("gemm", ("gemm_f16_kernel", "gemm16_f16_kernel")), ("attention_window", ("attention_window_kernel",)),
-          ("attention_global", ("attention_global_kernel",))]
+GROUPS = [("gemm_pp", ("gemm_pp_kernel", "gemm_pp128_kernel")), ("gemm_other", ("gemm_f16_kernel", "gemm16_f16_kernel")),
+          ("attention_window", ("attention_window_kernel",)), ("attention_global", ("attention_global",))]
 PEAK = 2.5e15
 
 
