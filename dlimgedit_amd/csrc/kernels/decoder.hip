@@ -479,39 +479,86 @@ __global__ __launch_bounds__(256) void token_linears_kernel(LinJob job) {
     token_linear_columns(op, row1, first, nullptr, stat_in, stat_res, w_first, row0);
 }
 
+// Deep layers (the token MLP's second linear, K = 2048): one column per wave like token_linears_kernel, but the input
+// rows are staged in LDS by the whole workgroup and the wave's weight row is requested in full before that, so no
+// load sits inside the accumulation loop (that loop, 8 dependent trips to L2, made this launch 20.5 us for one prompt).
+// Same order of additions as token_linear_columns: results are bit-identical.
+constexpr int TLD_MAX_K = 2048;
+__global__ __launch_bounds__(256) void token_linear_deep_kernel(k::TokenLinear op, int rows) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];        // [row slice][K]
+    __shared__ float2_t stat_res[TL_MAX_ROWS];
+    const int lane = lane_id();
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int K4 = op.K >> 2, trips = K4 >> 6;
+    const int row0 = blockIdx.y * TL_ROW_SLICE, row1 = min(rows, row0 + TL_ROW_SLICE);
+    float4_t w[TLD_MAX_K / 256];
+#pragma unroll
+    for (int t = 0; t < TLD_MAX_K / 256; ++t)
+        w[t] = (t < trips && n < op.N) ? reinterpret_cast<const float4_t*>(op.W + (size_t)n * op.K)[lane + 64 * t]
+                                       : float4_t{0.f, 0.f, 0.f, 0.f};
+    const float4_t* src = reinterpret_cast<const float4_t*>(op.in.x + (size_t)row0 * op.K);
+    float4_t* dst = reinterpret_cast<float4_t*>(lds);
+    for (int i = threadIdx.x; i < (row1 - row0) * K4; i += 256) dst[i] = src[i];
+    if (op.resid.x && op.resid.ln_w) token_row_stats(op.resid, row1, stat_res, row0);
+    __syncthreads();
+    if (n >= op.N) return;
+    for (int r = row0; r < row1; ++r) {
+        const float4_t* xr = dst + (size_t)(r - row0) * K4;
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < TLD_MAX_K / 256; ++t)
+            if (t < trips) {
+                const float4_t x = xr[lane + 64 * t];
+                acc = fmaf(x[0], w[t][0], fmaf(x[1], w[t][1], fmaf(x[2], w[t][2], fmaf(x[3], w[t][3], acc))));
+            }
+        float v = wave_sum(acc);
+        if (lane == 0) {
+            v += op.b ? op.b[n] : 0.f;
+            if (op.relu) v = fmaxf(v, 0.f);
+            if (op.resid.x) v += token_row_load1(op.resid, stat_res, r, n);
+            op.Y[(size_t)r * op.N + n] = v;
+        }
+    }
+}
+
 // Self-attention among the 7 tokens of every prompt (8 heads x 32), recomputed by every workgroup into LDS, followed by
 // the output projection (one column per wave) with bias and residual: one launch instead of two.
+// Thread c owns channel c of q, k and v of a prompt (21 registers); a head is 32 adjacent lanes, so a score is one product
+// per lane summed over the half wave (DPP inside the rows of 16, one lane exchange across them).  [The first version had
+// every lane walk all 32 channels of its head out of LDS: 3136 LDS reads per thread and prompt, 12-14 us per launch.]
+DLIMG_DEVICE float sum_over_32_lanes(float v) {
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    v += dpp_move<0x141>(v);
+    v += dpp_move<0x140>(v);
+    return v + __shfl_xor(v, 16, 64);
+}
 __global__ __launch_bounds__(256) void token_self_attn_out_kernel(const float* __restrict__ q, const float* __restrict__ kx,
                                                                   const float* __restrict__ v, k::TokenLinear op, int P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* att = lds;                                   // [P * 7][256]
-    float* sq = att + (size_t)P * TOK * DIM;            // [7][256] x 3, one prompt at a time
-    float* sk = sq + TOK * DIM;
-    float* sv = sk + TOK * DIM;
-    float2_t* stat_res = reinterpret_cast<float2_t*>(sv + TOK * DIM);        // [P * 7]
-    const float4_t w_first = token_weight_prefetch(op, blockIdx.x * 4);
-    const int c = threadIdx.x;
-    const int h0 = (c >> 5) * 32;
-    const float scale = 0.17677669529663687f;           // 32^-0.5
     // prompts are dealt to blockIdx.y in pairs (rows row0 .. row1 of the token matrix; LDS rows are local)
     const int p0 = blockIdx.y * TL_PROMPT_SLICE, p1 = min(P, p0 + TL_PROMPT_SLICE);
     const int row0 = p0 * TOK, row1 = p1 * TOK;
+    float* att = lds;                                   // [rows of this slice][256]
+    float2_t* stat_res = reinterpret_cast<float2_t*>(att + (size_t)TL_PROMPT_SLICE * TOK * DIM) - row0;     // indexed by global row
+    const float4_t w_first = token_weight_prefetch(op, blockIdx.x * 4);
+    const int c = threadIdx.x;
+    const float scale = 0.17677669529663687f;           // 32^-0.5
     for (int p = p0; p < p1; ++p) {
-        __syncthreads();
+        float rq[TOK], rk[TOK], rv[TOK];
+#pragma unroll
         for (int t = 0; t < TOK; ++t) {
-            sq[t * DIM + c] = q[((size_t)p * TOK + t) * DIM + c];
-            sk[t * DIM + c] = kx[((size_t)p * TOK + t) * DIM + c];
-            sv[t * DIM + c] = v[((size_t)p * TOK + t) * DIM + c];
+            rq[t] = q[((size_t)p * TOK + t) * DIM + c] * scale;
+            rk[t] = kx[((size_t)p * TOK + t) * DIM + c];
+            rv[t] = v[((size_t)p * TOK + t) * DIM + c];
         }
-        __syncthreads();
+#pragma unroll
         for (int t = 0; t < TOK; ++t) {
             float s[TOK];
             float m = -INFINITY;
 #pragma unroll
             for (int j = 0; j < TOK; ++j) {
-                float d = 0.f;
-                for (int e = 0; e < 32; ++e) d = fmaf(sq[t * DIM + h0 + e], sk[j * DIM + h0 + e], d);
-                s[j] = d * scale;
+                s[j] = sum_over_32_lanes(rq[t] * rk[j]);
                 m = fmaxf(m, s[j]);
             }
             float l = 0.f, o = 0.f;
@@ -519,7 +566,7 @@ __global__ __launch_bounds__(256) void token_self_attn_out_kernel(const float* _
             for (int j = 0; j < TOK; ++j) {
                 const float pj = expf(s[j] - m);
                 l += pj;
-                o = fmaf(pj, sv[j * DIM + c], o);
+                o = fmaf(pj, rv[j], o);
             }
             att[((size_t)(p - p0) * TOK + t) * DIM + c] = o / l;
         }
@@ -561,29 +608,25 @@ __global__ __launch_bounds__(256) void token_merge_out_kernel(const float* __res
 
 // ---------------------------------------------------------------------------------------------
 // Image side, start of a decode: keys = embedding + no_mask_embed (has_mask_input == 0, segmentation.cpp:43-45) as fp32
-// and f16, and keys + dense positional encoding as f16 (the A operand of the k / q projections), for all prompts.
+// and f16 (the A operand of the image-side projections), for all prompts.
 __global__ __launch_bounds__(256) void decoder_keys_init_kernel(const float* const* __restrict__ emb,
                                                                 const float* __restrict__ no_mask,
-                                                                const float* __restrict__ pos, float* __restrict__ keys,
-                                                                half_t* __restrict__ keys_h, half_t* __restrict__ kp_h,
+                                                                float* __restrict__ keys, half_t* __restrict__ keys_h,
                                                                 size_t n4_per_prompt, int P) {
     const size_t total = n4_per_prompt * P;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t p = i / n4_per_prompt, j = i % n4_per_prompt;
         float4_t v = reinterpret_cast<const float4_t*>(emb[p])[j];
         v += reinterpret_cast<const float4_t*>(no_mask)[j % (DIM / 4)];
-        const float4_t kp = v + reinterpret_cast<const float4_t*>(pos)[j];
         reinterpret_cast<float4_t*>(keys)[i] = v;
         reinterpret_cast<half4_t*>(keys_h)[i] = half4_t{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-        reinterpret_cast<half4_t*>(kp_h)[i] = half4_t{(half_t)kp[0], (half_t)kp[1], (half_t)kp[2], (half_t)kp[3]};
     }
 }
 
-// LayerNorm of the keys (norm4 of a two-way block) in place, with both f16 forms the next step consumes.
+// LayerNorm of the keys (norm4 of a two-way block) in place, with the f16 form the image-side GEMMs consume.
 __global__ __launch_bounds__(256) void decoder_keys_norm_kernel(float* __restrict__ keys, const float* __restrict__ w,
                                                                 const float* __restrict__ b, float eps,
-                                                                const float* __restrict__ pos, half_t* __restrict__ keys_h,
-                                                                half_t* __restrict__ kp_h, int rows) {
+                                                                half_t* __restrict__ keys_h, int rows) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = lane_id();
@@ -592,10 +635,8 @@ __global__ __launch_bounds__(256) void decoder_keys_norm_kernel(float* __restric
     v -= mean;
     const float rstd = 1.0f / sqrtf(wave_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) / (float)DIM + eps);
     const float4_t y = v * rstd * reinterpret_cast<const float4_t*>(w)[lane] + reinterpret_cast<const float4_t*>(b)[lane];
-    const float4_t kp = y + reinterpret_cast<const float4_t*>(pos + (size_t)(row % NTOK_IMG) * DIM)[lane];
     reinterpret_cast<float4_t*>(keys + (size_t)row * DIM)[lane] = y;
     reinterpret_cast<half4_t*>(keys_h + (size_t)row * DIM)[lane] = half4_t{(half_t)y[0], (half_t)y[1], (half_t)y[2], (half_t)y[3]};
-    reinterpret_cast<half4_t*>(kp_h + (size_t)row * DIM)[lane] = half4_t{(half_t)kp[0], (half_t)kp[1], (half_t)kp[2], (half_t)kp[3]};
 }
 
 }  // namespace
@@ -658,13 +699,24 @@ void token_linears(const TokenLinear* ops, int count, int rows, hipStream_t s) {
         job.op[i] = ops[i];
         blocks += ops[i].N / 4;
     }
-    hipLaunchKernelGGL(token_linears_kernel, dim3(blocks, (rows + TL_ROW_SLICE - 1) / TL_ROW_SLICE), dim3(256), 0, s, job);
+    const int slices = (rows + TL_ROW_SLICE - 1) / TL_ROW_SLICE;
+    if (count == 1 && ops[0].K > DIM && ops[0].K % 256 == 0 && ops[0].K <= TLD_MAX_K && !ops[0].in.ln_w && !ops[0].in.add) {
+        static std::once_flag once;
+        std::call_once(once, [] {
+            (void)hipFuncSetAttribute((const void*)token_linear_deep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      TL_ROW_SLICE * TLD_MAX_K * 4);
+        });
+        const size_t lds = (size_t)std::min(rows, TL_ROW_SLICE) * ops[0].K * 4;
+        hipLaunchKernelGGL(token_linear_deep_kernel, dim3(ops[0].N / 4, slices), dim3(256), lds, s, ops[0], rows);
+        return;
+    }
+    hipLaunchKernelGGL(token_linears_kernel, dim3(blocks, slices), dim3(256), 0, s, job);
 }
 
 void token_self_attention_out(const float* q, const float* kx, const float* v, const TokenLinear& out, int P, hipStream_t s) {
     if (P <= 0) return;
     if (P * TOK > TL_MAX_ROWS || out.K != DIM || out.N % 4) throw_error("token_self_attention_out: unsupported shape");
-    const size_t lds = ((size_t)P * TOK * DIM + 3 * TOK * DIM) * 4 + (size_t)P * TOK * 8;
+    const size_t lds = (size_t)TL_PROMPT_SLICE * TOK * (DIM * 4 + 8);
     static std::once_flag once;
     std::call_once(once, [] {
         (void)hipFuncSetAttribute((const void*)token_self_attn_out_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -694,20 +746,19 @@ void token_to_image_partials(const float* q, const half_t* K, int ldk, const hal
                        ldv, scratch);
 }
 
-void decoder_keys_init(const float* const* emb_dev, const float* no_mask, const float* pos, float* keys, half_t* keys_h,
-                       half_t* kp_h, int P, hipStream_t s) {
+void decoder_keys_init(const float* const* emb_dev, const float* no_mask, float* keys, half_t* keys_h, int P,
+                       hipStream_t s) {
     if (P <= 0) return;
     const size_t n4 = (size_t)NTOK_IMG * DIM / 4;
     const size_t total = n4 * P;
     const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(decoder_keys_init_kernel, dim3(grid), dim3(256), 0, s, emb_dev, no_mask, pos, keys, keys_h, kp_h, n4, P);
+    hipLaunchKernelGGL(decoder_keys_init_kernel, dim3(grid), dim3(256), 0, s, emb_dev, no_mask, keys, keys_h, n4, P);
 }
 
-void decoder_keys_norm(float* keys, const float* w, const float* b, float eps, const float* pos, half_t* keys_h,
-                       half_t* kp_h, int P, hipStream_t s) {
+void decoder_keys_norm(float* keys, const float* w, const float* b, float eps, half_t* keys_h, int P, hipStream_t s) {
     if (P <= 0) return;
     const int rows = P * NTOK_IMG;
-    hipLaunchKernelGGL(decoder_keys_norm_kernel, dim3(rows / 4), dim3(256), 0, s, keys, w, b, eps, pos, keys_h, kp_h, rows);
+    hipLaunchKernelGGL(decoder_keys_norm_kernel, dim3(rows / 4), dim3(256), 0, s, keys, w, b, eps, keys_h, rows);
 }
 
 void output_heads(const TokenRows& queries, const HeadWeights& hw, float* hyper, float* iou, int P, hipStream_t s) {

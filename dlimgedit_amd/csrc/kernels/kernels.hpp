@@ -137,12 +137,10 @@ void token_self_attention_out(const float* q, const float* k, const float* v, co
 void token_to_image_partials(const float* q, const half_t* K, int ldk, const half_t* V, int ldv, float* scratch, int P,
                              hipStream_t);
 void token_merge_out(const float* scratch, const TokenLinear& out, int P, hipStream_t);
-// image side: keys = emb[p] + no_mask (fp32 + f16) and f16(keys + pos) for all prompts; emb_dev: DEVICE array of P pointers
-void decoder_keys_init(const float* const* emb_dev, const float* no_mask, const float* pos, float* keys, half_t* keys_h,
-                       half_t* kp_h, int P, hipStream_t);
-// keys = LayerNorm(keys) in place + f16(keys) + f16(keys + pos)
-void decoder_keys_norm(float* keys, const float* w, const float* b, float eps, const float* pos, half_t* keys_h,
-                       half_t* kp_h, int P, hipStream_t);
+// image side: keys = emb[p] + no_mask (fp32 + f16) for all prompts; emb_dev: DEVICE array of P pointers
+void decoder_keys_init(const float* const* emb_dev, const float* no_mask, float* keys, half_t* keys_h, int P, hipStream_t);
+// keys = LayerNorm(keys) in place + f16(keys)
+void decoder_keys_norm(float* keys, const float* w, const float* b, float eps, half_t* keys_h, int P, hipStream_t);
 // hyper-network MLPs (4 x 256->256->256->32) and IoU head (256->256->256->4) on the output tokens
 struct HeadWeights { const float* w[5][3]; const float* b[5][3]; };
 void output_heads(const TokenRows& queries /*[P,7,256]*/, const HeadWeights& hw, float* hyper /*[P,4,32]*/,

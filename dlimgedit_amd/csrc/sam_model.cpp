@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 
 namespace dlimg {
@@ -86,20 +87,19 @@ struct Loader {
         linear_f(prefix + ".v", inner, dim, a.v);
         linear_f(prefix + ".o", dim, inner, a.o);
     }
-    // rows of `a` followed by rows of `b` -> one f16 GEMM weight with concatenated bias
-    void fused_h(std::string const& pa, std::string const& pb, int out_each, int in, LinearH& l) {
-        HostTensor const& wa = file.get(pa + ".w", {out_each, in});
-        HostTensor const& wb = file.get(pb + ".w", {out_each, in});
-        HostTensor const& ba = file.get(pa + ".b", {out_each});
-        HostTensor const& bb = file.get(pb + ".b", {out_each});
-        std::vector<float> w(2 * (size_t)out_each * in), b(2 * (size_t)out_each);
-        std::memcpy(w.data(), wa.data, wa.numel() * 4);
-        std::memcpy(w.data() + wa.numel(), wb.data, wb.numel() * 4);
-        std::memcpy(b.data(), ba.data, ba.numel() * 4);
-        std::memcpy(b.data() + out_each, bb.data, bb.numel() * 4);
+    // rows of the named linears one after the other -> one f16 GEMM weight with concatenated bias
+    void fused_h(std::vector<std::string> const& parts, int out_each, int in, LinearH& l) {
+        const size_t n = parts.size();
+        std::vector<float> w(n * (size_t)out_each * in), b(n * (size_t)out_each);
+        for (size_t i = 0; i < n; ++i) {
+            HostTensor const& wi = file.get(parts[i] + ".w", {out_each, in});
+            HostTensor const& bi = file.get(parts[i] + ".b", {out_each});
+            std::memcpy(w.data() + i * wi.numel(), wi.data, wi.numel() * 4);
+            std::memcpy(b.data() + i * out_each, bi.data, bi.numel() * 4);
+        }
         f16_host(w.data(), w.size(), l.w);
         f32_host(b, l.b);
-        l.out = 2 * out_each;
+        l.out = int(n) * out_each;
         l.in = in;
         l.has_bias = true;
     }
@@ -185,6 +185,7 @@ SamWeights::SamWeights(std::string const& weight_path, int device_index) : devic
     }
     ld.norm("enc.neck.ln2", kEmbedDim, neck_ln2_);
 
+    DeviceBuffer<half_t> pe_h;      // dense positional encoding as a GEMM operand, only needed below
     ld.f32("pe.gauss", {2, 128}, pe_gauss_);
     ld.f32("pe.point", {4, 256}, pe_point_);
     ld.f32("pe.not_a_point", {256}, pe_not_a_point_);
@@ -202,8 +203,20 @@ SamWeights::SamWeights(std::string const& weight_path, int device_index) : devic
                     row[128 + kf] = std::cos(v);
                 }
             }
-        ld.f32_host(pe, image_pe_);
+        ld.f16_host(pe.data(), pe.size(), pe_h);
     }
+    // (keys + pos) W = keys W + pos W: the second term is a constant of the model, computed here once (same GEMM
+    // kernel, f16 pos like the sum it replaces) and added by the image-side projections as an fp32 addend.  Columns
+    // past `with_pos` (the value projection, which takes the keys without pos) stay zero.
+    auto pos_term = [&](LinearH const& l, int with_pos, DeviceBuffer<float>& dst) {
+        dst.reserve((size_t)kTokens * l.out);
+        HIP_CHECK(hipMemsetAsync(dst.get(), 0, (size_t)kTokens * l.out * sizeof(float), stream_));
+        k::GemmArgs g;
+        g.A = pe_h.get(); g.lda = 256; g.W = l.w.get(); g.ldw = 256;
+        g.out_f32 = dst.get(); g.ldc32 = l.out; g.M = kTokens; g.N = with_pos; g.K = 256;
+        g.unit_rows = kTokens;
+        k::gemm(g, stream_);
+    };
     ld.f32("dec.iou_token", {256}, iou_token_);
     ld.f32("dec.mask_tokens", {4, 256}, mask_tokens_);
     for (int i = 0; i < 2; ++i) {
@@ -216,8 +229,8 @@ SamWeights::SamWeights(std::string const& weight_path, int device_index) : devic
         ld.norm(p + ".ln4", 256, L.ln4);
         ld.linear_f(p + ".t2i.q", 128, 256, L.t2i_q);
         ld.linear_f(p + ".t2i.o", 256, 128, L.t2i_o);
-        ld.fused_h(p + ".t2i.k", p + ".i2t.q", 128, 256, L.img_kq);
-        ld.linear_h(p + ".t2i.v", 128, 256, true, L.img_v);
+        ld.fused_h({p + ".t2i.k", p + ".i2t.q", p + ".t2i.v"}, 128, 256, L.img_kqv);
+        pos_term(L.img_kqv, 256, L.pos_kqv);
         ld.linear_f(p + ".mlp.fc1", 2048, 256, L.mlp1);
         ld.linear_f(p + ".mlp.fc2", 256, 2048, L.mlp2);
         ld.linear_f(p + ".i2t.k", 128, 256, L.i2t_k);
@@ -226,8 +239,8 @@ SamWeights::SamWeights(std::string const& weight_path, int device_index) : devic
     }
     ld.linear_f("dec.final.q", 128, 256, final_q_);
     ld.linear_f("dec.final.o", 256, 128, final_o_);
-    ld.linear_h("dec.final.k", 128, 256, true, final_k_);
-    ld.linear_h("dec.final.v", 128, 256, true, final_v_);
+    ld.fused_h({"dec.final.k", "dec.final.v"}, 128, 256, final_kv_);
+    pos_term(final_kv_, 128, final_pos_kv_);
     ld.norm("dec.ln_final", 256, ln_final_);
     ld.conv_transpose_h("dec.up1", 256, 64, up1_);
     ld.norm("dec.up_ln", 64, up_ln_);
@@ -630,9 +643,7 @@ void SamModel::reserve_decoder(int count) {
     const size_t P = count, M = P * kTokens;
     keys_.reserve(M * 256);
     keys_h_.reserve(M * 256);
-    kp_h_.reserve(M * 256);
-    kq_h_.reserve(M * 256);
-    v_h_.reserve(M * 128);
+    kqv_h_.reserve(M * 384);
     att_img_h_.reserve(M * 128);
     up1_f32_.reserve(M * 256);
     up1_h_.reserve(M * 256);
@@ -688,8 +699,8 @@ void SamModel::decode_chunk(float const* const* emb, float const* coords, float 
         k::prompt_tokens(coords_.get(), coords_.get() + (size_t)P * 4, W.pe_gauss_.get(), W.pe_point_.get(),
                          W.pe_not_a_point_.get(), W.iou_token_.get(), W.mask_tokens_.get(), tokens_.get(), queries_.get(),
                          P, s);
-        // keys = image_embedding + no_mask_embed (has_mask_input == 0, segmentation.cpp:43-45), + positional encoding
-        k::decoder_keys_init(emb_dev, W.pe_no_mask_.get(), W.image_pe_.get(), keys_.get(), keys_h_.get(), kp_h_.get(), P, s);
+        // keys = image_embedding + no_mask_embed (has_mask_input == 0, segmentation.cpp:43-45)
+        k::decoder_keys_init(emb_dev, W.pe_no_mask_.get(), keys_.get(), keys_h_.get(), P, s);
 
         // Token side.  `cur` is the running token matrix as its consumers read it: un-normalised rows plus the
         // LayerNorm that belongs in front of them (applied on the fly by whoever reads, kernels/decoder.hip).
@@ -706,10 +717,13 @@ void SamModel::decode_chunk(float const* const* emb, float const* coords, float 
         auto normed = [&](float const* x, NormW const& n) {
             k::TokenRows r; r.x = x; r.ln_w = n.w.get(); r.ln_b = n.b.get(); r.eps = kDecLnEps; return r;
         };
-        auto img_gemm = [&](half_t const* A, int K, LinearH const& l, half_t* out_h, int ldc) {
+        // image side of the attentions: all projections of the keys in one MFMA GEMM, the positional part of
+        // (keys + pos) W as the constant addend SamWeights prepared
+        auto img_gemm = [&](LinearH const& l, DeviceBuffer<float> const& pos) {
             k::GemmArgs g;
-            g.A = A; g.lda = K; g.W = l.w.get(); g.ldw = K; g.bias = l.b.get();
-            g.out_h = out_h; g.ldc16 = ldc; g.M = M; g.N = l.out; g.K = K;
+            g.A = keys_h_.get(); g.lda = 256; g.W = l.w.get(); g.ldw = 256; g.bias = l.b.get();
+            g.resid = pos.get(); g.ldr = l.out; g.resid_mod = kTokens;
+            g.out_h = kqv_h_.get(); g.ldc16 = l.out; g.M = M; g.N = l.out; g.K = 256;
             g.shared_gpu = shared_gpu_;
             g.unit_rows = kTokens;
             k::gemm(g, s);
@@ -725,12 +739,11 @@ void SamModel::decode_chunk(float const* const* emb, float const* coords, float 
             k::token_self_attention_out(tq_.get(), tk_.get(), tv_.get(),
                                         lin({}, 256, L.self_attn.o, i == 0 ? k::TokenRows{} : cur, tsa_.get(), 0), P, s);
             const k::TokenRows q1 = normed(tsa_.get(), L.ln1);
-            // (2) tokens -> image: K = (keys + pos) Wk, V = keys Wv (image side, MFMA GEMMs)
-            img_gemm(kp_h_.get(), 256, L.img_kq, kq_h_.get(), 256);
-            img_gemm(keys_h_.get(), 256, L.img_v, v_h_.get(), 128);
+            // (2) tokens -> image: [K | Q of step 4 | V] = [(keys + pos) Wk | (keys + pos) Wq | keys Wv]
+            img_gemm(L.img_kqv, L.pos_kqv);
             k::TokenLinear tq = lin(rows_of(q1, true), 256, L.t2i_q, {}, tq_.get(), 0);
             k::token_linears(&tq, 1, T, s);
-            k::token_to_image_partials(tq_.get(), kq_h_.get(), 256, v_h_.get(), 128, t2i_part_.get(), P, s);
+            k::token_to_image_partials(tq_.get(), kqv_h_.get(), 384, kqv_h_.get() + 256, 384, t2i_part_.get(), P, s);
             k::token_merge_out(t2i_part_.get(), lin({}, 128, L.t2i_o, q1, tt2i_.get(), 0), P, s);
             const k::TokenRows q2 = normed(tt2i_.get(), L.ln2);
             // (3) token MLP
@@ -743,7 +756,7 @@ void SamModel::decode_chunk(float const* const* emb, float const* coords, float 
             k::TokenLinear kv[2] = {lin(rows_of(q3, true), 256, L.i2t_k, {}, tk_.get(), 0),
                                     lin(q3, 256, L.i2t_v, {}, tv_.get(), 0)};
             k::token_linears(kv, 2, T, s);
-            k::image_to_token_attention(kq_h_.get() + 128, 256, tk_.get(), tv_.get(), att_img_h_.get(), P, s);
+            k::image_to_token_attention(kqv_h_.get() + 128, 384, tk_.get(), tv_.get(), att_img_h_.get(), P, s);
             k::GemmArgs g;
             g.A = att_img_h_.get(); g.lda = 128; g.W = L.i2t_o.w.get(); g.ldw = 128; g.bias = L.i2t_o.b.get();
             g.resid = keys_.get(); g.ldr = 256; g.resid_mod = M; g.out_f32 = keys_.get(); g.ldc32 = 256;
@@ -751,16 +764,14 @@ void SamModel::decode_chunk(float const* const* emb, float const* coords, float 
             g.shared_gpu = shared_gpu_;
             g.unit_rows = kTokens;
             k::gemm(g, s);
-            k::decoder_keys_norm(keys_.get(), L.ln4.w.get(), L.ln4.b.get(), kDecLnEps, W.image_pe_.get(), keys_h_.get(),
-                                 kp_h_.get(), P, s);
+            k::decoder_keys_norm(keys_.get(), L.ln4.w.get(), L.ln4.b.get(), kDecLnEps, keys_h_.get(), P, s);
             cur = q3;
         }
         // final token -> image attention
-        img_gemm(kp_h_.get(), 256, W.final_k_, kq_h_.get(), 128);
-        img_gemm(keys_h_.get(), 256, W.final_v_, v_h_.get(), 128);
+        img_gemm(W.final_kv_, W.final_pos_kv_);
         k::TokenLinear fq = lin(rows_of(cur, true), 256, W.final_q_, {}, tq_.get(), 0);
         k::token_linears(&fq, 1, T, s);
-        k::token_to_image_partials(tq_.get(), kq_h_.get(), 128, v_h_.get(), 128, t2i_part_.get(), P, s);
+        k::token_to_image_partials(tq_.get(), kqv_h_.get(), 256, kqv_h_.get() + 128, 256, t2i_part_.get(), P, s);
         k::token_merge_out(t2i_part_.get(), lin({}, 128, W.final_o_, cur, tsa_.get(), 0), P, s);
         const k::TokenRows qf = normed(tsa_.get(), W.ln_final_);
 
@@ -852,7 +863,10 @@ void SamModel::enqueue_masks(MaskSlot& slot, k::PostJob const* jobs, int count, 
 
 void SamModel::finish_masks(MaskSlot& slot, k::PostJob const* jobs, int count, float* iou_out, int iou_count) {
     if (count <= 0) return;
+    static const bool trace = std::getenv("DLIMGEDIT_TIMING") != nullptr;     // diagnostic: host time of the two phases
+    const auto t0 = std::chrono::steady_clock::now();
     HIP_CHECK(hipEventSynchronize(slot.done));
+    const auto t1 = std::chrono::steady_clock::now();
     uint8_t const* pin = static_cast<uint8_t const*>(slot.pin.get());
     size_t off = 0;
     for (int i = 0; i < count; ++i) {
@@ -860,6 +874,10 @@ void SamModel::finish_masks(MaskSlot& slot, k::PostJob const* jobs, int count, f
         off += mask_bytes(jobs[i]);
     }
     if (iou_out && iou_count > 0) std::memcpy(iou_out, pin + slot.iou_offset, (size_t)iou_count * sizeof(float));
+    if (trace)
+        std::fprintf(stderr, "finish_masks: wait %.1f us, copy out %.1f us (%zu bytes)\n",
+                     std::chrono::duration<double, std::micro>(t1 - t0).count(),
+                     std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count(), off);
 }
 
 void SamModel::masks_to_host(k::PostJob const* jobs, int count) {

@@ -58,8 +58,8 @@ struct DecoderLayer {
     TokenAttention self_attn;
     NormW ln1, ln2, ln3, ln4;
     LinearF t2i_q, t2i_o;            // token side of token->image attention
-    LinearH img_kq;                  // [t2i.k ; i2t.q] fused: both consume (keys + pos)
-    LinearH img_v;                   // t2i.v on keys
+    LinearH img_kqv;                 // [t2i.k ; i2t.q ; t2i.v] fused: one GEMM over the keys
+    DeviceBuffer<float> pos_kqv;     // [4096, 384] pos . [Wk ; Wq]^T, zeros for the v columns (which take no pos)
     LinearF mlp1, mlp2;
     LinearF i2t_k, i2t_v;            // token side of image->token attention
     LinearH i2t_o;                   // image side output projection (128 -> 256)
@@ -80,11 +80,11 @@ struct SamWeights {
     LinearH neck1_, neck2_;               // 1x1 conv [256, D]; 3x3 conv as [256, 9*256] (tap-major columns)
     NormW neck_ln1_, neck_ln2_;
     DeviceBuffer<float> pe_gauss_, pe_point_, pe_not_a_point_, pe_no_mask_;
-    DeviceBuffer<float> image_pe_;        // [4096, 256] dense positional encoding (constant)
     DeviceBuffer<float> iou_token_, mask_tokens_;
     std::array<DecoderLayer, 2> dec_;
     LinearF final_q_, final_o_;
-    LinearH final_k_, final_v_;
+    LinearH final_kv_;                    // [final.k ; final.v]
+    DeviceBuffer<float> final_pos_kv_;    // [4096, 256] pos . Wk^T | 0
     NormW ln_final_;
     LinearH up1_, up2_;                   // transposed-conv weights as GEMM operands (sub-pixel-major rows)
     NormW up_ln_;
@@ -217,7 +217,7 @@ class SamModel {
     // ---- decoder workspace (sized for dec_count_ prompts)
     int dec_count_ = 0;
     DeviceBuffer<float> keys_, up1_f32_, up_, logits_, iou_, hyper_;
-    DeviceBuffer<half_t> keys_h_, kp_h_, kq_h_, v_h_, att_img_h_, up1_h_;
+    DeviceBuffer<half_t> keys_h_, kqv_h_, att_img_h_, up1_h_;
     DeviceBuffer<float> coords_, tokens_, queries_, tq_, tk_, tv_, tatt_, tsa_, tt2i_, tmlp_, t2i_part_;
     std::vector<std::unique_ptr<MaskSlot>> mask_slots_;     // all ever made (owned), guarded by done_mutex_
     std::vector<MaskSlot*> mask_free_;                      // those not handed out, guarded by done_mutex_
