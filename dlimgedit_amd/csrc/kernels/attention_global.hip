@@ -683,12 +683,11 @@ void launch_global(const half_t* qkv, const half_t* rel_h, const half_t* rel_w, 
     const size_t tiles = 2 * ((size_t)KT * (HD + 8) + (size_t)KT * V_STRIDE) * 2;
     const size_t scratch = 4 * 32 * GW_STRIDE * 4;
     const size_t lds = 4 * 64 * RELH_STRIDE * 4 + (tiles > scratch ? tiles : scratch);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;       // one flag per template instance; lanes launch concurrently
+    std::call_once(attr_once, [lds] {
         (void)hipFuncSetAttribute((const void*)attention_global_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
-        attr_set = true;
-    }
+    });
     static const int ablate = [] { const char* e = std::getenv("DLIMGEDIT_ATTN_ABLATE"); return e ? std::atoi(e) : 0; }();
     static const bool pingpong = [] { const char* e = std::getenv("DLIMGEDIT_ATTN_PP"); return !e || std::atoi(e) != 0; }();
     if (pingpong && !ablate) {

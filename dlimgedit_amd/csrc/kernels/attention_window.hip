@@ -21,6 +21,8 @@
 #include "device_common.hpp"
 #include "kernels.hpp"
 
+#include <mutex>
+
 namespace dlimg {
 namespace {
 
@@ -265,12 +267,11 @@ void launch_window(const half_t* qkv, const float* bias, const float* rel_h, con
     const size_t images = (size_t)SLOTS * (HD + 8) * 2 + (size_t)SLOTS * V_STRIDE * 2;
     const size_t scratch = 7 * 32 * G_STRIDE * 4;
     const size_t lds = images > scratch ? images : scratch;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;       // one flag per template instance; lanes launch concurrently
+    std::call_once(attr_once, [lds] {
         (void)hipFuncSetAttribute((const void*)attention_window_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
-        attr_set = true;
-    }
+    });
     hipLaunchKernelGGL(attention_window_kernel<HD>, dim3(B * NW * NW * heads), dim3(448), lds, s, qkv, bias, rel_h,
                        rel_w, out, heads);
 }
