@@ -232,7 +232,8 @@ def main() -> None:
         step_flops = B * (cfg.encoder_flops() + decoder_flops)
         chip_tflops = step_flops / (result["ms_per_step"] * 1e-3) / 1e12          # per GPU (every rank runs the same step)
         result["roofline"] = {
-            "kernel": "gemm_f16_kernel / gemm16_f16_kernel (every MFMA GEMM launch of the encoder)",
+            "kernel": "gemm_pp_kernel / gemm_pp128_kernel (qkv, fc1 / patch, proj, fc2: 49 launches per image) + gemm_f16_kernel "
+                      "(neck, decoder image side): every MFMA GEMM launch of a step",
             "bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
             "launches": g["launches"], "avg_launch_us": 1e3 * g["ms"] / max(1, g["launches"]),
