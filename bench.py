@@ -318,9 +318,9 @@ def main() -> None:
                 if args.model_dir else W.synthetic_weights(cfg, args.seed)
         gpu_mask = np.empty((1024, 1024), np.uint8)
         ext.copy_to_host(env, gpu_mask, mask_ptrs[0])
-        # BLAS threads: all cores of a 256-core host oversubscribe these matrix sizes (15 s per image against 5 s on 8
-        # cores in the build container); 32 is where the numpy port is fastest on the boxes tried
-        threads = min(32, os.cpu_count() or 1)
+        # BLAS threads: a one-GPU box has a CPU quota of 16 (cgroup cpu.max) whatever os.cpu_count() says (256); more
+        # threads than that oversubscribe (per image: 15 s with 256 threads, 10.7 s with 32, 7.5 s with 16, 7.6 s with 8)
+        threads = min(16, os.cpu_count() or 1)
         from threadpoolctl import threadpool_limits
         with threadpool_limits(limits=threads):
             t0 = time.perf_counter()
