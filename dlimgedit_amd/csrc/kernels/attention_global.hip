@@ -327,9 +327,13 @@ __global__ __launch_bounds__(512, 2) void attention_global_pp_kernel(const half_
 
     const int D = heads * HD;
     const int ld = 3 * D;
-    const int qblk = blockIdx.x % (TOKENS / 256);
-    const int head = (blockIdx.x / (TOKENS / 256)) % heads;
-    const int img = blockIdx.x / ((TOKENS / 256) * heads);
+    // consecutive workgroup ids go round-robin over the 8 XCDs: remapped so that the 16 query blocks of a head run on ONE
+    // XCD and its L2 serves their K / V tiles (un-mapped, every XCD fetched every head: 107 MB per launch against
+    // 25 MB algorithmic, profiles/r02_hbm_traffic_pmc.json)
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int qblk = bid % (TOKENS / 256);
+    const int head = (bid / (TOKENS / 256)) % heads;
+    const int img = bid / ((TOKENS / 256) * heads);
     const half_t* base = qkv + (size_t)img * TOKENS * ld + head * HD;
     const int tid = threadIdx.x;
     const int lane = lane_id();
