@@ -688,7 +688,7 @@ void launch_global(const half_t* qkv, const half_t* rel_h, const half_t* rel_w, 
     const size_t scratch = 4 * 32 * GW_STRIDE * 4;
     const size_t lds = 4 * 64 * RELH_STRIDE * 4 + (tiles > scratch ? tiles : scratch);
     static std::once_flag attr_once;       // one flag per template instance; lanes launch concurrently
-    std::call_once(attr_once, [lds] {
+    std::call_once(attr_once, [] {
         (void)hipFuncSetAttribute((const void*)attention_global_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
     });

@@ -268,7 +268,7 @@ void launch_window(const half_t* qkv, const float* bias, const float* rel_h, con
     const size_t scratch = 7 * 32 * G_STRIDE * 4;
     const size_t lds = images > scratch ? images : scratch;
     static std::once_flag attr_once;       // one flag per template instance; lanes launch concurrently
-    std::call_once(attr_once, [lds] {
+    std::call_once(attr_once, [] {
         (void)hipFuncSetAttribute((const void*)attention_window_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
     });

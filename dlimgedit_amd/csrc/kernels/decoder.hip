@@ -50,81 +50,7 @@ __global__ __launch_bounds__(256) void prompt_tokens_kernel(const float* __restr
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Y[r,n] = act((X[r,:]+X2[r,:]) . W[n,:] + b[n]) + R[r,n]; one wave per output column, 16-byte loads.
-constexpr int RCHUNK = 8;
-__global__ __launch_bounds__(256) void token_linear_kernel(const float* __restrict__ X, const float* __restrict__ X2,
-                                                           const float* __restrict__ W, const float* __restrict__ b,
-                                                           const float* R, float* Y, int rows, int K, int N, int relu) {
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N) return;
-    const int lane = lane_id();
-    const float4_t* wr = reinterpret_cast<const float4_t*>(W + (size_t)n * K);
-    const int K4 = K >> 2;
-    for (int r0 = 0; r0 < rows; r0 += RCHUNK) {
-        float acc[RCHUNK];
-#pragma unroll
-        for (int r = 0; r < RCHUNK; ++r) acc[r] = 0.f;
-        for (int k4 = lane; k4 < K4; k4 += 64) {
-            const float4_t w = wr[k4];
-#pragma unroll
-            for (int r = 0; r < RCHUNK; ++r) {
-                if (r0 + r < rows) {
-                    float4_t x = reinterpret_cast<const float4_t*>(X + (size_t)(r0 + r) * K)[k4];
-                    if (X2) x += reinterpret_cast<const float4_t*>(X2 + (size_t)(r0 + r) * K)[k4];
-                    acc[r] = fmaf(x[0], w[0], fmaf(x[1], w[1], fmaf(x[2], w[2], fmaf(x[3], w[3], acc[r]))));
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < RCHUNK; ++r) {
-            float v = wave_sum(acc[r]);
-            if (lane == 0 && r0 + r < rows) {
-                v += b ? b[n] : 0.f;
-                if (relu) v = fmaxf(v, 0.f);
-                if (R) v += R[(size_t)(r0 + r) * N + n];
-                Y[(size_t)(r0 + r) * N + n] = v;
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Self-attention among the 7 tokens (8 heads x 32).
-__global__ __launch_bounds__(256) void token_self_attention_kernel(const float* __restrict__ q,
-                                                                   const float* __restrict__ kx,
-                                                                   const float* __restrict__ v,
-                                                                   float* __restrict__ out) {
-    __shared__ float sq[TOK * DIM], sk[TOK * DIM], sv[TOK * DIM];
-    const int p = blockIdx.x, c = threadIdx.x;
-    for (int t = 0; t < TOK; ++t) {
-        sq[t * DIM + c] = q[((size_t)p * TOK + t) * DIM + c];
-        sk[t * DIM + c] = kx[((size_t)p * TOK + t) * DIM + c];
-        sv[t * DIM + c] = v[((size_t)p * TOK + t) * DIM + c];
-    }
-    __syncthreads();
-    const int h0 = (c >> 5) * 32;
-    const float scale = 0.17677669529663687f;   // 32^-0.5
-    for (int t = 0; t < TOK; ++t) {
-        float s[TOK];
-        float m = -INFINITY;
-#pragma unroll
-        for (int j = 0; j < TOK; ++j) {
-            float d = 0.f;
-            for (int e = 0; e < 32; ++e) d = fmaf(sq[t * DIM + h0 + e], sk[j * DIM + h0 + e], d);
-            s[j] = d * scale;
-            m = fmaxf(m, s[j]);
-        }
-        float l = 0.f, o = 0.f;
-#pragma unroll
-        for (int j = 0; j < TOK; ++j) {
-            float pj = expf(s[j] - m);
-            l += pj;
-            o = fmaf(pj, sv[j * DIM + c], o);
-        }
-        out[((size_t)p * TOK + t) * DIM + c] = o / l;
-    }
-}
+constexpr int RCHUNK = 8;      // rows a wave accumulates at a time in the token linears
 
 // ---------------------------------------------------------------------------------------------
 // Tokens attend to the 4096 image positions (8 heads x 16), in two steps so that the 4096 keys of a head are spread
@@ -132,7 +58,7 @@ __global__ __launch_bounds__(256) void token_self_attention_kernel(const float* 
 //   partial: workgroup = (prompt, head, key group of 512); a thread takes 2 keys (requested up front), then query
 //            by query scores them, does the softmax against the wave's maximum (one exponential per score, no
 //            rescale) and its part of P.V; butterfly inside each wave -> per-wave (max, sum, output[16]) in `part`
-//   merge  : thread = (prompt, query, head, dim) folds the 8 x 4 wave partials in a fixed order
+//   merge  : token_merge_out_kernel folds the 8 group partials in a fixed order and applies the output projection
 constexpr int T2I_GROUPS = 8;                                  // key groups per head
 constexpr int T2I_THREADS = 256;
 constexpr int T2I_KEYS = NTOK_IMG / T2I_GROUPS / T2I_THREADS;  // keys per thread
@@ -211,25 +137,6 @@ __global__ __launch_bounds__(T2I_THREADS) void token_to_image_partial_kernel(con
         for (int w = 0; w < T2I_WAVES; ++w) acc += (e == 0 ? 0.f : wpart[t][w][e]) * __expf(wpart[t][w][0] - M);
         dst[(size_t)t * T2I_PARTS * 18 + e] = e == 0 ? M : acc;
     }
-}
-
-__global__ __launch_bounds__(256) void token_to_image_merge_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                                   int total) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;          // ((p * TOK + t) * HEADS + h) * 16 + e
-    if (idx >= total) return;
-    const int e = idx & 15, h = (idx >> 4) % HEADS, t = (idx / (16 * HEADS)) % TOK, p = idx / (16 * HEADS * TOK);
-    const float* src = part + ((((size_t)p * HEADS + h) * TOK + t) * T2I_PARTS) * 18;
-    float M = src[0];
-#pragma unroll
-    for (int w = 1; w < T2I_PARTS; ++w) M = fmaxf(M, src[w * 18]);
-    float ls = 0.f, os = 0.f;
-#pragma unroll
-    for (int w = 0; w < T2I_PARTS; ++w) {
-        const float f = __expf(src[w * 18] - M);
-        ls += src[w * 18 + 1] * f;
-        os += src[w * 18 + 2 + e] * f;
-    }
-    out[((size_t)p * TOK + t) * INNER + h * 16 + e] = os / ls;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -649,29 +556,6 @@ void prompt_tokens(const float* coords, const float* labels, const float* gauss,
     if (P <= 0) return;
     hipLaunchKernelGGL(prompt_tokens_kernel, dim3(P), dim3(256), 0, s, coords, labels, gauss, point_embed, not_a_point,
                        iou_token, mask_tokens, tokens, tokens_copy);
-}
-
-void token_linear(const float* X, const float* X2, const float* W, const float* b, const float* R, float* Y, int rows,
-                  int K, int N, int relu, hipStream_t s) {
-    if (rows <= 0 || N <= 0) return;
-    if (K <= 0 || K % 4) throw_error("token_linear: K must be a positive multiple of 4");
-    hipLaunchKernelGGL(token_linear_kernel, dim3((N + 3) / 4), dim3(256), 0, s, X, X2, W, b, R, Y, rows, K, N, relu);
-}
-
-void token_self_attention(const float* q, const float* kx, const float* v, float* out, int P, hipStream_t s) {
-    if (P <= 0) return;
-    hipLaunchKernelGGL(token_self_attention_kernel, dim3(P), dim3(256), 0, s, q, kx, v, out);
-}
-
-void token_to_image_attention(const float* q, const half_t* K, int ldk, const half_t* V, int ldv, float* scratch,
-                              float* out, int P, hipStream_t s) {
-    if (P <= 0) return;
-    if (ldk % 8 || ldv % 8 || (((uintptr_t)K | (uintptr_t)V) & 15))
-        throw_error("token_to_image_attention: K/V rows must be 16-byte aligned");
-    hipLaunchKernelGGL(token_to_image_partial_kernel, dim3(P * HEADS * T2I_GROUPS), dim3(T2I_THREADS), 0, s, q, K, ldk, V,
-                       ldv, scratch);
-    const int total = P * TOK * INNER;
-    hipLaunchKernelGGL(token_to_image_merge_kernel, dim3((total + 255) / 256), dim3(256), 0, s, scratch, out, total);
 }
 
 size_t token_to_image_scratch_floats(int P) { return (size_t)P * HEADS * TOK * T2I_PARTS * 18; }

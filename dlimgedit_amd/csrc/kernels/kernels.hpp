@@ -95,15 +95,7 @@ void attention_global(const half_t* qkv, const half_t* rel_h, const half_t* rel_
 void prompt_tokens(const float* coords, const float* labels, const float* gauss, const float* point_embed,
                    const float* not_a_point, const float* iou_token, const float* mask_tokens, float* tokens,
                    float* tokens_copy, int P, hipStream_t s);
-// Y[r,n] = act((X[r,:] + X2[r,:]) . W[n,:] + b[n]) + R[r,n]; X2/R optional; act: 0 none, 2 relu
-void token_linear(const float* X, const float* X2, const float* W, const float* b, const float* R, float* Y,
-                  int rows, int K, int N, int relu, hipStream_t);
-// multi-head attention among the 7 tokens of each prompt: q,k,v [P,7,256] -> out [P,7,256] (8 heads)
-void token_self_attention(const float* q, const float* k, const float* v, float* out, int P, hipStream_t);
-// tokens attend to the image: q [P,7,128] f32, K,V [P,4096,ld] f16 (column offsets given) -> out [P,7,128]
-// scratch: token_to_image_scratch_floats(P) floats of workspace for the per-key-group partial results
-void token_to_image_attention(const float* q, const half_t* K, int ldk, const half_t* V, int ldv, float* scratch,
-                              float* out, int P, hipStream_t s);
+// floats of workspace for the per-key-group partial results of token_to_image_partials
 size_t token_to_image_scratch_floats(int P);
 // image attends to tokens: q [P,4096,ldq] f16, k,v [P,7,128] f32 -> out [P,4096,128] f16
 void image_to_token_attention(const half_t* q, int ldq, const float* k, const float* v, half_t* out, int P,
