@@ -72,3 +72,20 @@ with tempfile.TemporaryDirectory() as d:
     r = run_threads(lanes, mixed_5prompts)
     print(f"{variant}: config 5 share (mixed resolution -> device resize, 5 prompts/image on the cached embedding), "
           f"{lanes} threads: {r:8.1f} img/s = {5 * r:8.1f} masks/s")
+
+    # the decode half of config 5 alone: prompts on embeddings that are already cached (the interactive use of the library)
+    cached = [api.Segmentation.process(v, env) for v in mixed]
+    def prompts_on_cached(i):
+        seg = cached[i % len(cached)]
+        e = seg.extent()
+        pts = [api.Point(int(e.width * fx), int(e.height * fy)) for fx, fy in ((.5, .5), (.25, .33), (.75, .2), (.6, .8), (.1, .9))]
+        api.Segmentation.compute_mask_batch([seg] * 5, points=pts)
+        return 5
+    print(f"{variant}: 5 prompts per call on cached embeddings (mixed sizes), 1 thread: {run_threads(1, prompts_on_cached):8.1f} masks/s, "
+          f"{lanes} threads: {run_threads(lanes, prompts_on_cached):8.1f} masks/s")
+    full = cached[-1]
+    def one_prompt(_):
+        full.compute_mask(api.Point(512, 512))
+        return 1
+    print(f"{variant}: 1 prompt per call on a cached 1024x1024 embedding, 1 thread: {run_threads(1, one_prompt):8.1f} masks/s, "
+          f"{lanes} threads: {run_threads(lanes, one_prompt):8.1f} masks/s")
