@@ -536,25 +536,27 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm16_f16_kernel(k::Gem
 //
 // Eight waves, 2 (M) x 4 (N), each owning 128 x 64 of the tile (8 x 4 accumulator tiles of 16 x 16).  The four waves
 // with wr = 0 and the four with wr = 1 are two GROUPS, one wave of each per SIMD, that run the same program ONE
-// BARRIER APART: per K tile of 64 a wave goes through four phases, each { L: fragment reads from LDS + two DMA
-// requests; barrier; M: 16 MFMAs (one 64 x 32 quadrant of its accumulators over the whole K tile); barrier }, and while
+// BARRIER APART: per K tile of 64 a wave goes through two phases, each { L: fragment reads from LDS + four DMA
+// requests; barrier; M: 32 MFMAs (one 64-row half of its accumulators over the whole K tile); barrier }, and while
 // one group is in an M segment the other is in an L segment -- the matrix pipe of every SIMD always has a wave feeding
-// it, and LDS reads / DMA issue never sit in front of MFMAs of the same wave.
+// it, and LDS reads / DMA issue never sit in front of MFMAs of the same wave.  [The template's four phases of 16 MFMAs
+// measured 2700 cycles per K tile against 2048 of MFMA issue: every M segment pays ~80 cycles for its barrier and
+// wait; with two phases of 32 MFMAs 2405 -- 4096^3: 2528 -> 2152, 1297 TFLOP/s at the 1.38 GHz the chip holds there.
+// The fragment registers are the same 64: both W halves were live across the four phases anyway.]
 //
 // LDS: 2 buffers (K tile parity) x 4 half-tiles of 16 KB: A rows 0-127, A rows 128-255, W rows 0-127, W rows 128-255
 // (128 rows x 64 halves, lane-linear DMA image, chunk ^= (row >> 1) & 7 on the source address and on the read).
 // All eight waves stage every half-tile (2 DMA wave-instructions each).  Half-tile life cycle, in slots (= intervals
-// between barriers; group 0 has L(t,q) in slot 8t+2q and M(t,q) in 8t+2q+1, group 1 one slot later):
-//   phase            reads (group's own A half; W half by wave column)       stages
-//   0 (mh0, nh0)     A rows mh0 (8 x b128), W cols nh0 (4)                   A0 of tile t+1
-//   1 (mh0, nh1)     W cols nh1 (4)                                          A1 of tile t+1
-//   2 (mh1, nh1)     A rows mh1 (8)                                          W0 of tile t+2
-//   3 (mh1, nh0)     -- (W fragments of phase 0 are still in registers)      W1 of tile t+2, then wait: tile t+1 landed
+// between barriers; group 0 has L(t,p) in slot 4t+2p and M(t,p) in 4t+2p+1, group 1 one slot later):
+//   phase        reads (group's own A half; W half by wave column)          stages
+//   A (rows mh0) W cols nh0 and nh1 (8 x b128), A rows mh0 (8)              A0, A1 of tile t+1
+//   B (rows mh1) A rows mh1 (8); the W fragments stay in registers          W0, W1 of tile t+2, then wait: tile t+1 landed
 // WAR: every L segment ends with lgkmcnt(0) BEFORE its barrier, so a half-tile is overwritten only in a later slot
-// than its last read (A0/A1 of the other buffer were last read in phase 2 of tile t-1; W of this buffer in phase 1 of
-// this tile by the later group, slot 8t+3, restaged from slot 8t+4 on).  RAW: the vmcnt wait of phase 3 (4 newer
-// requests may stay in flight) is passed by every wave before the barrier that ends slot 8t+7; tile t+1 is first read
-// in slot 8t+8.
+// than its last read (A0/A1 of the other buffer were last read in phase B of tile t-1, by the later group in slot
+// 4t-1, and are restaged from slot 4t on; W of THIS buffer is last read in phase A of this tile by the later group,
+// slot 4t+1, and restaged from slot 4t+2 on).  RAW: the vmcnt wait of phase B (the 4 newer requests, W of tile t+2,
+// may stay in flight) is passed by every wave before the barrier that ends slot 4t+3; tile t+1 is first read in
+// slot 4t+4.
 constexpr int kPPHalfBytes = 128 * 128;
 constexpr int kPPBufBytes = 4 * kPPHalfBytes;
 constexpr int kPPAuxBytes = 256 * 8 + 2 * 256 * 4 + 256 * 4 * 8;      // rowstat, colvec[2], rowpart [256][4]
@@ -825,33 +827,26 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(k::GemmArgs a) {
     auto step = [&](int t, auto buf_tag, auto steady_tag) {
         constexpr int buf = decltype(buf_tag)::value;
         constexpr bool STEADY = decltype(steady_tag)::value;
-        // phase 0
+        // phase A (rows mh0): all of W(t) and the first A half; 32 MFMAs
         read_w(buf, 0);
+        read_w(buf, 1);
         read_a(buf, 0);
-        if (STEADY || t + 1 < nk) stage(t + 1, 0);
+        if (STEADY || t + 1 < nk) { stage(t + 1, 0); stage(t + 1, 1); }
         pp_barrier_after_reads();
         mfma_quadrant(0, 0);
-        pp_barrier();
-        // phase 1
-        read_w(buf, 1);
-        if (STEADY || t + 1 < nk) stage(t + 1, 1);
-        pp_barrier_after_reads();
         mfma_quadrant(0, 1);
         pp_barrier();
-        // phase 2
+        // phase B (rows mh1): the second A half, W fragments still in registers; 32 MFMAs
         read_a(buf, 1);
-        if (STEADY || t + 2 < nk) stage(t + 2, 2);
-        pp_barrier_after_reads();
-        mfma_quadrant(1, 1);
-        pp_barrier();
-        // phase 3
         if (STEADY || t + 2 < nk) {
+            stage(t + 2, 2);
             stage(t + 2, 3);
             wait_dma<4>();                       // everything older than W(t+2) has landed: tile t+1 is complete
         } else {
             wait_dma<0>();
         }
-        pp_barrier();
+        pp_barrier_after_reads();
+        mfma_quadrant(1, 1);
         mfma_quadrant(1, 0);
         pp_barrier();
     };
@@ -887,16 +882,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(k::GemmArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 // 128 x 256 x 64 variant of the ping-pong kernel, for the GEMMs whose N gives too few 256 x 256 tiles (proj / fc2 of
 // ViT-B: N = 768 -> 96 workgroups instead of 48).  Same two wave groups one barrier apart; a wave owns 64 x 64 (4 x 4
-// accumulator tiles), group g the A rows 64g .. 64g+63, and a K tile takes TWO phases of 16 MFMAs:
-//   phase           reads                                              stages
-//   0 (cols nh0)    A rows of the group (8 x b128), W cols nh0 (4)     W0, W1 of tile t+2
-//   1 (cols nh1)    W cols nh1 (4)                                     A of tile t+2, then wait: tile t+1 landed
-// LDS: A in 2 buffers of 16 KB (128 rows), W in 3 buffers of 2 x 16 KB: A(t) is last read in slot 4t+1 (group 1, phase
-// 0) and restaged from slot 4t+2 on; W(t) is last read in slot 4t+3 and its buffer is next written for tile t+3 in
-// slot 4t+4 (the third W buffer is what puts 7 slots between a request and its first read instead of 3).
-// vmcnt(6): the A/W requests of tiles t+2 issued in this tile may stay in flight, everything older has landed.
-constexpr int kPP128WBase = 2 * kPPHalfBytes;                        // A buffers first
-constexpr int kPP128Operands = 2 * kPPHalfBytes + 3 * 2 * kPPHalfBytes;   // 128 KB
+// accumulator tiles), group g the A rows 64g .. 64g+63, and a K tile is ONE read slot (all fragments of the tile: 8 A
+// and 8 W reads of 16 bytes, and the six DMA requests of tile t+2) followed by ONE slot of 32 MFMAs -- with two phases
+// of 16 MFMAs per tile the barrier and the wait in front of every MFMA slot cost ~100 of 358 cycles per slot
+// (1432 cycles per K tile against 1024 of MFMA issue).
+// LDS: A in 3 buffers of 16 KB (128 rows), W in 3 buffers of 2 x 16 KB, tile t in buffers t % 3.  Group 0 reads tile t
+// in slot 2t, group 1 in slot 2t+1; tile t+2 is requested in those same slots into the buffers of tile t-1, whose last
+// reader was group 1 in slot 2t-1.  [Two A buffers would do only with the A request of tile t+2 issued after BOTH
+// groups have read tile t, i.e. in a second read slot.]
+// vmcnt(6): the six requests of tile t+2 issued in this slot may stay in flight, everything older has landed.
+constexpr int kPP128WBase = 3 * kPPHalfBytes;                        // A buffers first
+constexpr int kPP128Operands = 3 * kPPHalfBytes + 3 * 2 * kPPHalfBytes;   // 144 KB
 constexpr int kPP128Aux = 128 * 8 + 2 * 256 * 4 + 128 * 4 * 8;
 constexpr int kPP128Lds = kPP128Operands + kPP128Aux;
 
@@ -935,8 +931,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(k::GemmArgs a) {
         src_w[q] = a.W + (size_t)(n0 + row) * a.ldw + chunk * 8;
     }
     const size_t w_half = (size_t)128 * a.ldw;
-    auto stage_a = [&](int t) {
-        char* dst = smem + (t & 1) * kPPHalfBytes + wave * 2048;
+    auto stage_a = [&](int t, int abuf) {
+        char* dst = smem + abuf * kPPHalfBytes + wave * 2048;
 #pragma unroll
         for (int q = 0; q < 2; ++q) glds16(src_a[q] + (size_t)t * 64, dst + q * 1024);
     };
@@ -957,9 +953,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(k::GemmArgs a) {
     RowStats<BM, 512, EPI> row_stats;
     column_vectors.issue(a, n0);
     row_stats.issue(a, m0);
-    // tiles 0 and 1 (tile t lives in A buffer t & 1 and W buffer t % 3)
-    stage_a(0); stage_w(0, 0, 0); stage_w(0, 0, 1);
-    if (nk > 1) { stage_a(1); stage_w(1, 1, 0); stage_w(1, 1, 1); }
+    // tiles 0 and 1 (tile t lives in A buffer and W buffer t % 3)
+    stage_a(0, 0); stage_w(0, 0, 0); stage_w(0, 0, 1);
+    if (nk > 1) { stage_a(1, 1); stage_w(1, 1, 0); stage_w(1, 1, 1); }
     column_vectors.store(colvec);
     row_stats.finish(a, rowstat);
     if (nk > 1) wait_dma<6>(); else wait_dma<0>();
@@ -986,47 +982,38 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(k::GemmArgs a) {
     pp_barrier();
     if (wr == 1) pp_barrier();
 
-    half8_t fa[4][2], fw[2][2];                  // A: [i][ks]; W of the current column half: [j][ks]
-    auto mfma_half = [&](int nh) {
+    half8_t fa[4][2], fw[4][2];                  // A: [i][ks]; W: [column tile j of the wave's 64][ks]
+    auto mfma_tile = [&] {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][nh * 2 + j] =
-                        __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[j][ks], fa[i][ks], acc[i][nh * 2 + j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[j][ks], fa[i][ks], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
-    auto read_w = [&](const char* wb, int nh) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            fw[j][0] = frag(wb + (nh * 32 + j * 16) * 128 + off0);
-            fw[j][1] = frag(wb + (nh * 32 + j * 16) * 128 + off1);
-        }
-    };
-    int wbuf = 0;                                // t % 3
+    int buf3 = 0;                                // t % 3
     auto step = [&](int t, auto steady_tag) {
         constexpr bool STEADY = decltype(steady_tag)::value;
-        const char* ab = a_base + (t & 1) * kPPHalfBytes;
-        const char* wb = w_base + wbuf * 2 * kPPHalfBytes;
-        const int wbuf2 = wbuf == 0 ? 2 : wbuf - 1;      // (t + 2) % 3
-        // phase 0
-        read_w(wb, 0);
+        const char* ab = a_base + buf3 * kPPHalfBytes;
+        const char* wb = w_base + buf3 * 2 * kPPHalfBytes;
+        const int next2 = buf3 == 0 ? 2 : buf3 - 1;      // (t + 2) % 3
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            fw[j][0] = frag(wb + j * 2048 + off0);
+            fw[j][1] = frag(wb + j * 2048 + off1);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             fa[i][0] = frag(ab + i * 2048 + off0);
             fa[i][1] = frag(ab + i * 2048 + off1);
         }
-        if (STEADY || t + 2 < nk) { stage_w(t + 2, wbuf2, 0); stage_w(t + 2, wbuf2, 1); }
-        pp_barrier_after_reads();
-        mfma_half(0);
-        pp_barrier();
-        // phase 1
-        read_w(wb, 1);
         if (STEADY || t + 2 < nk) {
-            stage_a(t + 2);
+            stage_w(t + 2, next2, 0);
+            stage_w(t + 2, next2, 1);
+            stage_a(t + 2, next2);
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(0) vmcnt(6)\n\ts_barrier" ::: "memory");
         } else {
@@ -1034,9 +1021,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(k::GemmArgs a) {
             asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)\n\ts_barrier" ::: "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
-        mfma_half(1);
+        mfma_tile();
         pp_barrier();
-        wbuf = wbuf == 2 ? 0 : wbuf + 1;
+        buf3 = buf3 == 2 ? 0 : buf3 + 1;
     };
     const unsigned long long t_loop = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     const unsigned long long r_loop = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -1169,8 +1156,8 @@ constexpr TileCfg kTiles[] = {
     {256, 256, 1, 0.00f},   // 7: as 6 on v_mfma_f32_16x16x32_f16, fragments one K tile ahead (4096^3: 1010 TFLOP/s); forced only
     {128, 128, 2, 0.00f},   // 8: 2x2 waves on 16x16x32, BK 32, 4 stages, 64 KB LDS (forced only until measured)
     {256, 256, 1, 1.60f},   // 9: ping-pong kernel (gemm_pp_kernel): 8 waves in two groups one barrier apart, BK 64
-                            //    (4096^3: 1110-1160 TFLOP/s at the 1.3-1.6 GHz the chip holds under that load)
-    {128, 256, 1, 0.00f},   // 10: 128 x 256 ping-pong kernel (gemm_pp128_kernel), two phases per K tile
+                            //    (4096^3: 1300 TFLOP/s at the 1.4 GHz the chip holds under that load)
+    {128, 256, 1, 0.00f},   // 10: 128 x 256 ping-pong kernel (gemm_pp128_kernel), one read slot + one MFMA slot per K tile
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
