@@ -24,7 +24,9 @@ Besides the contract fields the JSON line carries
                 included): slots 3-4 from one and from several host threads, slots 13-14 with 8 images per call
   cpu_baseline  the CPU oracle (oracle/sam_oracle.py, a port: the reference's onnxruntime path cannot
                 be built here) timed on this host on one image of the same workload
-  mask_iou      IoU of the HIP mask against the oracle's mask for that image
+  encoder_only  images/s of pre-processing + encoder alone; decode_only: prompts/s on a cached embedding
+  mask_iou      IoU of the HIP mask against the oracle's mask for that image (+ logits_check: max-abs error of the
+                decoder's logits / IoU predictions / the embedding against the oracle, fraction of near-zero logits)
   stages        per-stage breakdown of the profiled repeat (profile_mode says how it was taken)
   rccl          N > 1: ranks counted by an all-reduce of ones, and the optional gather of the finished masks to
                 every rank (RCCL all_gather over xGMI, after the timed region: no collective is on the data path)
@@ -266,6 +268,18 @@ def main() -> None:
                              "mfma_frac": B * cfg.encoder_flops() / (enc_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS
                              if enc_ms > 0 else 0.0}
 
+    # ---- per-stage rates SURVEY.md section 8d asks for next to the metric: encoder alone (device resident, all lanes)
+    if rank == 0 and world == 1:
+        for _ in range(2):
+            ext.encode_only(env, views)
+        ext.synchronize(env)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ext.encode_only(env, views)
+        ext.synchronize(env)
+        result["encoder_only"] = {"value": B * args.steps / (time.perf_counter() - t0), "unit": "images/s",
+                                  "note": "pre-processing + ViT encoder + neck, inputs resident in HBM, all lanes"}
+
     # ---- the drop-in ABI itself: host buffers in and out (PCIe inclusive), rank 0, N = 1 only
     if rank == 0 and world == 1 and not args.no_abi_path:
         import threading
@@ -301,7 +315,26 @@ def main() -> None:
             [t.join() for t in ts]
             return sum(counts) / (time.perf_counter() - t0)
 
+        cached = api.Segmentation.process(view, env)
+
+        def one_prompt():
+            cached.compute_mask(api.Point(512, 512))
+            return 1
+
+        def five_prompts():
+            api.Segmentation.compute_mask_batch([cached] * 5, points=[api.Point(200 + 150 * j, 300 + 100 * j) for j in range(5)])
+            return 5
+
         lanes = ext.lane_count(env)
+        result["decode_only"] = {
+            "unit": "prompts/s", "note": "prompt encoder + mask decoder + post-processing on a cached embedding through "
+                                         "the ABI (slots 4 / 14), 1 MiB host mask out per prompt",
+            "one_prompt_per_call_one_thread": rate(one_prompt, 1, 1.0),
+            f"one_prompt_per_call_{lanes}_threads": rate(one_prompt, lanes, 1.0),
+            "five_prompts_per_call_one_thread": rate(five_prompts, 1, 1.0),
+            f"five_prompts_per_call_{lanes}_threads": rate(five_prompts, lanes, 1.0),
+        }
+        cached.close()
         result["abi_path"] = {
             "unit": "images/s", "note": "host pixels in, host masks out through dlimg_Api; PCIe and host copies included",
             "slots_3_4_one_thread": rate(one_image, 1),
@@ -347,6 +380,13 @@ def main() -> None:
                               dict(region=(256, 256, 768, 768)))):
             want = ora.compute_mask(**op)
             checks.append({"prompt": name, "iou": iou_of(seg.compute_mask(gp), want), "foreground": float((want > 0).mean())})
+        low_gpu, iou_gpu = ext.get_logits(seg, point=api.Point(512, 512))
+        low_cpu, iou_cpu = ora.logits(point=(512, 512))
+        result["logits_check"] = {"max_abs_error": float(np.abs(low_gpu - low_cpu).max()),
+                                  "max_abs_logit": float(np.abs(low_cpu).max()),
+                                  "fraction_abs_logit_below_1e-3": float((np.abs(low_cpu) < 1e-3).mean()),
+                                  "iou_prediction_max_abs_error": float(np.abs(iou_gpu - iou_cpu).max()),
+                                  "embedding_max_abs_error": float(np.abs(ext.get_embedding(seg) - ora.embedding).max())}
         result["mask_iou"] = min(c["iou"] for c in checks)
         result["mask_iou_checks"] = checks
 
