@@ -13,12 +13,15 @@ timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o f
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o write -- $B > $O/w.log 2>&1 && echo write ok &&
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES -d $O/pmc_mfma -o m -- $B > $O/m.log 2>&1 && echo mfma ok
 
+# the profiler's own --stats table of the 4-lane run (csv)
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $O/st -o st --output-format csv -- $B > $O/st.log 2>&1 && echo stats ok
 # summaries only travel back (the databases are larger than gpurun's 64 MiB return limit)
 S=$R/gpurun_out/r02_summary; rm -rf $S; mkdir -p $S
 python3 $R/tools/kernel_stats.py $O/kt/kt_results.db 40 > $S/kernel_stats_4lanes.txt
 python3 $R/tools/kernel_stats.py $O/kt1/kt1_results.db 40 > $S/kernel_stats_single_lane.txt
 python3 $R/tools/pmc_traffic.py $O/pmc_fetch/fetch_results.db $O/pmc_write/write_results.db $S/hbm_traffic_pmc.json > $S/traffic.log 2>&1
 python3 $R/tools/pmc_mfma.py $O/pmc_mfma/m_results.db $S/mfma_util_pmc.json > $S/mfma.log 2>&1
+cp $(ls $O/st/*/st_kernel_stats.csv $O/st/st_kernel_stats.csv 2>/dev/null | head -1) $S/kernel_stats_rocprofv3.csv 2>/dev/null
 grep "^{" $O/bench_kt.log | tail -1 > $S/bench_under_kernel_trace.json
 rm -rf $O
 ls -la $S
