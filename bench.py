@@ -84,6 +84,9 @@ def main() -> None:
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model-dir", default=None, help="existing model directory (default: seeded synthetic weights)")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="one-GPU rehearsal of the N > 1 code path: every rank uses GPU 0 and the collectives run on gloo / CPU "
+                         "tensors (RCCL refuses two ranks on one device); the line is marked as a rehearsal, never a result")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -93,16 +96,21 @@ def main() -> None:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
-    os.environ["DLIMGEDIT_DEVICE"] = str(local_rank)
+    dev_index = 0 if args.rehearse_gloo else local_rank
+    coll_dev = "cpu" if args.rehearse_gloo else "cuda"
+    os.environ["DLIMGEDIT_DEVICE"] = str(dev_index)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from dlimgedit_amd import api, sharding, weights as W
     from dlimgedit_amd.sam_config import get_config
@@ -129,11 +137,14 @@ def main() -> None:
     # ---- inputs resident in HBM before the timed region
     imgs = [synthetic_image(rank * B + i) for i in range(B)]
     img_ptrs, mask_ptrs = [], []
-    for im in imgs:
+    # N > 1: the masks live in ONE torch tensor per rank, so the RCCL gather below reads them where the kernels wrote them
+    # (no host round trip); N = 1 keeps torch off the data path altogether
+    local_masks = torch.zeros((B, 1024, 1024), dtype=torch.uint8, device="cuda") if world > 1 else None
+    for i, im in enumerate(imgs):
         p = ext.device_alloc(env, im.nbytes)
         ext.copy_to_device(env, p, im)
         img_ptrs.append(p)
-        mask_ptrs.append(ext.device_alloc(env, 1024 * 1024))
+        mask_ptrs.append(local_masks[i].data_ptr() if world > 1 else ext.device_alloc(env, 1024 * 1024))
     views = ext.device_views(img_ptrs, 1024, 1024)
     points = [api.Point(512, 512)] * B
 
@@ -157,7 +168,7 @@ def main() -> None:
             step()
         ext.synchronize(env)
         torch.cuda.synchronize()                 # ... and behind them
-        repeat_s.append(sharding.max_over_ranks(time.perf_counter() - t0, device="cuda"))
+        repeat_s.append(sharding.max_over_ranks(time.perf_counter() - t0, device=coll_dev))
         if world > 1:
             dist.barrier()
     elapsed = float(np.median(repeat_s))
@@ -181,6 +192,7 @@ def main() -> None:
             "data": "synthetic",
             "config": {"workload": f"SAM {args.model} encoder + 1 point prompt, {B} image(s)/GPU/step, 1024x1024 RGBA, "
                                    "inputs and masks resident in HBM", "images_per_gpu_per_step": B, "lanes_per_gpu": ext.lane_count(env),
+                       "requests_coalesced_per_pass": int(os.environ.get("DLIMGEDIT_COALESCE", "2")),
                        "weights": "seeded synthetic" if args.model_dir is None else "from --model-dir"},
             "repeats": len(repeat_s),
             "timed_total_s": float(sum(repeat_s)),
@@ -190,57 +202,73 @@ def main() -> None:
 
     # ---- N > 1: the ranks that really take part, and the optional gather of the masks (after the timed region)
     if world > 1:
-        ranks = sharding.count_ranks(device="cuda")
-        local_masks = torch.empty((B, 1024, 1024), dtype=torch.uint8, device="cuda")
-        for i, mp in enumerate(mask_ptrs):
-            host = np.empty((1024, 1024), np.uint8)
-            ext.copy_to_host(env, host, mp)
-            local_masks[i] = torch.from_numpy(host).cuda()
+        ranks = sharding.count_ranks(device=coll_dev)
+        ext.synchronize(env)                     # the masks of the last timed step are in local_masks (device memory)
+        torch.cuda.synchronize()
+        foreground = float((local_masks > 0).float().mean().item())
+        src = local_masks.cpu() if args.rehearse_gloo else local_masks
+        sharding.gather_device_masks(src, world * B)                     # first call: communicator set-up, not timed
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
-        gathered = sharding.gather_device_masks(local_masks, world * B)
+        gathered = sharding.gather_device_masks(src, world * B)
         torch.cuda.synchronize()
-        t_gather = sharding.max_over_ranks(time.perf_counter() - t0, device="cuda")
-        ok = bool(torch.equal(gathered[rank::world][:B], local_masks))     # item i = b * world + rank
+        t_gather = sharding.max_over_ranks(time.perf_counter() - t0, device=coll_dev)
+        ok = bool(torch.equal(gathered[rank::world][:B], src))             # item i = b * world + rank
         if rank == 0:
-            result["rccl"] = {"rccl_ranks": ranks, "gather": {"masks": int(gathered.shape[0]), "bytes": int(gathered.numel()),
-                                                              "ms": 1e3 * t_gather, "own_share_intact": ok,
-                                                              "note": "all_gather_into_tensor of the u8 masks, outside the timed region"}}
+            result["rccl"] = {"rccl_ranks": ranks, "backend": "gloo (one-GPU REHEARSAL, not a result)" if args.rehearse_gloo else "nccl (RCCL)",
+                              "gather": {"masks": int(gathered.shape[0]), "bytes": int(gathered.numel()), "ms": 1e3 * t_gather,
+                                         "gbs": gathered.numel() / t_gather / 1e9, "own_share_intact": ok,
+                                         "own_share_foreground": foreground,
+                                         "note": "RCCL all_gather_into_tensor straight from the device buffers the post-processing "
+                                                 "kernel wrote (no host copy), outside the timed region: no collective is on "
+                                                 "the data path"}}
     elif rank == 0:
         result["rccl"] = {"rccl_ranks": 1, "gather": None}
 
-    # ---- profiled repeat of the same steps: HIP events around every launch on the executor's stream
+    # ---- profiled repeats of the same steps: HIP events attached to every GEMM dispatch, on the stream it is launched on.
+    # First in the regime `value` is measured in (all lanes, requests coalesced as in the timed region), then with every
+    # request on lane 0 (each kernel alone on the chip).
     if rank == 0:
-        ext.set_profiling(env, True)
-        ext.take_stage_stats(env)
-        for _ in range(args.steps):
-            step()
-        ext.synchronize(env)
-        st = ext.take_stage_stats(env)
-        ext.set_profiling(env, False)
-        g = st["gemm"]
-        achieved = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
-        # HBM-side bytes per GEMM launch come from a separate rocprofv3 --pmc run of this same command
-        # (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); null if not collected
-        traffic, traffic_note = None, None
-        tfile = ROOT / "profiles" / "r02_hbm_traffic_pmc.json"
-        if tfile.exists() and args.model == "vit_b" and B == 1:
-            t = json.loads(tfile.read_text())["per_kernel"].get("gemm_pp")
-            if t:
-                traffic = t["fetch_bytes_per_launch_corrected_x2"] + t["write_bytes_per_launch"]
-                traffic_note = ("bytes per launch of the ping-pong GEMM kernels (49 of the 51 launches) from "
-                                "profiles/r02_hbm_traffic_pmc.json (separate --pmc passes)")
+        def profiled(mode):
+            ext.set_profiling(env, mode)
+            ext.take_stage_stats(env)
+            for _ in range(args.steps):
+                step()
+            ext.synchronize(env)
+            stats = ext.take_stage_stats(env)
+            ext.set_profiling(env, 0)
+            return stats
+
+        st_lanes = profiled(2)
+        st = profiled(1)
+        g, gl = st["gemm"], st_lanes["gemm"]
+        achieved = gl["work"] / (gl["ms"] * 1e-3) / 1e12 if gl["ms"] > 0 else 0.0
+        achieved_alone = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        # HBM-side bytes per GEMM launch are NOT measured in this run: they come from separate rocprofv3 --pmc passes of
+        # this command (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE), kept under profiles/
+        traffic_static = None
+        for tfile in (ROOT / "profiles" / "r03_hbm_traffic_pmc.json", ROOT / "profiles" / "r02_hbm_traffic_pmc.json"):
+            if tfile.exists() and args.model == "vit_b" and B == 1:
+                t = json.loads(tfile.read_text())["per_kernel"].get("gemm_pp")
+                if t:
+                    traffic_static = {"value": t["fetch_bytes_per_launch_corrected_x2"] + t["write_bytes_per_launch"],
+                                      "source": f"profiles/{tfile.name} (static: separate --pmc passes, not measured in this run)"}
+                    break
         step_flops = B * (cfg.encoder_flops() + decoder_flops)
         chip_tflops = step_flops / (result["ms_per_step"] * 1e-3) / 1e12          # per GPU (every rank runs the same step)
         result["roofline"] = {
-            "kernel": "gemm_pp_kernel / gemm_pp128_kernel (qkv, fc1 / patch, proj, fc2: 49 launches per image) + gemm_f16_kernel "
-                      "(neck, decoder image side): every MFMA GEMM launch of a step",
+            "kernel": "every MFMA GEMM launch of a step: gemm_pp_kernel / gemm_pp128_kernel (qkv, fc1, patch, proj, fc2) + "
+                      "gemm_f16_kernel (neck, decoder image side)",
             "bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
-            "launches": g["launches"], "avg_launch_us": 1e3 * g["ms"] / max(1, g["launches"]),
-            "flops_per_launch": g["work"] / max(1, g["launches"]),
-            "clock": "HIP events attached to each GEMM dispatch (hipExtLaunchKernelGGL): the kernel's own execution time",
+            "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": None, "traffic_static": traffic_static,
+            "mode": "all lanes, as the timed region: a GEMM shares the chip with the other lanes' kernels while it is clocked",
+            "launches": gl["launches"], "avg_launch_us": 1e3 * gl["ms"] / max(1, gl["launches"]),
+            "flops_per_launch": gl["work"] / max(1, gl["launches"]),
+            "achieved_single_lane": achieved_alone, "frac_single_lane": achieved_alone / MFMA_F16_PEAK_TFLOPS,
+            "avg_launch_us_single_lane": 1e3 * g["ms"] / max(1, g["launches"]),
+            "clock": "HIP events attached to each GEMM dispatch (hipExtLaunchKernelGGL) on the lane's own stream: the kernel's "
+                     "own execution time",
             "chip_achieved": chip_tflops, "chip_frac": chip_tflops / MFMA_F16_PEAK_TFLOPS,
             "chip_note": "per GPU: (encoder + decoder FLOPs of a step) / ms_per_step / peak -- all lanes, every kernel, gaps included",
         }
@@ -257,11 +285,11 @@ def main() -> None:
                 e["frac_hbm_peak"] = e["gbs"] / HBM_PEAK_GBS
             stages[name] = e
         result["stages"] = stages
-        result["profile_mode"] = ("single lane, serial: a repeat of the timed steps with every request on lane 0, so each "
-                                  "kernel runs alone on the chip; GEMM launches are clocked by events attached to the "
+        result["profile_mode"] = ("`stages`: single lane, serial -- a repeat of the timed steps with every request on lane 0, so "
+                                  "each kernel runs alone on the chip; GEMM launches are clocked by events attached to the "
                                   "dispatch, the other stages by hipEventRecord pairs around the launch (which adds a few "
                                   "microseconds per launch).  The stage times therefore do not add up to ms_per_step, "
-                                  "which overlaps the lanes.")
+                                  "which overlaps the lanes.  `roofline.frac` is taken in a second repeat with all lanes.")
         enc_ms = sum(v["ms_per_step"] for k, v in stages.items() if k not in ("decoder", "post", "pre"))
         result["encoder"] = {"gflop_per_image": cfg.encoder_flops() / 1e9, "event_ms_per_step": enc_ms,
                              "tflops": B * cfg.encoder_flops() / (enc_ms * 1e-3) / 1e12 if enc_ms > 0 else 0.0,
@@ -392,7 +420,7 @@ def main() -> None:
 
     if rank == 0:
         print(json.dumps(result))
-    for p in img_ptrs + mask_ptrs:
+    for p in img_ptrs + (mask_ptrs if world == 1 else []):
         ext.device_free(env, p)
     env.close()
     if world > 1:

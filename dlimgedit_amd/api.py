@@ -12,6 +12,7 @@ fallback implementation in Python.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import enum
 from dataclasses import dataclass
 from pathlib import Path
@@ -20,6 +21,9 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libdlimgedit.so"
+# tools/ only: the -DDLIMG_TUNING build with ablated kernel variants and in-kernel stamps (python -m dlimgedit_amd.build --tuning)
+if os.environ.get("DLIMGEDIT_TUNING_LIB") == "1":
+    LIB_PATH = LIB_PATH.with_name("libdlimgedit_tuning.so")
 
 
 class Error(RuntimeError):
@@ -373,6 +377,8 @@ class ext:
                 "dlimg_amd_lane_count": ([vp], ci),
                 "dlimg_amd_replica_count": ([vp], ci),
                 "dlimg_amd_segmentation_device": ([vp, C.POINTER(ci), C.POINTER(ci)], ci),
+                "dlimg_amd_get_segmentation_masks_device": ([C.POINTER(vp), ci, C.POINTER(ci), C.POINTER(ci), ci, vp,
+                                                             C.POINTER(C.c_size_t)], ci),
                 "dlimg_amd_set_profiling": ([vp, ci], ci),
                 "dlimg_amd_take_stage_stats": ([vp, vp, vp, vp], ci),
                 "dlimg_amd_test_preprocess": ([vp, ci, ci, ci, ci, vp], ci),
@@ -398,7 +404,7 @@ class ext:
     EXPORTS = ("dlimg_amd_device_count", "dlimg_amd_model_geometry", "dlimg_amd_get_embedding", "dlimg_amd_get_logits",
                "dlimg_amd_device_alloc", "dlimg_amd_device_free", "dlimg_amd_copy_to_device", "dlimg_amd_copy_to_host",
                "dlimg_amd_encode_and_mask", "dlimg_amd_encode_only", "dlimg_amd_synchronize", "dlimg_amd_lane_count",
-               "dlimg_amd_replica_count", "dlimg_amd_segmentation_device",
+               "dlimg_amd_replica_count", "dlimg_amd_segmentation_device", "dlimg_amd_get_segmentation_masks_device",
                "dlimg_amd_set_profiling",
                "dlimg_amd_take_stage_stats", "dlimg_amd_test_preprocess", "dlimg_amd_test_postprocess",
                "dlimg_amd_test_gemm", "dlimg_amd_test_gemm_ln", "dlimg_amd_test_layernorm", "dlimg_amd_test_attention", "dlimg_amd_test_resize",
@@ -489,6 +495,22 @@ class ext:
         r, d = C.c_int(), C.c_int()
         _check(cls._l().dlimg_amd_segmentation_device(seg._handle, C.byref(r), C.byref(d)))
         return r.value, d.value
+
+    @classmethod
+    def compute_mask_batch_device(cls, segs, dev_out: int, points=None, regions=None, root_device: int = 0) -> list:
+        """Device-output form of Segmentation.compute_mask_batch: masks land tightly packed at `dev_out` (a device pointer
+        on HIP device `root_device`), wherever their embeddings live; returns the byte offset of every mask."""
+        n = len(segs)
+        handles = (C.c_void_p * n)(*[s._handle for s in segs])
+        p = r = None
+        if points is not None:
+            p = (C.c_int * (2 * n))(*[v for q in points for v in (q.x, q.y)])
+        if regions is not None:
+            r = (C.c_int * (4 * n))(*[v for q in regions for v in (q.top_left.x, q.top_left.y, q.bottom_right.x,
+                                                                  q.bottom_right.y)])
+        offsets = (C.c_size_t * n)()
+        _check(cls._l().dlimg_amd_get_segmentation_masks_device(handles, n, p, r, root_device, dev_out, offsets))
+        return list(offsets)
 
     @classmethod
     def set_profiling(cls, env, on: bool) -> None:

@@ -2,6 +2,10 @@
 
 In-tree, no cmake: `python -m dlimgedit_amd.build`.  hipcc cross-compiles without a GPU, so this also
 runs in the CPU-only build container.  Objects are cached by source mtime under csrc/_obj/.
+
+`--tuning` builds a SECOND library, lib/libdlimgedit_tuning.so, with -DDLIMG_TUNING: it additionally holds the ablated
+kernel variants and in-kernel cycle stamps the scripts under tools/ use (DLIMGEDIT_*_ABLATE, GemmArgs::stamps).  The
+product library never contains them; tools select the tuning library with DLIMGEDIT_TUNING_LIB=1.
 """
 from __future__ import annotations
 
@@ -16,7 +20,9 @@ PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 CSRC = PKG / "csrc"
 OBJ = CSRC / "_obj"
+OBJ_TUNING = CSRC / "_obj_tuning"
 LIB = PKG / "lib" / "libdlimgedit.so"
+LIB_TUNING = PKG / "lib" / "libdlimgedit_tuning.so"
 ARCH = "gfx950"
 SONAME = "libdlimgedit.so.1"
 
@@ -67,14 +73,15 @@ def _deps_mtime() -> float:
     return max(p.stat().st_mtime for p in hdrs)
 
 
-def _compile(src: str, force: bool, hdr_mtime: float) -> Path:
+def _compile(src: str, force: bool, hdr_mtime: float, tuning: bool = False) -> Path:
     s = CSRC / src
     if not s.exists():
         raise FileNotFoundError(s)
-    o = OBJ / (src.replace("/", "_") + ".o")
+    o = (OBJ_TUNING if tuning else OBJ) / (src.replace("/", "_") + ".o")
     if not force and o.exists() and o.stat().st_mtime > max(s.stat().st_mtime, hdr_mtime):
         return o
-    cmd = [hipcc(), *_flags(), *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c", str(s), "-o", str(o)]
+    cmd = [hipcc(), *_flags(), *(["-DDLIMG_TUNING"] if tuning else []), *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c",
+           str(s), "-o", str(o)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -83,13 +90,23 @@ def _compile(src: str, force: bool, hdr_mtime: float) -> Path:
     return o
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
-    OBJ.mkdir(parents=True, exist_ok=True)
+def build(force: bool = False, verbose: bool = False, tuning: bool = False) -> Path:
+    (OBJ_TUNING if tuning else OBJ).mkdir(parents=True, exist_ok=True)
     LIB.parent.mkdir(parents=True, exist_ok=True)
     hdr = _deps_mtime()
     workers = min(6, os.cpu_count() or 1)
     with ThreadPoolExecutor(workers) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force, hdr), SOURCES))
+        objs = list(ex.map(lambda s: _compile(s, force, hdr, tuning), SOURCES))
+    if tuning:
+        if force or not LIB_TUNING.exists() or LIB_TUNING.stat().st_mtime < max(o.stat().st_mtime for o in objs):
+            cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB_TUNING), *map(str, objs),
+                   "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined", "-ldl", "-lz"]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print(f"built {LIB_TUNING} ({LIB_TUNING.stat().st_size / 1e6:.1f} MB)")
+        return LIB_TUNING
     if force or not LIB.exists() or LIB.stat().st_mtime < max(o.stat().st_mtime for o in objs):
         cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs),
                "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined", f"-Wl,-soname,{SONAME}", "-ldl", "-lz"]
@@ -107,4 +124,4 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
+    build(force="--force" in sys.argv, verbose=True, tuning="--tuning" in sys.argv)

@@ -81,6 +81,10 @@ EnvironmentImpl::EnvironmentImpl(dlimg_Options const& options) : backend(options
     // those of the shared-GPU configuration): a kernel trace taken this way shows each kernel alone on the chip, which
     // is what bench.py's per-kernel clocks measure
     if (const char* e = std::getenv("DLIMGEDIT_SINGLE_LANE")) forced_single_lane_ = std::atoi(e) != 0;
+    if (const char* e = std::getenv("DLIMGEDIT_COALESCE")) {
+        const int v = std::atoi(e);
+        coalesce = v < 1 ? 1 : (v > 8 ? 8 : v);
+    }
     single_lane_.store(forced_single_lane_);
     for (int d : devices) {
         if (d < 0 || d >= device_count())

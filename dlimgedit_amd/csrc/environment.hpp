@@ -74,6 +74,16 @@ class EnvironmentImpl {
     // While set, every request goes to lane 0 of its replica (per-kernel clocks must not see other lanes' kernels).
     void set_single_lane(bool on) { single_lane_.store(on || forced_single_lane_); }
 
+    // Asynchronous steps of the device-resident entry point (dlimg_amd_encode_and_mask) that have been accepted but not
+    // launched yet: independent single-image requests are coalesced into ONE batched pass of `coalesce` images (dynamic
+    // batching, as a serving host would do): with two images per pass the N = 768 GEMMs (patch, proj, fc2) reach 96
+    // tiles of the 256 x 256 kernel instead of 96 of the 128 x 256 one.  Results are bit-identical to single-image
+    // passes (kernels/gemm.hip, tile choice).  DLIMGEDIT_COALESCE = 1 switches it off; dlimg_amd_synchronize flushes.
+    struct PendingStep { dlimg_ImageView view; int x, y; uint8_t* mask; };
+    std::mutex pending_mutex;
+    std::vector<PendingStep> pending;
+    int coalesce = 2;
+
   private:
     struct SamLanes {
         SamLanes(std::string const& weight_path, int device, int count);

@@ -177,61 +177,139 @@ DLIMG_API int dlimg_amd_encode_only(dlimg_Environment env, dlimg_ImageView const
     });
 }
 
+namespace dlimg {
+namespace {
+
+// One batched pass of the device-resident hot path over `steps` on the next lane: pre-process, encode, decode one point
+// prompt per image (single-mask mode), masks to the callers' device buffers.  Enqueues only.
+void run_device_steps(EnvironmentImpl& env, EnvironmentImpl::PendingStep const* steps, int count) {
+    SamModel& m = env.next_lane(0);
+    std::lock_guard<std::mutex> lock(m.mutex());
+    HIP_CHECK(hipSetDevice(m.device()));
+    std::vector<dlimg_ImageView> views(count);
+    for (int i = 0; i < count; ++i) views[i] = steps[i].view;
+    encode_device_images(m, views.data(), count);
+    std::vector<float> coords((size_t)count * 4), labels((size_t)count * 2);
+    std::vector<float const*> emb(count);
+    std::vector<ResizeLongestSide> rs(count);
+    for (int i = 0; i < count; ++i) {
+        rs[i].set(Extent{views[i].width, views[i].height});
+        Point p{steps[i].x, steps[i].y};
+        pack_prompt(rs[i], &p, nullptr, &coords[i * 4], &labels[i * 2]);
+        emb[i] = m.embeddings() + (size_t)i * kTokens * kEmbedDim;
+    }
+    m.decode(emb.data(), coords.data(), labels.data(), count);
+    std::vector<k::PostJob> jobs(count);
+    for (int i = 0; i < count; ++i)
+        jobs[i] = k::PostJob{m.logits() + (size_t)i * 4 * kLowRes * kLowRes, m.iou() + (size_t)i * 4, steps[i].mask,
+                             rs[i].original.width, rs[i].original.height, rs[i].resized.width, rs[i].resized.height};
+    m.masks_on_device(jobs.data(), count);
+}
+
+// Launches what is waiting: passes of `width` images while at least that many wait; everything with `all`.
+// pending_mutex held by the caller.
+void flush_device_steps(EnvironmentImpl& env, bool all) {
+    const size_t width = (size_t)std::max(1, env.coalesce);
+    size_t done = 0;
+    try {
+        while (env.pending.size() - done >= width || (all && done < env.pending.size())) {
+            const size_t n = std::min(width, env.pending.size() - done);
+            run_device_steps(env, env.pending.data() + done, (int)n);
+            done += n;
+        }
+    } catch (...) {
+        env.pending.clear();         // a failed pass must not be retried by the next call
+        throw;
+    }
+    env.pending.erase(env.pending.begin(), env.pending.begin() + done);
+}
+
+}  // namespace
+}  // namespace dlimg
+
 DLIMG_API int dlimg_amd_encode_and_mask(dlimg_Environment env, dlimg_ImageView const* dev_images, int count,
                                         int const* points, uint8_t* const* dev_masks) {
     return guarded([&] {
         DLIMG_ASSERT(dev_images != nullptr && points != nullptr && dev_masks != nullptr && count > 0);
-        SamModel& m = impl(env).next_lane(0);
-        std::lock_guard<std::mutex> lock(m.mutex());
-        HIP_CHECK(hipSetDevice(m.device()));
-        encode_device_images(m, dev_images, count);
-        std::vector<float> coords((size_t)count * 4), labels((size_t)count * 2);
-        std::vector<float const*> emb(count);
-        std::vector<ResizeLongestSide> rs(count);
+        EnvironmentImpl& e = impl(env);
         for (int i = 0; i < count; ++i) {
-            rs[i].set(Extent{dev_images[i].width, dev_images[i].height});
-            Point p{points[i * 2], points[i * 2 + 1]};
-            pack_prompt(rs[i], &p, nullptr, &coords[i * 4], &labels[i * 2]);
-            emb[i] = m.embeddings() + (size_t)i * kTokens * kEmbedDim;
-        }
-        m.decode(emb.data(), coords.data(), labels.data(), count);
-        std::vector<k::PostJob> jobs(count);
-        for (int i = 0; i < count; ++i) {
+            check_image(dev_images[i]);
             DLIMG_ASSERT(dev_masks[i] != nullptr);
-            jobs[i] = k::PostJob{m.logits() + (size_t)i * 4 * kLowRes * kLowRes, m.iou() + (size_t)i * 4, dev_masks[i],
-                                 rs[i].original.width, rs[i].original.height, rs[i].resized.width, rs[i].resized.height};
+            if (std::max(dev_images[i].width, dev_images[i].height) != kImageSize)
+                throw Exception("device-resident images must have their longest side at 1024 pixels");
         }
-        m.masks_on_device(jobs.data(), count);
+        std::lock_guard<std::mutex> lock(e.pending_mutex);
+        if (count >= e.coalesce) {
+            // a call that is a batch already runs as it is (behind whatever single requests were waiting)
+            flush_device_steps(e, true);
+            std::vector<EnvironmentImpl::PendingStep> steps(count);
+            for (int i = 0; i < count; ++i)
+                steps[i] = EnvironmentImpl::PendingStep{dev_images[i], points[i * 2], points[i * 2 + 1], dev_masks[i]};
+            run_device_steps(e, steps.data(), count);
+            return;
+        }
+        for (int i = 0; i < count; ++i)
+            e.pending.push_back(EnvironmentImpl::PendingStep{dev_images[i], points[i * 2], points[i * 2 + 1], dev_masks[i]});
+        flush_device_steps(e, false);
+    });
+}
+
+DLIMG_API int dlimg_amd_get_segmentation_masks_device(dlimg_Segmentation const* segs, int count, int const* points,
+                                                      int const* regions, int root_device, uint8_t* dev_out,
+                                                      size_t* out_offsets) {
+    return guarded([&] {
+        DLIMG_ASSERT(segs != nullptr && count >= 0);
+        std::vector<SegmentationImpl const*> s(count);
+        for (int i = 0; i < count; ++i) {
+            DLIMG_ASSERT(segs[i] != nullptr);
+            s[i] = &impl(segs[i]);
+        }
+        SegmentationImpl::compute_mask_batch_device(s.data(), count, points, regions, root_device, dev_out, out_offsets);
     });
 }
 
 DLIMG_API int dlimg_amd_synchronize(dlimg_Environment env) {
-    return guarded([&] { for_each_lane(impl(env), [](SamModel& m) { m.synchronize(); }); });
+    return guarded([&] {
+        EnvironmentImpl& e = impl(env);
+        {
+            std::lock_guard<std::mutex> lock(e.pending_mutex);
+            flush_device_steps(e, true);
+        }
+        for_each_lane(e, [](SamModel& m) { m.synchronize(); });
+    });
 }
 
 DLIMG_API int dlimg_amd_set_profiling(dlimg_Environment env, int enabled) {
     return guarded([&] {
         EnvironmentImpl& e = impl(env);
-        // drain everything, then pin requests to lane 0 while the clocks run
+        {
+            std::lock_guard<std::mutex> lock(e.pending_mutex);
+            flush_device_steps(e, true);
+        }
+        // drain everything; mode 1 pins requests to lane 0 while the clocks run (every kernel alone on the chip),
+        // mode 2 leaves the lanes as they are (the regime the throughput figure is measured in)
         for_each_lane(e, [](SamModel& m) { m.synchronize(); });
-        e.set_single_lane(enabled != 0);
-        SamModel& m = e.lane(0, 0);
-        std::lock_guard<std::mutex> lock(m.mutex());
-        m.set_profiling(enabled != 0);
+        e.set_single_lane(enabled == 1);
+        for_each_lane(e, [&](SamModel& m) { m.set_profiling(enabled == 2 || (enabled == 1 && &m == &e.lane(0, 0))); });
     });
 }
 
 DLIMG_API int dlimg_amd_take_stage_stats(dlimg_Environment env, double* out_ms, double* out_work, long* out_launches) {
     static_assert(ST_COUNT == DLIMG_AMD_STAGE_COUNT, "stage table out of sync with the public header");
     return guarded([&] {
-        SamModel& m = impl(env).lane(0, 0);
-        std::lock_guard<std::mutex> lock(m.mutex());
-        HIP_CHECK(hipSetDevice(m.device()));
-        StageStats s = m.take_stats();
+        StageStats total;
+        for_each_lane(impl(env), [&](SamModel& m) {
+            StageStats s = m.take_stats();
+            for (int i = 0; i < ST_COUNT; ++i) {
+                total.ms[i] += s.ms[i];
+                total.work[i] += s.work[i];
+                total.launches[i] += s.launches[i];
+            }
+        });
         for (int i = 0; i < ST_COUNT; ++i) {
-            if (out_ms) out_ms[i] = s.ms[i];
-            if (out_work) out_work[i] = s.work[i];
-            if (out_launches) out_launches[i] = s.launches[i];
+            if (out_ms) out_ms[i] = total.ms[i];
+            if (out_work) out_work[i] = total.work[i];
+            if (out_launches) out_launches[i] = total.launches[i];
         }
     });
 }
@@ -379,17 +457,27 @@ DLIMG_API int dlimg_amd_test_attention(int global, uint16_t const* qkv, float co
         Upload<float> dh(rel_h, (size_t)(2 * span - 1) * hd), dw(rel_w, (size_t)(2 * span - 1) * hd);
         DeviceBuffer<half_t> o(rows * D);
         HIP_CHECK(hipMemset(o.get(), 0, rows * D * sizeof(half_t)));
+        HIP_CHECK(hipDeviceSynchronize());
+        // a stream of the calling thread's own (not the process-wide null stream): calls from several host threads then
+        // overlap on the GPU as the execution lanes' kernels do (tests/test_gpu_concurrency.py stress test)
+        struct OwnStream {
+            hipStream_t s = nullptr;
+            ~OwnStream() { if (s) (void)hipStreamDestroy(s); }
+        };
+        thread_local OwnStream own;
+        if (!own.s) HIP_CHECK(hipStreamCreateWithFlags(&own.s, hipStreamNonBlocking));
         if (global) {
             const size_t n = (size_t)(2 * span - 1) * hd;
             DeviceBuffer<half_t> dh16(n), dw16(n);
-            k::cast_f16(dh.get(), dh16.get(), n, nullptr);
-            k::cast_f16(dw.get(), dw16.get(), n, nullptr);
-            k::attention_global(dq.get(), dh16.get(), dw16.get(), o.get(), batch, heads, hd, nullptr);
+            k::cast_f16(dh.get(), dh16.get(), n, own.s);
+            k::cast_f16(dw.get(), dw16.get(), n, own.s);
+            k::attention_global(dq.get(), dh16.get(), dw16.get(), o.get(), batch, heads, hd, own.s);
+            HIP_CHECK(hipStreamSynchronize(own.s));      // dh16 / dw16 go out of scope below
         } else {
             DLIMG_ASSERT(qkv_bias != nullptr);
-            k::attention_window(dq.get(), db.get(), dh.get(), dw.get(), o.get(), batch, heads, hd, nullptr);
+            k::attention_window(dq.get(), db.get(), dh.get(), dw.get(), o.get(), batch, heads, hd, own.s);
         }
-        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipStreamSynchronize(own.s));
         download(reinterpret_cast<half_t*>(out), o.get(), rows * D);
     });
 }
@@ -526,6 +614,10 @@ DLIMG_API int dlimg_amd_bench_gemm_stamps(int M, int N, int K, int act, int flav
         // `streams` concurrent copies of the problem (own outputs, shared operands), launched round-robin: the regime
         // of the execution lanes, where kernels of different images share the chip
         DeviceBuffer<unsigned long long> stamps;
+#ifndef DLIMG_TUNING
+        if (out_stamps && max_groups > 0)
+            throw Exception("in-kernel stamps exist only in the tuning build (python -m dlimgedit_amd.build --tuning, DLIMGEDIT_TUNING_LIB=1)");
+#endif
         if (out_stamps && max_groups > 0) {
             stamps.reserve((size_t)max_groups * 4);
             HIP_CHECK(hipMemset(stamps.get(), 0, (size_t)max_groups * 4 * sizeof(unsigned long long)));

@@ -199,6 +199,12 @@ uint8_t* load_image_file(char const* filepath, int* out_extent, int* out_channel
         ph[p] = interlace ? (h - ys[p] + dy[p] - 1) / dy[p] : h;
         if (pw[p] && ph[p]) expect += (row_bytes(pw[p]) + 1) * ph[p];
     }
+    // stb_image refuses images whose byte counts do not fit an int (stbi__mad3sizes_valid); and deflate cannot expand
+    // by more than 1032:1, so a header that promises more than its IDAT can hold is refused BEFORE anything of that
+    // size is allocated and zero-filled (a 100-byte file must not cost gigabytes)
+    constexpr size_t kIntMax = 0x7fffffff;
+    if ((size_t)w * h > kIntMax / (size_t)out_ch || expect > kIntMax) throw fail("too large");
+    if (expect > idat.size() * 1032 + 1024) throw fail("bad zlib data");
     std::vector<uint8_t> raw(expect);
     uLongf got = uLongf(expect);
     const int zr = uncompress(raw.data(), &got, idat.data(), uLong(idat.size()));

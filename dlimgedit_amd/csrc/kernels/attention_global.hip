@@ -687,37 +687,39 @@ void launch_global(const half_t* qkv, const half_t* rel_h, const half_t* rel_w, 
     const size_t tiles = 2 * ((size_t)KT * (HD + 8) + (size_t)KT * V_STRIDE) * 2;
     const size_t scratch = 4 * 32 * GW_STRIDE * 4;
     const size_t lds = 4 * 64 * RELH_STRIDE * 4 + (tiles > scratch ? tiles : scratch);
-    static std::once_flag attr_once;       // one flag per template instance; lanes launch concurrently
-    std::call_once(attr_once, [] {
-        (void)hipFuncSetAttribute((const void*)attention_global_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-    });
-    static const int ablate = [] { const char* e = std::getenv("DLIMGEDIT_ATTN_ABLATE"); return e ? std::atoi(e) : 0; }();
+    const size_t pp_lds = 8 * 64 * RELH_STRIDE * 4 + tiles;
     static const bool pingpong = [] { const char* e = std::getenv("DLIMGEDIT_ATTN_PP"); return !e || std::atoi(e) != 0; }();
-    if (pingpong && !ablate) {
-        const size_t pp_tiles = 2 * ((size_t)KT * (HD + 8) + (size_t)KT * V_STRIDE) * 2;
-        const size_t pp_lds = 8 * 64 * RELH_STRIDE * 4 + pp_tiles;
-        static std::once_flag once;
-        std::call_once(once, [&] {
-            (void)hipFuncSetAttribute((const void*)attention_global_pp_kernel<HD, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)pp_lds);
-        });
-        static const int pp_abl = [] { const char* e = std::getenv("DLIMGEDIT_ATTN_PP_ABLATE"); return e ? std::atoi(e) : 0; }();
-        auto ppk = attention_global_pp_kernel<HD, 0>;
-        if (HD == 64 && pp_abl == 1) ppk = attention_global_pp_kernel<HD, 1>;
-        if (HD == 64 && pp_abl == 2) ppk = attention_global_pp_kernel<HD, 2>;
-        if (HD == 64 && pp_abl == 3) ppk = attention_global_pp_kernel<HD, 3>;
-        if (HD == 64 && pp_abl == 4) ppk = attention_global_pp_kernel<HD, 4>;
-        if (pp_abl) (void)hipFuncSetAttribute((const void*)ppk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp_lds);
+#ifdef DLIMG_TUNING     // tuning build only (python -m dlimgedit_amd.build --tuning): ablated variants with WRONG results
+    static const int ablate = [] { const char* e = std::getenv("DLIMGEDIT_ATTN_ABLATE"); return e ? std::atoi(e) : 0; }();
+    static const int pp_abl = [] { const char* e = std::getenv("DLIMGEDIT_ATTN_PP_ABLATE"); return e ? std::atoi(e) : 0; }();
+    if (HD == 64 && pingpong && !ablate && pp_abl >= 1 && pp_abl <= 4) {
+        auto ppk = pp_abl == 1 ? attention_global_pp_kernel<HD, 1> : pp_abl == 2 ? attention_global_pp_kernel<HD, 2>
+                   : pp_abl == 3 ? attention_global_pp_kernel<HD, 3> : attention_global_pp_kernel<HD, 4>;
+        static k::LdsOptIn once[5];
+        once[pp_abl].ensure((const void*)ppk, pp_lds, "attention_global: the device refuses the kernel's LDS size");
         hipLaunchKernelGGL(ppk, dim3(B * heads * (TOKENS / 256)), dim3(512), pp_lds, s, qkv, rel_h, rel_w, out, heads);
         return;
     }
-    auto kern = attention_global_kernel<HD, 0>;
-    if (HD == 64 && ablate == 1) kern = attention_global_kernel<HD, 1>;
-    if (HD == 64 && ablate == 2) kern = attention_global_kernel<HD, 2>;
-    if (HD == 64 && ablate == 3) kern = attention_global_kernel<HD, 3>;
-    if (ablate) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(B * heads * (TOKENS / 128)), dim3(256), lds, s, qkv, rel_h, rel_w, out, heads);
+    if (HD == 64 && ablate >= 1 && ablate <= 3) {
+        auto kern = ablate == 1 ? attention_global_kernel<HD, 1> : ablate == 2 ? attention_global_kernel<HD, 2>
+                                                                                : attention_global_kernel<HD, 3>;
+        static k::LdsOptIn once[4];
+        once[ablate].ensure((const void*)kern, lds, "attention_global: the device refuses the kernel's LDS size");
+        hipLaunchKernelGGL(kern, dim3(B * heads * (TOKENS / 128)), dim3(256), lds, s, qkv, rel_h, rel_w, out, heads);
+        return;
+    }
+#endif
+    if (pingpong) {
+        static k::LdsOptIn once;       // one per template instance; state per device (lanes and replicas launch concurrently)
+        once.ensure((const void*)attention_global_pp_kernel<HD, 0>, pp_lds, "attention_global: the device refuses the kernel's LDS size");
+        hipLaunchKernelGGL((attention_global_pp_kernel<HD, 0>), dim3(B * heads * (TOKENS / 256)), dim3(512), pp_lds, s, qkv,
+                           rel_h, rel_w, out, heads);
+        return;
+    }
+    static k::LdsOptIn once4;
+    once4.ensure((const void*)attention_global_kernel<HD, 0>, lds, "attention_global: the device refuses the kernel's LDS size");
+    hipLaunchKernelGGL((attention_global_kernel<HD, 0>), dim3(B * heads * (TOKENS / 128)), dim3(256), lds, s, qkv, rel_h, rel_w,
+                       out, heads);
 }
 
 }  // namespace

@@ -267,11 +267,8 @@ void launch_window(const half_t* qkv, const float* bias, const float* rel_h, con
     const size_t images = (size_t)SLOTS * (HD + 8) * 2 + (size_t)SLOTS * V_STRIDE * 2;
     const size_t scratch = 7 * 32 * G_STRIDE * 4;
     const size_t lds = images > scratch ? images : scratch;
-    static std::once_flag attr_once;       // one flag per template instance; lanes launch concurrently
-    std::call_once(attr_once, [] {
-        (void)hipFuncSetAttribute((const void*)attention_window_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-    });
+    static k::LdsOptIn opt_in;       // one per template instance, state per device; lanes and replicas launch concurrently
+    opt_in.ensure((const void*)attention_window_kernel<HD>, lds, "attention_window: the device refuses the kernel's LDS size");
     hipLaunchKernelGGL(attention_window_kernel<HD>, dim3(B * NW * NW * heads), dim3(448), lds, s, qkv, bias, rel_h,
                        rel_w, out, heads);
 }

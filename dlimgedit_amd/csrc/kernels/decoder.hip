@@ -585,11 +585,9 @@ void token_linears(const TokenLinear* ops, int count, int rows, hipStream_t s) {
     }
     const int slices = (rows + TL_ROW_SLICE - 1) / TL_ROW_SLICE;
     if (count == 1 && ops[0].K > DIM && ops[0].K % 256 == 0 && ops[0].K <= TLD_MAX_K && !ops[0].in.ln_w && !ops[0].in.add) {
-        static std::once_flag once;
-        std::call_once(once, [] {
-            (void)hipFuncSetAttribute((const void*)token_linear_deep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      TL_ROW_SLICE * TLD_MAX_K * 4);
-        });
+        static k::LdsOptIn opt_in;
+        opt_in.ensure((const void*)token_linear_deep_kernel, (size_t)TL_ROW_SLICE * TLD_MAX_K * 4,
+                      "token_linears: the device refuses the kernel's LDS size");
         const size_t lds = (size_t)std::min(rows, TL_ROW_SLICE) * ops[0].K * 4;
         hipLaunchKernelGGL(token_linear_deep_kernel, dim3(ops[0].N / 4, slices), dim3(256), lds, s, ops[0], rows);
         return;
@@ -601,10 +599,8 @@ void token_self_attention_out(const float* q, const float* kx, const float* v, c
     if (P <= 0) return;
     if (P * TOK > TL_MAX_ROWS || out.K != DIM || out.N % 4) throw_error("token_self_attention_out: unsupported shape");
     const size_t lds = (size_t)TL_PROMPT_SLICE * TOK * (DIM * 4 + 8);
-    static std::once_flag once;
-    std::call_once(once, [] {
-        (void)hipFuncSetAttribute((const void*)token_self_attn_out_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
+    static k::LdsOptIn opt_in;
+    opt_in.ensure((const void*)token_self_attn_out_kernel, 160 * 1024, "token_self_attention_out: the device refuses the kernel's LDS size");
     hipLaunchKernelGGL(token_self_attn_out_kernel, dim3(out.N / 4, (P + TL_PROMPT_SLICE - 1) / TL_PROMPT_SLICE), dim3(256), lds, s, q, kx,
                        v, out, P);
 }
@@ -613,10 +609,8 @@ void token_merge_out(const float* scratch, const TokenLinear& out, int P, hipStr
     if (P <= 0) return;
     if (P * TOK > TL_MAX_ROWS || out.K != INNER || out.N % 4) throw_error("token_merge_out: unsupported shape");
     const size_t lds = (size_t)P * TOK * INNER * 4 + (size_t)P * TOK * 8;
-    static std::once_flag once;
-    std::call_once(once, [] {
-        (void)hipFuncSetAttribute((const void*)token_merge_out_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
+    static k::LdsOptIn opt_in;
+    opt_in.ensure((const void*)token_merge_out_kernel, 160 * 1024, "token_merge_out: the device refuses the kernel's LDS size");
     hipLaunchKernelGGL(token_merge_out_kernel, dim3(out.N / 4, (P + TL_PROMPT_SLICE - 1) / TL_PROMPT_SLICE), dim3(256), lds, s, scratch, out,
                        P);
 }

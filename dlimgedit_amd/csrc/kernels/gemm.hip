@@ -34,6 +34,14 @@
 namespace dlimg {
 namespace {
 
+// In-kernel cycle stamps (GemmArgs::stamps) exist in the tuning build only (python -m dlimgedit_amd.build --tuning);
+// the product kernels carry neither the branches nor the s_memtime reads.
+#ifdef DLIMG_TUNING
+#define DLIMG_STAMPS(a) ((a).stamps)
+#else
+#define DLIMG_STAMPS(a) (static_cast<unsigned long long*>(nullptr))
+#endif
+
 constexpr int BK_CHECK = 64;    // K must be a multiple of this for every configuration
 
 // LDS rows hold BKT halves (128 or 64 bytes).  The 16-byte chunk index is XOR-swizzled with row bits so that
@@ -779,8 +787,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(k::GemmArgs a) {
     const char* w_base = smem + (2 + (wc >> 1)) * kPPHalfBytes + (wc & 1) * 64 * 128;  // + buffer + (nh*32 + j*16) * 128
     auto frag = [&](const char* p) { return *reinterpret_cast<const half8_t*>(p); };
 
-    const unsigned long long t_start = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-    const unsigned long long r_start = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long t_start = DLIMG_STAMPS(a) ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long r_start = DLIMG_STAMPS(a) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     ColumnVectors<BM, BN, 512, EPI> column_vectors;
     RowStats<BM, 512, EPI> row_stats;
     column_vectors.issue(a, n0);                 // ordinary loads first: they are the oldest entries of the vm counter
@@ -852,8 +860,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(k::GemmArgs a) {
     };
     using Even = std::integral_constant<int, 0>;
     using Odd = std::integral_constant<int, 1>;
-    const unsigned long long t_loop = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-    const unsigned long long r_loop = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long t_loop = DLIMG_STAMPS(a) ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long r_loop = DLIMG_STAMPS(a) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     int t = 0;
     for (; t + 3 < nk; t += 2) {
         step(t, Even{}, std::true_type{});
@@ -864,13 +872,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(k::GemmArgs a) {
         if (t + 1 < nk) step(t + 1, Odd{}, std::false_type{});
     }
     if (wr == 0) pp_barrier();                   // group 0 waits for group 1's last M segment: barrier counts match
-    const unsigned long long t_loop_end = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-    const unsigned long long r_loop_end = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long t_loop_end = DLIMG_STAMPS(a) ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long r_loop_end = DLIMG_STAMPS(a) ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
     pp_epilogue<8, ACT, EPI>(a, acc, smem, rowstat, colvec, rowpart, m0, n0, wr * 128, wc, wave, lane);
-    if (a.stamps && threadIdx.x == 0) {
+    if (DLIMG_STAMPS(a) && threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the wave's own stores have left
-        unsigned long long* d = a.stamps + (size_t)blockIdx.x * 4;
+        unsigned long long* d = DLIMG_STAMPS(a) + (size_t)blockIdx.x * 4;
         d[0] = t_loop_end - t_loop;
         d[1] = r_loop_end - r_loop;
         d[2] = ((t_loop - t_start) << 32) | ((__builtin_amdgcn_s_memtime() - t_loop_end) & 0xffffffffull);   // prologue | epilogue cycles
@@ -1025,19 +1033,19 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(k::GemmArgs a) {
         pp_barrier();
         buf3 = buf3 == 2 ? 0 : buf3 + 1;
     };
-    const unsigned long long t_loop = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-    const unsigned long long r_loop = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long t_loop = DLIMG_STAMPS(a) ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long r_loop = DLIMG_STAMPS(a) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     int t = 0;
     for (; t + 2 < nk; ++t) step(t, std::true_type{});
     for (; t < nk; ++t) step(t, std::false_type{});
     if (wr == 0) pp_barrier();
-    const unsigned long long t_loop_end = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-    const unsigned long long r_loop_end = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long t_loop_end = DLIMG_STAMPS(a) ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long r_loop_end = DLIMG_STAMPS(a) ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
     pp_epilogue<4, ACT, EPI, PRE>(a, acc, smem, rowstat, colvec, rowpart, m0, n0, wr * 64, wc, wave, lane, PRE ? rpre : nullptr);
-    if (a.stamps && threadIdx.x == 0) {
+    if (DLIMG_STAMPS(a) && threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned long long* d = a.stamps + (size_t)blockIdx.x * 4;
+        unsigned long long* d = DLIMG_STAMPS(a) + (size_t)blockIdx.x * 4;
         d[0] = t_loop_end - t_loop;
         d[1] = r_loop_end - r_loop;
         d[2] = (__builtin_amdgcn_s_memtime() - t_loop_end) & 0xffffffffull;
@@ -1050,17 +1058,12 @@ typedef void (*GemmKernel)(k::GemmArgs);
 // Picks the epilogue flavour the arguments ask for and launches; LDS above the default limit is opted into once.
 struct Timing { hipEvent_t start = nullptr, stop = nullptr; };
 
-void launch_flavour(GemmKernel const (&kernels)[5], std::once_flag (&attr_once)[5], const k::GemmArgs& a, int grid,
+void launch_flavour(GemmKernel const (&kernels)[5], k::LdsOptIn (&opt_in)[5], const k::GemmArgs& a, int grid,
                     int threads, size_t lds, hipStream_t s, Timing t) {
     const int index = a.stats_out ? 4 : (a.ln_stats ? 2 : 0) + (a.act == k::ACT_GELU ? 1 : 0);
-    if (lds > 48 * 1024) {
-        bool refused = false;        // concurrent lanes launch the same kernels: opt in exactly once, under the flag
-        std::call_once(attr_once[index], [&] {
-            refused = hipFuncSetAttribute((const void*)kernels[index], hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)lds) != hipSuccess;
-        });
-        if (refused) throw_error("gemm: the device refuses the LDS size of this tile configuration");
-    }
+    // concurrent lanes (and the replicas of several GPUs) launch the same kernels: per-device state, k::LdsOptIn
+    if (lds > 48 * 1024)
+        opt_in[index].ensure((const void*)kernels[index], lds, "gemm: the device refuses the LDS size of this tile configuration");
     if (t.start && t.stop)
         hipExtLaunchKernelGGL(kernels[index], dim3(grid), dim3(threads), lds, s, t.start, t.stop, 0, a);
     else
@@ -1077,24 +1080,28 @@ void launch16(const k::GemmArgs& a, hipStream_t s, Timing t) {
         gemm16_f16_kernel<BM, BN, WGM, WGN, NSTAGE, MINW, k::ACT_GELU, EPI_NORM>,
         gemm16_f16_kernel<BM, BN, WGM, WGN, NSTAGE, MINW, k::ACT_NONE, EPI_STATS>,
     };
-    static std::once_flag attr_once[5];
+    static k::LdsOptIn attr_once[5];
     launch_flavour(kernels, attr_once, a, (a.M / BM) * (a.N / BN), 64 * WGM * WGN, lds, s, t);
 }
 
 template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE, int MINW>
 void launch(const k::GemmArgs& a, hipStream_t s, Timing t) {
     const size_t lds = (size_t)NSTAGE * (BM + BN) * BKT * 2 + aux_bytes(BM, BN);
+#ifdef DLIMG_TUNING     // tuning build only (python -m dlimgedit_amd.build --tuning): ablated variants with WRONG results
     static const int ablate = [] { const char* e = std::getenv("DLIMGEDIT_GEMM_ABLATE"); return e ? std::atoi(e) : 0; }();
+#endif
     static const GemmKernel kernels[5] = {
+#ifdef DLIMG_TUNING
         ablate == 1   ? gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_NONE, EPI_PLAIN, 1>
-        : ablate == 2 ? gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_NONE, EPI_PLAIN, 2>
-                      : gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_NONE, EPI_PLAIN>,
+        : ablate == 2 ? gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_NONE, EPI_PLAIN, 2> :
+#endif
+        gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_NONE, EPI_PLAIN>,
         gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_GELU, EPI_PLAIN>,
         gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_NONE, EPI_NORM>,
         gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_GELU, EPI_NORM>,
         gemm_f16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, MINW, k::ACT_NONE, EPI_STATS>,
     };
-    static std::once_flag attr_once[5];
+    static k::LdsOptIn attr_once[5];
     launch_flavour(kernels, attr_once, a, (a.M / BM) * (a.N / BN), 64 * WGM * WGN, lds, s, t);
 }
 
@@ -1103,7 +1110,7 @@ void launch_pp(const k::GemmArgs& a, hipStream_t s, Timing t) {
         gemm_pp_kernel<k::ACT_NONE, EPI_PLAIN>, gemm_pp_kernel<k::ACT_GELU, EPI_PLAIN>, gemm_pp_kernel<k::ACT_NONE, EPI_NORM>,
         gemm_pp_kernel<k::ACT_GELU, EPI_NORM>,  gemm_pp_kernel<k::ACT_NONE, EPI_STATS>,
     };
-    static std::once_flag attr_once[5];
+    static k::LdsOptIn attr_once[5];
     launch_flavour(kernels, attr_once, a, (a.M / 256) * (a.N / 256), 512, kPPLds, s, t);
 }
 
@@ -1113,7 +1120,7 @@ void launch_pp128(const k::GemmArgs& a, hipStream_t s, Timing t) {
         gemm_pp128_kernel<k::ACT_NONE, EPI_NORM>,  gemm_pp128_kernel<k::ACT_GELU, EPI_NORM>,
         gemm_pp128_kernel<k::ACT_NONE, EPI_STATS>,
     };
-    static std::once_flag attr_once[5];
+    static k::LdsOptIn attr_once[5];
     launch_flavour(kernels, attr_once, a, (a.M / 128) * (a.N / 256), 512, kPP128Lds, s, t);
 }
 
@@ -1158,6 +1165,9 @@ constexpr TileCfg kTiles[] = {
     {256, 256, 1, 1.60f},   // 9: ping-pong kernel (gemm_pp_kernel): 8 waves in two groups one barrier apart, BK 64
                             //    (4096^3: 1300 TFLOP/s at the 1.4 GHz the chip holds under that load)
     {128, 256, 1, 0.00f},   // 10: 128 x 256 ping-pong kernel (gemm_pp128_kernel), one read slot + one MFMA slot per K tile
+    {128, 256, 2, 0.00f},   // 11: 4 waves 2x2 (64x128 each) on 16x16x32, BK 32, 3 stages, 75 KB LDS: TWO workgroups per CU, so
+                            //     one's prologue / epilogue runs beside the other's main loop (forced only until measured)
+    {256, 128, 2, 0.00f},   // 12: as 11 with 128x64 wave tiles
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -1187,11 +1197,19 @@ int gemm_pick_tile(const GemmArgs& a) {
     if (shared && forced < 0 && unit % 256 == 0 && a.N % 256 == 0 &&
         (unit / 256) * (a.N / 256) >= 64 && !wraps_inside(256))
         return 9;
+    // The same with the rows of a whole BATCHED pass (several images stacked in M): two images give ViT-B's proj / fc2
+    // 96 tiles of 256 x 256.  Tiles 9 and 10 compute the same bits (BN = 256, the same MFMA, K order, epilogue
+    // arithmetic and 64-column statistics groups), so the result does not depend on which one a pass uses -- the
+    // batch-equals-single tests assert it.
+    // (only where a single unit would run tile 10: the other tiles use a different MFMA shape, i.e. another summation order)
     // too few 256 x 256 tiles (ViT-B proj / fc2: 48): the 128 x 256 ping-pong kernel doubles them
     static const bool use_pp128 = [] { const char* e = std::getenv("DLIMGEDIT_GEMM_PP128"); return !e || std::atoi(e) != 0; }();
     if (use_pp128 && shared && forced < 0 && unit % 128 == 0 && a.N % 256 == 0 && (unit / 128) * (a.N / 256) >= 64 &&
-        !wraps_inside(128))
+        !wraps_inside(128)) {
+        static const bool batch_pp = [] { const char* e = std::getenv("DLIMGEDIT_GEMM_BATCH_PP"); return !e || std::atoi(e) != 0; }();
+        if (batch_pp && a.M % 256 == 0 && (a.M / 256) * (a.N / 256) >= 96 && !wraps_inside(256)) return 9;
         return 10;
+    }
     for (int i = 0; i < kNumTiles; ++i) {
         const TileCfg& t = kTiles[i];
         if (unit % t.bm || a.N % t.bn || wraps_inside(t.bm)) continue;
@@ -1235,6 +1253,8 @@ void gemm(const GemmArgs& a, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
     case 8: return launch16<128, 128, 2, 2, 4, 2>(a, s, t);
     case 9: return launch_pp(a, s, t);
     case 10: return launch_pp128(a, s, t);
+    case 11: return launch16<128, 256, 2, 2, 3, 2>(a, s, t);
+    case 12: return launch16<256, 128, 2, 2, 3, 2>(a, s, t);
     default: throw_error("gemm: no tile configuration fits this shape");
     }
 }

@@ -14,6 +14,31 @@ typedef _Float16 half_t;
 
 namespace k {
 
+// Opt-in of one kernel to more than 64 KB of dynamic LDS.  hipFuncAttributeMaxDynamicSharedMemorySize belongs to the
+// function ON THE CURRENT DEVICE, and an environment may hold one replica per GPU (DLIMGEDIT_DEVICES), so the state is
+// kept per device: the first launcher on each GPU sets the attribute, every later one only reads the outcome.  A refused
+// opt-in is remembered and reported by every caller (launching anyway would fail with an invalid-configuration error
+// or, worse, run with less LDS than the kernel addresses).  One static instance per kernel at its launch site.
+class LdsOptIn {
+  public:
+    static constexpr int kMaxDevices = 64;
+    void ensure(const void* kernel, size_t bytes, const char* refused_message) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) throw_error("kernel launch: no current HIP device");
+        int st = __atomic_load_n(&state_[dev], __ATOMIC_ACQUIRE);
+        if (st == 0) {
+            // several lanes may arrive together: setting the same value twice is harmless, the outcome is the same
+            st = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 1 : -1;
+            if (st < 0) (void)hipGetLastError();
+            __atomic_store_n(&state_[dev], st, __ATOMIC_RELEASE);
+        }
+        if (st < 0) throw_error(refused_message);
+    }
+
+  private:
+    int state_[kMaxDevices] = {};        // 0 = not tried on this device, 1 = granted, -1 = refused
+};
+
 enum Act { ACT_NONE = 0, ACT_GELU = 1 };
 
 // ---- GEMM ------------------------------------------------------------------------------------

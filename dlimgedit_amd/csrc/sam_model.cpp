@@ -880,6 +880,63 @@ void SamModel::finish_masks(MaskSlot& slot, k::PostJob const* jobs, int count, f
                      std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count(), off);
 }
 
+namespace {
+// Direct xGMI copies between two GPUs need peer access switched on once per direction (without it the runtime stages
+// the copy through host memory: still correct, slower).  Failures are not errors: the copy falls back by itself.
+void enable_peer_access(int from_device, int to_device) {
+    static std::mutex m;
+    static std::vector<std::pair<int, int>> done;
+    std::lock_guard<std::mutex> lock(m);
+    for (auto& d : done)
+        if (d.first == from_device && d.second == to_device) return;
+    done.emplace_back(from_device, to_device);
+    if (from_device == to_device) return;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, from_device, to_device) == hipSuccess && can) {
+        (void)hipSetDevice(from_device);
+        if (hipDeviceEnablePeerAccess(to_device, 0) != hipSuccess) (void)hipGetLastError();
+    }
+    if (hipDeviceCanAccessPeer(&can, to_device, from_device) == hipSuccess && can) {
+        (void)hipSetDevice(to_device);
+        if (hipDeviceEnablePeerAccess(from_device, 0) != hipSuccess) (void)hipGetLastError();
+    }
+    (void)hipSetDevice(prev);
+}
+}  // namespace
+
+void SamModel::enqueue_masks_device(MaskSlot& slot, k::PostJob const* jobs, int count, int dst_device) {
+    if (count <= 0) return;
+    // test hook: take the staging + peer-copy path even when the destination is this lane's own GPU (a one-GPU box
+    // has no second device to copy to; the path is the same code, the copy degenerates to device-to-device)
+    const char* fp = std::getenv("DLIMGEDIT_FORCE_PEER_COPY");       // read per call: the tests switch it on and off
+    const bool force_peer = fp && std::atoi(fp) != 0;
+    double bytes = 0;
+    for (int i = 0; i < count; ++i) bytes += (double)kLowRes * kLowRes * 4 + (double)jobs[i].out_w * jobs[i].out_h;
+    if (dst_device == device_ && !force_peer) {
+        timed(ST_POST, bytes, [&] { k::postprocess_masks(jobs, count, stream_); });
+    } else {
+        size_t total = 0;
+        for (int i = 0; i < count; ++i) total += mask_bytes(jobs[i]);
+        slot.dev.reserve(total);             // the slot is ours; its previous user waited for slot.done
+        std::vector<k::PostJob> staged(jobs, jobs + count);
+        size_t off = 0;
+        for (int i = 0; i < count; ++i) {
+            staged[i].dst = slot.dev.get() + off;
+            off += mask_bytes(jobs[i]);
+        }
+        timed(ST_POST, bytes, [&] { k::postprocess_masks(staged.data(), count, stream_); });
+        enable_peer_access(device_, dst_device);
+        for (int i = 0; i < count; ++i)
+            HIP_CHECK(hipMemcpyPeerAsync(jobs[i].dst, dst_device, staged[i].dst, device_,
+                                         (size_t)jobs[i].out_w * jobs[i].out_h, stream_));
+    }
+    HIP_CHECK(hipEventRecord(slot.done, stream_));
+}
+
+void SamModel::wait_masks(MaskSlot& slot) { HIP_CHECK(hipEventSynchronize(slot.done)); }
+
 void SamModel::masks_to_host(k::PostJob const* jobs, int count) {
     MaskSlot& slot = acquire_mask_slot();
     try {

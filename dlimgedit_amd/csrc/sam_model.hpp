@@ -159,6 +159,12 @@ class SamModel {
     void release_mask_slot(MaskSlot& s);
     void enqueue_masks(MaskSlot& slot, k::PostJob const* jobs, int count, int iou_count);
     void finish_masks(MaskSlot& slot, k::PostJob const* jobs, int count, float* iou_out, int iou_count);
+    // Masks to DEVICE memory that may belong to ANOTHER GPU ("all masks on one device"): jobs[i].dst are
+    // pointers valid on HIP device dst_device.  Same device as this lane's: the kernel writes them directly.  Another
+    // device: the kernel writes the slot's staging memory and one hipMemcpyPeerAsync per mask moves it over xGMI.
+    // slot.done is recorded behind the last write; wait_masks() (no mutex needed) waits for it.
+    void enqueue_masks_device(MaskSlot& slot, k::PostJob const* jobs, int count, int dst_device);
+    void wait_masks(MaskSlot& slot);
     // Blocking convenience form of the three calls above (mutex() held throughout).
     void masks_to_host(k::PostJob const* jobs, int count);
     // Same kernel, but jobs[i].dst are DEVICE pointers and nothing is copied or waited for.

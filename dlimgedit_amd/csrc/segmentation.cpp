@@ -108,6 +108,19 @@ template <typename F> void for_each_replica(std::vector<int> const& used, F&& bo
 
 struct Waiting { SamModel* model; hipEvent_t done; };
 
+// Error paths: a request that threw half-way may have queued kernels or copies that still write into buffers the
+// caller is about to hand back (pooled embedding buffers, mask staging slots).  Everything queued on that lane runs
+// to completion first; errors of the drain itself are not interesting any more.
+void drain_lane(SamModel* model) noexcept {
+    if (!model) return;
+    try {
+        std::lock_guard<std::mutex> lock(model->mutex());
+        (void)hipSetDevice(model->device());
+        model->synchronize();
+    } catch (...) {
+    }
+}
+
 void wait_all(std::vector<Waiting>& waiting) {
     std::exception_ptr first;
     for (auto& w : waiting) {
@@ -158,6 +171,7 @@ void SegmentationImpl::process_batch(EnvironmentImpl& env, SegmentationImpl* con
     for_each_replica(used, [&](int replica) {
         HIP_CHECK(hipSetDevice(env.device_of(replica)));
         std::vector<Waiting> waiting;
+        SamModel* enqueueing = nullptr;          // the lane whose request is being put together (error path: drained)
         const auto t0 = std::chrono::steady_clock::now();
         try {
             std::vector<int> mine;
@@ -170,6 +184,7 @@ void SegmentationImpl::process_batch(EnvironmentImpl& env, SegmentationImpl* con
                 std::vector<float*> emb(n);
                 for (int j = 0; j < n; ++j) emb[j] = segs[mine[base + j]]->embedding_storage(replica);
                 SamModel& model = env.next_lane(replica);
+                enqueueing = &model;
                 roctx::Range range("dlimg.process");
                 std::lock_guard<std::mutex> lock(model.mutex());
                 {
@@ -184,8 +199,12 @@ void SegmentationImpl::process_batch(EnvironmentImpl& env, SegmentationImpl* con
                     model.encode(n, emb.data());
                 }
                 waiting.push_back(Waiting{&model, model.completion()});
+                enqueueing = nullptr;
             }
         } catch (...) {
+            // the chunk that threw has no completion event: whatever it queued (it writes the handles' embedding
+            // buffers, which their destructors return to the pool) is waited for on its stream
+            drain_lane(enqueueing);
             try { wait_all(waiting); } catch (...) {}
             throw;
         }
@@ -245,6 +264,7 @@ void SegmentationImpl::compute_mask(Point const* point, Region const* region, ui
         }
         model_.finish_masks(slot, jobs, n_jobs, iou, is_single_mask ? 0 : 4);      // waits outside the lane's mutex
     } catch (...) {
+        drain_lane(&model_);                     // a copy into the slot's staging memory may still be queued
         model_.release_mask_slot(slot);
         throw;
     }
@@ -324,9 +344,102 @@ void SegmentationImpl::compute_mask_batch(SegmentationImpl const* const* segs, i
             }
             for (auto& c : chunks) finish(c);
         } catch (...) {
+            // a chunk whose enqueue failed has no valid completion event: drain the lanes before the slots go back
+            for (auto& c : chunks)
+                if (c.slot) drain_lane(c.model);
             for (auto& c : chunks) {
                 try { finish(c); } catch (...) {}
             }
+            throw;
+        }
+    });
+}
+
+// Device-output variant: the "gather" of SURVEY.md 8e.  Every GPU of the environment decodes the prompts whose
+// embeddings it holds; a mask whose GPU is the root is written in place by the post-processing kernel, the others cross
+// xGMI as one peer copy each (hipMemcpyPeerAsync on the producing lane's stream, so the copy of one chunk runs beside the
+// decoder of the next).  No host memory is touched.  The reference has nothing comparable (one device, host tensors:
+// /root/reference/src/session.cpp:63-66, /root/reference/src/environment.cpp:142).
+void SegmentationImpl::compute_mask_batch_device(SegmentationImpl const* const* segs, int count, int const* points,
+                                                 int const* regions, int root_device, uint8_t* dev_out,
+                                                 size_t* out_offsets) {
+    if (count <= 0) return;
+    DLIMG_ASSERT((points != nullptr) != (regions != nullptr));
+    DLIMG_ASSERT(dev_out != nullptr);
+    if (root_device < 0 || root_device >= EnvironmentImpl::device_count())
+        throw Exception("root device " + std::to_string(root_device) + " is out of range: " +
+                        std::to_string(EnvironmentImpl::device_count()) + " device(s) visible");
+    constexpr int kPromptChunk = 8;
+    EnvironmentImpl& env = segs[0]->env_;
+    std::vector<float> coords((size_t)count * 4), labels((size_t)count * 2);
+    std::vector<size_t> offsets(count);
+    std::vector<int> used;
+    size_t total = 0;
+    for (int i = 0; i < count; ++i) {
+        DLIMG_ASSERT(&segs[i]->env_ == &env);
+        DLIMG_ASSERT(segs[i]->embedding_ != nullptr);
+        if (points) {
+            Point p{points[i * 2], points[i * 2 + 1]};
+            pack_prompt(segs[i]->image_size_, &p, nullptr, &coords[i * 4], &labels[i * 2]);
+        } else {
+            Region r{Point{regions[i * 4], regions[i * 4 + 1]}, Point{regions[i * 4 + 2], regions[i * 4 + 3]}};
+            pack_prompt(segs[i]->image_size_, nullptr, &r, &coords[i * 4], &labels[i * 2]);
+        }
+        offsets[i] = total;
+        total += (size_t)segs[i]->image_size_.original.width * segs[i]->image_size_.original.height;
+        if (std::find(used.begin(), used.end(), segs[i]->replica_) == used.end()) used.push_back(segs[i]->replica_);
+    }
+    if (out_offsets) std::copy(offsets.begin(), offsets.end(), out_offsets);
+    for_each_replica(used, [&](int replica) {
+        HIP_CHECK(hipSetDevice(env.device_of(replica)));
+        std::vector<int> mine;
+        for (int i = 0; i < count; ++i)
+            if (segs[i]->replica_ == replica) mine.push_back(i);
+        struct Chunk { SamModel* model; SamModel::MaskSlot* slot; };
+        std::vector<Chunk> chunks;
+        auto settle = [&](bool drain) {          // wait for every chunk, hand the slots back; first error wins
+            std::exception_ptr first;
+            for (auto& c : chunks) {
+                if (!c.slot) continue;
+                if (drain) drain_lane(c.model);
+                try {
+                    c.model->wait_masks(*c.slot);
+                } catch (...) {
+                    if (!first) first = std::current_exception();
+                }
+                c.model->release_mask_slot(*c.slot);
+                c.slot = nullptr;
+            }
+            if (first) std::rethrow_exception(first);
+        };
+        try {
+            for (size_t base = 0; base < mine.size(); base += kPromptChunk) {
+                const int n = (int)std::min<size_t>(kPromptChunk, mine.size() - base);
+                std::vector<float const*> emb(n);
+                std::vector<float> cc((size_t)n * 4), ll((size_t)n * 2);
+                std::vector<k::PostJob> jobs(n);
+                for (int j = 0; j < n; ++j) {
+                    const int i = mine[base + j];
+                    emb[j] = segs[i]->embedding_;
+                    std::copy_n(&coords[(size_t)i * 4], 4, &cc[(size_t)j * 4]);
+                    std::copy_n(&labels[(size_t)i * 2], 2, &ll[(size_t)j * 2]);
+                }
+                SamModel& model = env.next_lane(replica);
+                chunks.push_back(Chunk{&model, &model.acquire_mask_slot()});
+                roctx::Range range("dlimg.compute_masks_device");
+                std::lock_guard<std::mutex> lock(model.mutex());
+                model.decode(emb.data(), cc.data(), ll.data(), n);
+                for (int j = 0; j < n; ++j) {
+                    const int i = mine[base + j];
+                    const Extent o = segs[i]->image_size_.original, r = segs[i]->image_size_.resized;
+                    jobs[j] = k::PostJob{model.logits() + (size_t)j * 4 * kLowRes * kLowRes, model.iou() + (size_t)j * 4,
+                                         dev_out + offsets[i], o.width, o.height, r.width, r.height};
+                }
+                model.enqueue_masks_device(*chunks.back().slot, jobs.data(), n, root_device);
+            }
+            settle(false);
+        } catch (...) {
+            try { settle(true); } catch (...) {}
             throw;
         }
     });

@@ -50,6 +50,12 @@ class SegmentationImpl {
     static void compute_mask_batch(SegmentationImpl const* const* segs, int count, int const* points,
                                    int const* regions, uint8_t* const* out_masks);
 
+    // Device-output form of compute_mask_batch: mask i is produced on the GPU that holds segs[i]'s embedding
+    // and lands at dev_out + offset_i in the memory of HIP device `root_device` (offset_i = sum of width*height of the
+    // entries before it; also returned in out_offsets when given).  Returns when every mask is in place.
+    static void compute_mask_batch_device(SegmentationImpl const* const* segs, int count, int const* points,
+                                          int const* regions, int root_device, uint8_t* dev_out, size_t* out_offsets);
+
     Extent extent() const { return image_size_.original; }
     ResizeLongestSide const& geometry() const { return image_size_; }
     float const* embedding() const { return embedding_; }

@@ -44,7 +44,10 @@ DLIMG_API int dlimg_amd_copy_to_host(dlimg_Environment env, void* dst_host, void
 /* One pass of the hot path over `count` images already in HBM: pre-process, encode (one batched
  * pass), decode one point prompt per image (single-mask mode) and write the 0/255 masks to
  * dev_masks[i] (width*height bytes each, device memory).  Views carry DEVICE pixel pointers.
- * points: count x {x,y}.  Returns after enqueueing; call dlimg_amd_synchronize to wait. */
+ * points: count x {x,y}.  Asynchronous: returns once the request is accepted; call dlimg_amd_synchronize to wait.
+ * Independent single-image requests are coalesced into batched passes of DLIMGEDIT_COALESCE images (default 2, 1 = off;
+ * dynamic batching -- the results are bit-identical to single-image passes); a request that is still waiting for a
+ * partner is launched by the next request or by dlimg_amd_synchronize. */
 DLIMG_API int dlimg_amd_encode_and_mask(dlimg_Environment env, dlimg_ImageView const* dev_images, int count,
                                         int const* points, uint8_t* const* dev_masks);
 /* Encode only / decode only variants of the above, for per-stage rates. */
@@ -60,11 +63,25 @@ DLIMG_API int dlimg_amd_lane_count(dlimg_Environment env);
 DLIMG_API int dlimg_amd_replica_count(dlimg_Environment env);
 DLIMG_API int dlimg_amd_segmentation_device(dlimg_Segmentation seg, int* out_replica, int* out_device);
 
+/* Device-output form of get_segmentation_masks (table slot 14; reference: there is no multi-device or device-output
+ * path at all, src/session.cpp:63-66 uses the default device and src/environment.cpp:142 binds every tensor to host
+ * memory): one single-mask query per entry, points / regions as in slot 14.  Mask i is produced on the GPU that holds
+ * segs[i]'s embedding and is delivered into the memory of HIP device `root_device` at dev_out + offset_i, where
+ * offset_i = sum over the entries before i of width*height (tightly packed, 0 / 255 bytes); the offsets are also written
+ * to out_offsets[count] when it is non-null.  Masks of other GPUs cross xGMI as peer-to-peer copies (hipMemcpyPeerAsync);
+ * no host memory is involved.  Returns when every mask is in place.  This is the "gather of mask outputs" of the
+ * multi-GPU design. */
+DLIMG_API int dlimg_amd_get_segmentation_masks_device(dlimg_Segmentation const* segs, int count, int const* points,
+                                                      int const* regions, int root_device, uint8_t* dev_out,
+                                                      size_t* out_offsets);
+
 /* ---- stage clocks (HIP events on the executor's stream) -------------------------------------- */
 #define DLIMG_AMD_STAGE_COUNT 8
 /* stage ids: 0 pre, 1 gemm (all MFMA GEMMs of the encoder), 2 layernorm, 3 attention_window,
  * 4 attention_global, 5 encoder_other, 6 decoder (whole prompt+mask decoder), 7 post */
-/* While profiling is enabled all requests run on lane 0 so per-kernel clocks are not disturbed by other lanes. */
+/* enabled = 1: all requests run on lane 0, so every kernel is clocked alone on the chip; enabled = 2: the lanes run as
+ * usual and every lane clocks its own launches (the regime the throughput figure is measured in); 0 = off.
+ * dlimg_amd_take_stage_stats sums over the lanes. */
 DLIMG_API int dlimg_amd_set_profiling(dlimg_Environment env, int enabled);
 /* Accumulated since the previous call: milliseconds, algorithmic work (FLOPs for stages 1,3,4,6;
  * bytes for the others) and launch counts; arrays of DLIMG_AMD_STAGE_COUNT. Resets the counters. */

@@ -65,6 +65,44 @@ def model_dirs(tmp_path_factory):
     return get
 
 
+# ---- parity tolerances (fp32 oracle / Hugging Face fixtures vs the f16-operand MFMA path with fp32 accumulation, softmax
+# and LayerNorm statistics).  Set at 3-5x what the kernels measure on MI355X (round 3: embedding 0.0036-0.0048, low-res
+# logits 0.006, IoU predictions 0.0004), so a kernel that loses a few bits of accuracy fails; every checked value is also
+# appended to gpurun_out/parity_margins.txt so the margins can be read after a run.
+EMB_TOL = 0.015        # max-abs error of the image embedding (LayerNorm'ed values, |x| ~ 4)
+LOGIT_TOL = 0.03       # max-abs error of the low-res mask logits (std ~ 1.3, range about +-5)
+IOU_PRED_TOL = 0.003   # max-abs error of the decoder's IoU predictions
+IOU_BAR = 0.98         # BASELINE.json: mask IoU vs the CPU reference
+
+
+def within(name: str, err, tol: float) -> float:
+    """assert err < tol, and leave (name, err, tol) in gpurun_out/parity_margins.txt."""
+    err = float(err)
+    try:
+        out = ROOT / "gpurun_out"
+        out.mkdir(exist_ok=True)
+        with open(out / "parity_margins.txt", "a") as f:
+            f.write(f"{name}\t{err:.6g}\t{tol:.6g}\n")
+    except OSError:
+        pass
+    assert err < tol, f"{name}: {err:.6g} is not below {tol:.6g}"
+    return err
+
+
+def at_least(name: str, value, bar: float) -> float:
+    """assert value >= bar (IoU-like quantities), logged like within()."""
+    value = float(value)
+    try:
+        out = ROOT / "gpurun_out"
+        out.mkdir(exist_ok=True)
+        with open(out / "parity_margins.txt", "a") as f:
+            f.write(f"{name}\t{value:.6g}\t>={bar:.6g}\n")
+    except OSError:
+        pass
+    assert value >= bar, f"{name}: {value:.6g} is below {bar:.6g}"
+    return value
+
+
 def iou(a: np.ndarray, b: np.ndarray) -> float:
     a, b = a > 0, b > 0
     union = np.logical_or(a, b).sum()

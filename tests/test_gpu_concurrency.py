@@ -82,3 +82,74 @@ def test_async_steps_on_device_resident_images(setup):
     finally:
         for p in ptrs + mptrs:
             ext.device_free(env, p)
+
+
+def test_concurrent_compute_mask_on_one_handle(setup):
+    """compute_mask is const in the reference and touches only read-only shared state, so several threads may query ONE
+    Segmentation handle at once (reference: src/include/dlimgedit/dlimgedit.hpp:98-101, src/segmentation.cpp:131-174).
+    Four threads, single-mask and multi-mask queries mixed, every result bit-equal to the serial answer."""
+    api, env = setup
+    seg = api.Segmentation.process(api.ImageView(synthetic_image(41), api.Channels.rgba), env)
+    prompts = [api.Point(150 + 90 * i, 900 - 85 * i) for i in range(8)]
+    boxes = [api.Region(api.Point(40 * i, 30 * i), api.Point(600 + 50 * i, 500 + 60 * i)) for i in range(8)]
+    want_pt = [seg.compute_mask(p) for p in prompts]
+    want_box = [seg.compute_mask(b) for b in boxes]
+    want_multi = [[m.image for m in seg.compute_masks(p)] for p in prompts[:3]]
+    errors, mismatches = [], []
+
+    def worker(t):
+        try:
+            for rep in range(6):
+                for i in range(8):
+                    j = (i + 2 * t + rep) % 8
+                    if not np.array_equal(seg.compute_mask(prompts[j]), want_pt[j]):
+                        mismatches.append(("point", t, rep, j))
+                    if not np.array_equal(seg.compute_mask(boxes[j]), want_box[j]):
+                        mismatches.append(("box", t, rep, j))
+                got = seg.compute_masks(prompts[t % 3])
+                if not all(np.array_equal(g.image, w) for g, w in zip(got, want_multi[t % 3])):
+                    mismatches.append(("multi", t, rep))
+        except Exception as e:       # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
+    assert not mismatches, mismatches[:5]
+    seg.close()
+
+
+@pytest.mark.parametrize("kind,heads,hd", [("window", 12, 64), ("window", 16, 80), ("global", 12, 64)])
+def test_attention_kernels_are_bit_stable_under_concurrent_lanes(setup, kind, heads, hd):
+    """Stress for the attention kernels (a windowed variant with two workgroups per CU was once seen to produce sporadic
+    wrong rows): 500 launches of the kernel from four host threads at once -- each call is its own
+    upload + launch + download on the null stream of its thread's context, so launches of different threads interleave
+    on the GPU -- and every output must equal the first one bit for bit."""
+    api, _ = setup
+    rng = np.random.default_rng(17)
+    D = heads * hd
+    span = 14 if kind == "window" else 64
+    qkv = (rng.standard_normal((4096, 3 * D)) * 1.5).astype(np.float16)
+    bias = (rng.standard_normal(3 * D) * 0.2).astype(np.float32)
+    rel_h = (rng.standard_normal((2 * span - 1, hd)) * 0.3).astype(np.float32)
+    rel_w = (rng.standard_normal((2 * span - 1, hd)) * 0.3).astype(np.float32)
+    first = api.ext.test_attention(kind == "global", qkv, bias, rel_h, rel_w, 1, heads, hd)
+    per_thread = 125 if kind == "window" else 40          # 4 threads: 500 windowed launches, 160 global ones (8x longer each)
+    bad, errors = [], []
+
+    def worker(t):
+        try:
+            for i in range(per_thread):
+                out = api.ext.test_attention(kind == "global", qkv, bias, rel_h, rel_w, 1, heads, hd)
+                if not np.array_equal(out, first):
+                    rows = np.flatnonzero((out != first).any(axis=1))
+                    bad.append((t, i, rows[:8].tolist(), len(rows)))
+        except Exception as e:       # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
+    assert not bad, bad[:5]

@@ -3,14 +3,10 @@ table) against the CPU oracle on the same seeded weights, inputs and prompts."""
 import numpy as np
 import pytest
 
-from conftest import iou, single_mask_index, synthetic_image
+from conftest import (EMB_TOL, IOU_BAR, IOU_PRED_TOL, LOGIT_TOL, at_least, iou, single_mask_index, synthetic_image,
+                      within)
 
 pytestmark = pytest.mark.gpu
-
-# Tolerances (fp32 oracle vs f16-operand MFMA path, fp32 accumulate / softmax / LayerNorm):
-EMB_TOL = 0.05        # max-abs error of the image embedding (values are LayerNorm'ed, |x| ~ 4)
-LOGIT_TOL = 0.15      # max-abs error of the low-res mask logits (std ~ 1.3)
-IOU_BAR = 0.98        # BASELINE.json: mask IoU vs CPU reference
 
 
 @pytest.fixture(scope="module")
@@ -49,8 +45,7 @@ def test_extent(api, session):
 def test_embedding_parity(api, session):
     *_, seg, ora = session
     emb = api.ext.get_embedding(seg)
-    err = np.abs(emb - ora.embedding).max()
-    assert err < EMB_TOL, err
+    within("e2e.embedding", np.abs(emb - ora.embedding).max(), EMB_TOL)
 
 
 @pytest.mark.parametrize("prompt", ["point", "region"])
@@ -63,8 +58,8 @@ def test_logits_parity(api, session, prompt):
         r = api.Region(api.Point(256, 256), api.Point(768, 768))
         got, got_iou = api.ext.get_logits(seg, region=r)
         want, want_iou = ora.logits(region=(256, 256, 768, 768))
-    assert np.abs(got - want).max() < LOGIT_TOL, np.abs(got - want).max()
-    assert np.abs(got_iou - want_iou).max() < 0.05
+    within(f"e2e.logits.{prompt}", np.abs(got - want).max(), LOGIT_TOL)
+    within(f"e2e.iou_pred.{prompt}", np.abs(got_iou - want_iou).max(), IOU_PRED_TOL)
 
 
 def test_point_mask_iou(api, session):
@@ -72,14 +67,14 @@ def test_point_mask_iou(api, session):
     got = seg.compute_mask(api.Point(512, 512))
     want = ora.compute_mask(point=(512, 512))
     assert got.shape == (1024, 1024) and set(np.unique(got)) <= {0, 255}
-    assert iou(got, want) >= IOU_BAR, iou(got, want)
+    at_least("e2e.point_mask_iou", iou(got, want), IOU_BAR)
 
 
 def test_region_mask_iou(api, session):
     *_, seg, ora = session
     got = seg.compute_mask(api.Region(api.Point(256, 256), api.Point(768, 768)))
     want = ora.compute_mask(region=(256, 256, 768, 768))
-    assert iou(got, want) >= IOU_BAR, iou(got, want)
+    at_least("e2e.region_mask_iou", iou(got, want), IOU_BAR)
 
 
 def test_multi_mask_mode(api, session):
@@ -87,9 +82,9 @@ def test_multi_mask_mode(api, session):
     *_, seg, ora = session
     got = seg.compute_masks(api.Point(300, 700))
     want_masks, want_acc = ora.compute_masks((300, 700))
-    for g, wm, wa in zip(got, want_masks, want_acc):
-        assert iou(g.image, wm) >= IOU_BAR
-        assert abs(g.accuracy - wa) < 0.05
+    for t, (g, wm, wa) in enumerate(zip(got, want_masks, want_acc)):
+        at_least(f"e2e.multi_mask_iou.{t}", iou(g.image, wm), IOU_BAR)
+        within(f"e2e.multi_mask_accuracy.{t}", abs(g.accuracy - wa), IOU_PRED_TOL)
 
 
 def test_mask_is_bit_exact_given_logits(api, session):
@@ -144,8 +139,8 @@ def test_head_dim_80_variant(api, model_dirs):
     img = synthetic_image(4)
     seg = api.Segmentation.process(api.ImageView(img, api.Channels.rgba), env)
     ora = O.OracleSegmentation(params, cfg).process(img, O.CH_RGBA)
-    assert np.abs(api.ext.get_embedding(seg) - ora.embedding).max() < EMB_TOL
-    assert iou(seg.compute_mask(api.Point(512, 512)), ora.compute_mask(point=(512, 512))) >= IOU_BAR
+    within("e2e.hd80.embedding", np.abs(api.ext.get_embedding(seg) - ora.embedding).max(), EMB_TOL)
+    at_least("e2e.hd80.mask_iou", iou(seg.compute_mask(api.Point(512, 512)), ora.compute_mask(point=(512, 512))), IOU_BAR)
 
 
 def test_folded_and_separate_layernorm_agree(api, session, model_dirs, monkeypatch):
@@ -158,10 +153,11 @@ def test_folded_and_separate_layernorm_agree(api, session, model_dirs, monkeypat
     seg_split = api.Segmentation.process(api.ImageView(img, api.Channels.rgba), env_split)
     folded, split = api.ext.get_embedding(seg), api.ext.get_embedding(seg_split)
     assert not np.array_equal(folded, split)                 # really two code paths
-    assert np.abs(split - ora.embedding).max() < EMB_TOL
-    assert np.abs(folded - ora.embedding).max() < EMB_TOL
-    assert np.abs(folded - split).max() < EMB_TOL
-    assert iou(seg_split.compute_mask(api.Point(512, 512)), ora.compute_mask(point=(512, 512))) >= IOU_BAR
+    within("e2e.ln_split.embedding", np.abs(split - ora.embedding).max(), EMB_TOL)
+    within("e2e.ln_folded.embedding", np.abs(folded - ora.embedding).max(), EMB_TOL)
+    within("e2e.ln_folded_vs_split", np.abs(folded - split).max(), EMB_TOL)
+    at_least("e2e.ln_split.mask_iou", iou(seg_split.compute_mask(api.Point(512, 512)), ora.compute_mask(point=(512, 512))),
+             IOU_BAR)
 
 
 def test_error_paths(api, session, tmp_path):
@@ -216,11 +212,11 @@ def test_non_1024_images_end_to_end(api, session, w, h, channels, point):
     seg = api.Segmentation.process(api.ImageView(img, ch), env)
     assert seg.extent() == api.Extent(w, h)
     ora = O.OracleSegmentation(params, cfg).process(img, int(ch))
-    assert np.abs(api.ext.get_embedding(seg) - ora.embedding).max() < EMB_TOL
+    within(f"e2e.{w}x{h}.embedding", np.abs(api.ext.get_embedding(seg) - ora.embedding).max(), EMB_TOL)
     got = seg.compute_mask(api.Point(*point))
     want = ora.compute_mask(point=point)
     assert got.shape == (h, w)
-    assert iou(got, want) >= IOU_BAR, iou(got, want)
+    at_least(f"e2e.{w}x{h}.mask_iou", iou(got, want), IOU_BAR)
 
 
 @pytest.mark.parametrize("w,h", [(1, 1), (3, 1024), (2048, 16), (1024, 1), (17, 13), (4000, 3000)])
@@ -238,7 +234,7 @@ def test_extreme_geometries(api, session, w, h):
     if w * h <= 2048 * 16:          # keep the oracle side cheap
         ora = O.OracleSegmentation(params, cfg).process(img, O.CH_RGBA)
         want = ora.compute_mask(point=pt)
-        assert (got != want).mean() <= 0.02
+        within(f"e2e.extreme.{w}x{h}.differing_pixels", (got != want).mean(), 0.002)
 
 
 def test_prompts_outside_the_image_and_degenerate_boxes(api, session):
@@ -246,10 +242,10 @@ def test_prompts_outside_the_image_and_degenerate_boxes(api, session):
     for pt in [(-50, -50), (5000, 5000), (0, 0), (1023, 1023)]:
         got = seg.compute_mask(api.Point(*pt))
         want = ora.compute_mask(point=pt)
-        assert iou(got, want) >= IOU_BAR or (got != want).mean() < 0.01
+        at_least(f"e2e.outside.{pt[0]},{pt[1]}.mask_iou", iou(got, want), IOU_BAR)
     got = seg.compute_mask(api.Region(api.Point(700, 700), api.Point(100, 100)))      # inverted box
     want = ora.compute_mask(region=(700, 700, 100, 100))
-    assert iou(got, want) >= IOU_BAR or (got != want).mean() < 0.01
+    at_least("e2e.inverted_box.mask_iou", iou(got, want), IOU_BAR)
 
 
 def test_mask_and_rgb_inputs(api, session):
@@ -259,7 +255,7 @@ def test_mask_and_rgb_inputs(api, session):
     gray = np.ascontiguousarray(img[:, :, 0])
     seg = api.Segmentation.process(api.ImageView(gray, api.Channels.mask), env)
     ora = O.OracleSegmentation(params, cfg).process(gray, O.CH_MASK)
-    assert np.abs(api.ext.get_embedding(seg) - ora.embedding).max() < EMB_TOL
+    within("e2e.mask_input.embedding", np.abs(api.ext.get_embedding(seg) - ora.embedding).max(), EMB_TOL)
     rgb = np.ascontiguousarray(img[:, :, :3])
     seg3 = api.Segmentation.process(api.ImageView(rgb, api.Channels.rgb), env)
     assert np.array_equal(api.ext.get_embedding(seg3), api.ext.get_embedding(session[4]))
@@ -297,17 +293,17 @@ def test_full_size_models_against_committed_golden(api, model_dirs, monkeypatch,
     img = synthetic_image(int(g["image_seed"]))
     seg = api.Segmentation.process(api.ImageView(img, api.Channels.rgba), env)
     emb = api.ext.get_embedding(seg).reshape(-1)[::257]
-    assert np.abs(emb - g["emb_samples"]).max() < EMB_TOL
+    within(f"golden.{variant}.embedding", np.abs(emb - g["emb_samples"]).max(), EMB_TOL)
     for name, kw, call in (("point", dict(point=api.Point(512, 512)), lambda: seg.compute_mask(api.Point(512, 512))),
                            ("box", dict(region=api.Region(api.Point(256, 256), api.Point(768, 768))),
                             lambda: seg.compute_mask(api.Region(api.Point(256, 256), api.Point(768, 768))))):
         low, iou_pred = api.ext.get_logits(seg, **kw)
-        assert np.abs(low.reshape(4, -1)[:, ::61] - g[f"{name}_low_samples"]).max() < LOGIT_TOL
-        assert np.abs(iou_pred - g[f"{name}_iou"]).max() < 0.02
+        within(f"golden.{variant}.{name}.logits", np.abs(low.reshape(4, -1)[:, ::61] - g[f"{name}_low_samples"]).max(), LOGIT_TOL)
+        within(f"golden.{variant}.{name}.iou_pred", np.abs(iou_pred - g[f"{name}_iou"]).max(), IOU_PRED_TOL)
         # single-mask mode returns the best of tokens 1..3: the rule is applied to Hugging Face's own predictions
         best = single_mask_index(g[f"{name}_iou"])
         want = np.unpackbits(g[f"{name}_masks_bits"], axis=1).reshape(3, 1024, 1024)[best - 1] * 255
-        assert iou(call(), want) >= IOU_BAR
+        at_least(f"golden.{variant}.{name}.mask_iou", iou(call(), want), IOU_BAR)
 
 
 @pytest.mark.parametrize("variant", ["vit_test", "vit_b"])
@@ -333,10 +329,11 @@ def test_trained_like_activation_statistics(api, tmp_path_factory, monkeypatch, 
         env = api.Environment(api.Options(api.Backend.gpu, str(d)))
         seg = api.Segmentation.process(api.ImageView(img, api.Channels.rgba), env)
         errs[fused] = float(np.abs(api.ext.get_embedding(seg) - ora.embedding).max())
-        assert errs[fused] < EMB_TOL, (fused, errs)
-        assert iou(seg.compute_mask(api.Point(512, 512)), want) >= IOU_BAR
+        within(f"trained_like.{variant}.fused{fused}.embedding", errs[fused], EMB_TOL)
+        at_least(f"trained_like.{variant}.fused{fused}.point_iou", iou(seg.compute_mask(api.Point(512, 512)), want), IOU_BAR)
         got_box = seg.compute_mask(api.Region(api.Point(256, 256), api.Point(768, 768)))
-        assert iou(got_box, ora.compute_mask(region=(256, 256, 768, 768))) >= IOU_BAR
+        at_least(f"trained_like.{variant}.fused{fused}.box_iou", iou(got_box, ora.compute_mask(region=(256, 256, 768, 768))),
+                 IOU_BAR)
         seg.close()
         env.close()
     # folding the LayerNorm in must not cost more than a small multiple of the separate kernels' own f16 error

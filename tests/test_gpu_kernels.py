@@ -362,6 +362,15 @@ def test_resize_bit_exact(ext, w, h, ow, oh, channels):
     assert np.array_equal(got, want)
 
 
+def test_resize_upsampling_against_pillow_on_device(ext):
+    """The device resampler against the fixture that does not come from oracle/stb_resize.py (Pillow Catmull-Rom in
+    linear light, tests/golden/make_resize_golden.py): within 1 LSB everywhere."""
+    from dlimgedit_amd import api
+    from test_oracle_kats import _check_against_pillow_upsample
+    _check_against_pillow_upsample(
+        lambda src, ow, oh: ext.test_resize(src, api.Channels.rgb if src.shape[2] == 3 else api.Channels.rgba, ow, oh))
+
+
 def test_resize_reference_kat_on_device(ext):
     from dlimgedit_amd import api
     img = np.zeros((8, 8, 4), np.uint8)

@@ -111,6 +111,27 @@ def test_image_resize_kat():
         assert tuple(int(v) for v in out[i // 4, i % 4]) == (255, 2 + 8 * (i // 4), 2 + 8 * (i % 4), 255)
 
 
+def _check_against_pillow_upsample(resize):
+    """resize(src, out_w, out_h) against tests/golden/resize_upsample_pil.npz (Pillow BICUBIC = Catmull-Rom, a = -0.5, in
+    linear light with the sRGB formulas in float64; made by tests/golden/make_resize_golden.py, no oracle code in it).
+    Not bit-exact by construction (border treatment, float tables): every byte within 1 LSB, at most 3 % of them off."""
+    from pathlib import Path
+    g = np.load(Path(__file__).resolve().parent / "golden" / "resize_upsample_pil.npz")
+    for name in ("rgb_96x60_to_256x160", "rgba_50x80_to_160x256"):
+        src, want = g[name + "_src"], g[name + "_out"]
+        got = resize(src, want.shape[1], want.shape[0])
+        assert got.shape == want.shape and got.dtype == np.uint8
+        d = np.abs(got.astype(int) - want.astype(int))
+        assert d.max() <= 1, (name, int(d.max()))
+        assert (d > 0).mean() < 0.03, (name, float((d > 0).mean()))
+
+
+def test_image_resize_upsampling_against_pillow_catmull_rom():
+    """The up-sampling half of the default filter (Catmull-Rom), which the reference's KAT does not reach."""
+    from oracle import stb_resize as R
+    _check_against_pillow_upsample(R.resize_srgb)
+
+
 def test_srgb_tables_round_trip_and_are_monotonic():
     """Giesen's float->sRGB8 conversion must invert the 256-entry decode table and never decrease."""
     from oracle import stb_resize as R

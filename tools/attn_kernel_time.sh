@@ -1,7 +1,7 @@
 #!/bin/bash
 # kernel durations of the attention probe under rocprofv3 --kernel-trace for each ablation of the ping-pong kernel
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R="${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set (run through gpurun)}"
 for a in ${ABLS:-0 1 2 3}; do
   rm -rf /tmp/kt_$a
   DLIMGEDIT_ATTN_PP_ABLATE=$a timeout -k 10 90 rocprofv3 --kernel-trace -d /tmp/kt_$a -o k -- python3 $R/tools/attn_probe.py global 12 64 5 > /tmp/kt_$a.log 2>&1

@@ -1,6 +1,6 @@
 #!/bin/bash
 # package power and shader clock while bench.py runs a long block (evidence for the power-limit statement in DESIGN.md)
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set (run through gpurun)}"
 python3 bench.py --steps 3000 --warmup 5 --repeats 3 --no-cpu-baseline --no-abi-path > gpurun_out/power_bench.log 2>&1 &
 BP=$!
 sleep 25
