@@ -391,6 +391,7 @@ class ext:
                 "dlimg_amd_birefnet_prepare_image": ([vp, ci, ci, ci, ci, vp, vp, vp], ci),
                 "dlimg_amd_birefnet_process_mask": ([vp, ci, ci, vp], ci),
                 "dlimg_amd_resize_mask": ([vp, ci, ci, ci, ci, ci, vp], ci),
+                "dlimg_amd_bench_attention": ([ci, ci, ci, ci, ci, C.POINTER(C.c_double)], ci),
                 "dlimg_amd_bench_gemm": ([ci, ci, ci, ci, ci, ci, C.POINTER(C.c_double)], ci),
                 "dlimg_amd_bench_gemm_streams": ([ci, ci, ci, ci, ci, ci, ci, ci, ci, C.POINTER(C.c_double)], ci),
                 "dlimg_amd_bench_gemm_stamps": ([ci, ci, ci, ci, ci, ci, ci, ci, ci, C.POINTER(C.c_double), vp, ci], ci),
@@ -409,7 +410,7 @@ class ext:
                "dlimg_amd_take_stage_stats", "dlimg_amd_test_preprocess", "dlimg_amd_test_postprocess",
                "dlimg_amd_test_gemm", "dlimg_amd_test_gemm_ln", "dlimg_amd_test_layernorm", "dlimg_amd_test_attention", "dlimg_amd_test_resize",
                "dlimg_amd_birefnet_prepare_image", "dlimg_amd_birefnet_process_mask", "dlimg_amd_resize_mask",
-               "dlimg_amd_bench_gemm", "dlimg_amd_bench_gemm_streams", "dlimg_amd_bench_gemm_stamps")
+               "dlimg_amd_bench_attention", "dlimg_amd_bench_gemm", "dlimg_amd_bench_gemm_streams", "dlimg_amd_bench_gemm_stamps")
 
     @staticmethod
     def _ptr(a: Optional[np.ndarray]):
@@ -644,6 +645,13 @@ class ext:
         out = np.empty((out_h, out_w), dtype=np.uint8)
         _check(cls._l().dlimg_amd_resize_mask(mask.ctypes.data, w, h, mask.strides[0], out_w, out_h, out.ctypes.data))
         return out
+
+    @classmethod
+    def bench_attention(cls, is_global: bool, heads: int = 12, hd: int = 64, batch: int = 1, iters: int = 50) -> float:
+        """ms per launch of the encoder attention kernel alone, device-resident random data."""
+        ms = C.c_double()
+        _check(cls._l().dlimg_amd_bench_attention(int(is_global), batch, heads, hd, iters, C.byref(ms)))
+        return ms.value
 
     @classmethod
     def bench_gemm(cls, M: int, N: int, K: int, act: int = 0, iters: int = 20, flavour: int = 0, tile: int = -1,

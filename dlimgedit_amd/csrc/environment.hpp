@@ -64,6 +64,8 @@ class EnvironmentImpl {
     SamModel& next_lane(int replica);
     SamModel& lane(int replica, int index);
     int lane_count(int replica = 0);
+    // lanes that requests are really spread over (1 while set_single_lane is on)
+    int effective_lane_count(int replica = 0) { return single_lane_.load() ? 1 : lane_count(replica); }
     // Replica for the next independent image (round-robin over the device list).
     int next_replica() { return replicas_.size() == 1 ? 0 : int(next_replica_.fetch_add(1) % replicas_.size()); }
     // Loads the model on every replica (reports a missing weight file where the reference does).

@@ -206,16 +206,28 @@ void run_device_steps(EnvironmentImpl& env, EnvironmentImpl::PendingStep const* 
     m.masks_on_device(jobs.data(), count);
 }
 
-// Launches what is waiting: passes of `width` images while at least that many wait; everything with `all`.
-// pending_mutex held by the caller.
+// Launches what is waiting.  Requests are launched in WAVES of one pass per lane: once lanes x `coalesce` requests wait,
+// every lane gets one pass of `coalesce` images; with `all` (dlimg_amd_synchronize) the rest is dealt over the lanes as
+// evenly as possible (pass sizes differ by at most one).  A burst of K requests therefore ends with every lane holding
+// the same number of images (K = 20, four lanes, two per pass: 2 + 2 + 1 on every lane) instead of two lanes finishing
+// a whole pass after the others.  pending_mutex held by the caller.
 void flush_device_steps(EnvironmentImpl& env, bool all) {
     const size_t width = (size_t)std::max(1, env.coalesce);
+    const size_t lanes = (size_t)std::max(1, env.effective_lane_count(0));
+    const size_t wave = width * lanes;
     size_t done = 0;
     try {
-        while (env.pending.size() - done >= width || (all && done < env.pending.size())) {
-            const size_t n = std::min(width, env.pending.size() - done);
-            run_device_steps(env, env.pending.data() + done, (int)n);
-            done += n;
+        while (env.pending.size() - done >= wave) {
+            for (size_t l = 0; l < lanes; ++l, done += width) run_device_steps(env, env.pending.data() + done, (int)width);
+        }
+        if (all && done < env.pending.size()) {
+            const size_t rest = env.pending.size() - done;
+            const size_t passes = std::min(lanes, rest);
+            for (size_t p = 0; p < passes; ++p) {
+                const size_t n = rest / passes + (p < rest % passes ? 1 : 0);
+                run_device_steps(env, env.pending.data() + done, (int)n);
+                done += n;
+            }
         }
     } catch (...) {
         env.pending.clear();         // a failed pass must not be retried by the next call
@@ -553,6 +565,47 @@ DLIMG_API int dlimg_amd_resize_mask(uint8_t const* mask, int width, int height, 
         k::resize_srgb(src.get(), width, height, stride, 1, ax, ay, dlut.get(), nullptr, tmp.get(), dst.get(), nullptr);
         HIP_CHECK(hipDeviceSynchronize());
         download(out_mask, dst.get(), (size_t)out_w * out_h);
+    });
+}
+
+DLIMG_API int dlimg_amd_bench_attention(int global, int batch, int heads, int hd, int iters, double* out_ms) {
+    return guarded([&] {
+        require_gpu();
+        DLIMG_ASSERT(batch > 0 && batch <= 16 && heads > 0 && heads <= 32 && (hd == 64 || hd == 80) && iters > 0 && out_ms);
+        const int D = heads * hd, span = global ? 64 : 14;
+        const size_t rows = (size_t)batch * kTokens, nrel = (size_t)(2 * span - 1) * hd;
+        std::vector<half_t> hq(rows * 3 * D);
+        std::vector<float> hb(3 * D), hrel(nrel);
+        uint32_t seed = 777u;
+        auto rnd = [&] { seed = seed * 1664525u + 1013904223u; return ((seed >> 8) & 0xffff) / 32768.0f - 1.0f; };
+        for (auto& v : hq) v = (half_t)(rnd() * 1.5f);
+        for (auto& v : hb) v = rnd() * 0.2f;
+        for (auto& v : hrel) v = rnd() * 0.3f;
+        Upload<half_t> dq(hq.data(), hq.size());
+        Upload<float> db(hb.data(), hb.size()), dh(hrel.data(), nrel), dw(hrel.data(), nrel);
+        DeviceBuffer<half_t> o(rows * D), dh16(nrel), dw16(nrel);
+        hipStream_t st;
+        HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        k::cast_f16(dh.get(), dh16.get(), nrel, st);
+        k::cast_f16(dw.get(), dw16.get(), nrel, st);
+        auto launch = [&] {
+            if (global) k::attention_global(dq.get(), dh16.get(), dw16.get(), o.get(), batch, heads, hd, st);
+            else k::attention_window(dq.get(), db.get(), dh.get(), dw.get(), o.get(), batch, heads, hd, st);
+        };
+        for (int i = 0; i < 3; ++i) launch();
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipEventRecord(e0, st));
+        for (int i = 0; i < iters; ++i) launch();
+        HIP_CHECK(hipEventRecord(e1, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        *out_ms = ms / iters;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        (void)hipStreamDestroy(st);
     });
 }
 

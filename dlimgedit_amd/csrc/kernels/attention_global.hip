@@ -302,7 +302,11 @@ __global__ __launch_bounds__(256, 2) void attention_global_kernel(const half_t* 
 //   V(t-2), ended at 2t-1) and then requests K(t+2) and V(t+1) into the same registers.
 // ABL (tuning builds only, wrong results): 1 = no softmax arithmetic, 2 = no MFMAs in the M slot, 3 = neither,
 // 4 = per-slot cycle counters written over the start of `out`
-template <int HD, int ABL = 0>
+// VAR (bit mask; the product build uses kPPVariant, the tuning build lets DLIMGEDIT_ATTN_VAR choose):
+//   1 = no s_setprio around the MFMAs of the M slot, 2 = softmax arithmetic on single values (v_fma_f32 / v_add_f32
+//   through asm helpers, so the compiler does not pack them) instead of v_pk_*_f32, 4 = row sum and f16 conversion of P
+//   moved from the X slot into the next M slot (implies 2), 8 = waves 4-7 run at priority 1 throughout
+template <int HD, int ABL = 0, int VAR = 0>
 __global__ __launch_bounds__(512, 2) void attention_global_pp_kernel(const half_t* __restrict__ qkv,
                                                                      const half_t* __restrict__ rel_h,
                                                                      const half_t* __restrict__ rel_w,
@@ -448,6 +452,7 @@ __global__ __launch_bounds__(512, 2) void attention_global_pp_kernel(const half_
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) o[dt] = zero16();
     float m = -INFINITY, l = 0.f;
+    float alpha_prev = 1.0f;    // VAR & 4: rescale factor of the tile whose row sum is still to be added (see finish_softmax)
     float16_t s[2];
     half8_t pf[2][2];           // P(t) as B-operand fragments: [jt][st]
 
@@ -511,12 +516,46 @@ __global__ __launch_bounds__(512, 2) void attention_global_pp_kernel(const half_
             mx[g] = max3(s[e0 >> 4][e0 & 15], s[e1 >> 4][e1 & 15], s[e2 >> 4][e2 & 15]);
         }
         float tm = max3(max3(mx[0], mx[1], mx[2]), max3(mx[3], mx[4], mx[5]), max3(mx[6], mx[7], mx[8]));
-        tm = max3(tm, mx[9], max3(s[1][14], s[1][15], s[1][15]));
-        tm = max3(tm, swap_halves(tm), tm) + rh;
+        if (VAR & 6) {
+            // the other half's maximum without an LDS round trip (ds_bpermute sits in the slot's serial chain: every
+            // exponent argument waits for it): v_permlane32_swap on two copies of tm leaves tm of lanes 0-31 in one and tm
+            // of lanes 32-63 in the other, in every lane.  As ONE asm statement with its own wait states: two before (a
+            // vector write of an operand, whoever made it) and one behind; the builtin form is not usable here -- hipcc
+            // 7.2 folds fmax(result0, result1) of a swap of two equal operands to result0 (checked on the device).
+            tm = max3(tm, mx[9], max3(s[1][14], s[1][15], s[1][15]));
+            float ta = tm, tb = tm;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(ta), "+v"(tb));
+            tm = max3(ta, tb, tb) + rh;
+        } else {
+            tm = max3(tm, mx[9], max3(s[1][14], s[1][15], s[1][15]));
+            tm = max3(tm, swap_halves(tm), tm) + rh;
+        }
         const float m_new = fmaxf(m, tm);
         const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c);
         const float off = (rh - m_new) * c;
         m = m_new;
+        if (VAR & 4) {
+            // the exponentials only; row sum and f16 conversion wait for the next M slot (finish_softmax)
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[jt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[jt][r], c, off));
+            alpha_prev = alpha;
+        } else if (VAR & 2) {
+            // single-value arithmetic written as plain C (the file is built with -fno-slp-vectorize so it stays that way;
+            // asm helpers are not an option here: an asm v_add that reads a fresh v_exp result misses the wait state the
+            // compiler inserts between its own instructions -- wrong sums, measured)
+            float ps1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[jt][r], c, off));
+                    s[jt][r] = p;
+                    ps1[r & 3] += p;
+                }
+            l = l * alpha + ((ps1[0] + ps1[1]) + (ps1[2] + ps1[3]));
+        } else {
         float2_t ps[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
         const float2_t c2 = {c, c}, off2 = {off, off};
 #pragma unroll
@@ -531,12 +570,33 @@ __global__ __launch_bounds__(512, 2) void attention_global_pp_kernel(const half_
             }
         const float2_t pss = (ps[0] + ps[1]) + (ps[2] + ps[3]);
         l = l * alpha + (pss[0] + pss[1]);
+        }
         if (!__all(alpha == 1.0f)) {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
         }
+        if (!(VAR & 4)) {
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[jt][st][e] = (half_t)s[jt][st * 8 + e];
+        }
+    };
+    // VAR & 4: the part of the softmax that the MFMAs of the NEXT M slot do not have to wait for is done inside that M
+    // slot, behind its LDS requests and before its first MFMA (which overwrites s): row sum of P(t-1), l, P(t-1) -> f16.
+    // The X slot is the longer one (1280 against 900-1200 cycles measured); the M slot spends ~300 cycles waiting for
+    // its first fragments, which is where this work now sits.
+    auto finish_softmax = [&] {
+        float ps1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ps1[r & 3] += s[jt][r];
+        l = l * alpha_prev + ((ps1[0] + ps1[1]) + (ps1[2] + ps1[3]));
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
@@ -574,7 +634,11 @@ __global__ __launch_bounds__(512, 2) void attention_global_pp_kernel(const half_
                         }
             }
             __builtin_amdgcn_sched_barrier(0);   // all requests first
-            __builtin_amdgcn_s_setprio(2);       // the MFMA stream wins the issue arbitration; the partner's VALU fills its gaps
+            if ((VAR & 4) && t > 0) {
+                finish_softmax();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!(VAR & 1)) __builtin_amdgcn_s_setprio(2);       // the MFMA stream wins the issue arbitration; the partner's VALU fills its gaps
             if (t < NT) {
 #pragma unroll
                 for (int jt = 0; jt < 2; ++jt)
@@ -598,8 +662,9 @@ __global__ __launch_bounds__(512, 2) void attention_global_pp_kernel(const half_
                             else o[dt] = mfma32(vf, pf[jt][st], o[dt]);
                         }
             }
-            __builtin_amdgcn_s_setprio(0);
+            if (!(VAR & 1)) __builtin_amdgcn_s_setprio(0);
         } else {
+            if ((VAR & 4) && t > 0) finish_softmax();
             if (t < NT) scores(t);
             if (t > 0) values(t - 1);
         }
@@ -611,6 +676,7 @@ __global__ __launch_bounds__(512, 2) void attention_global_pp_kernel(const half_
         }
     };
 
+    if ((VAR & 8) && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);   // T5, static form
     if (group == 1) slot_end();                  // group B runs one slot behind group A
     unsigned long long tm = 0, tmb = 0, tx = 0, txb = 0, c_start = 0, r_start = 0, c_loop = 0, r_loop = 0;
     if (ABL == 4) {
@@ -681,6 +747,8 @@ __global__ __launch_bounds__(512, 2) void attention_global_pp_kernel(const half_
 }
 
 
+constexpr int kPPVariant = 3;        // VAR of the product build (see attention_global_pp_kernel): 105 -> 92 us per ViT-B launch
+
 template <int HD>
 void launch_global(const half_t* qkv, const half_t* rel_h, const half_t* rel_w, half_t* out, int B, int heads,
                    hipStream_t s) {
@@ -692,6 +760,28 @@ void launch_global(const half_t* qkv, const half_t* rel_h, const half_t* rel_w, 
 #ifdef DLIMG_TUNING     // tuning build only (python -m dlimgedit_amd.build --tuning): ablated variants with WRONG results
     static const int ablate = [] { const char* e = std::getenv("DLIMGEDIT_ATTN_ABLATE"); return e ? std::atoi(e) : 0; }();
     static const int pp_abl = [] { const char* e = std::getenv("DLIMGEDIT_ATTN_PP_ABLATE"); return e ? std::atoi(e) : 0; }();
+    static const int pp_var = [] { const char* e = std::getenv("DLIMGEDIT_ATTN_VAR"); return e ? std::atoi(e) : -1; }();
+    if (pingpong && !ablate && !pp_abl && pp_var >= 0 && pp_var <= 15) {
+        typedef void (*PPK)(const half_t*, const half_t*, const half_t*, half_t*, int);
+        static const PPK variants[16] = {
+            attention_global_pp_kernel<HD, 0, 0>,  attention_global_pp_kernel<HD, 0, 1>,  attention_global_pp_kernel<HD, 0, 2>,
+            attention_global_pp_kernel<HD, 0, 3>,  attention_global_pp_kernel<HD, 0, 4>,  attention_global_pp_kernel<HD, 0, 5>,
+            attention_global_pp_kernel<HD, 0, 6>,  attention_global_pp_kernel<HD, 0, 7>,  attention_global_pp_kernel<HD, 0, 8>,
+            attention_global_pp_kernel<HD, 0, 9>,  attention_global_pp_kernel<HD, 0, 10>, attention_global_pp_kernel<HD, 0, 11>,
+            attention_global_pp_kernel<HD, 0, 12>, attention_global_pp_kernel<HD, 0, 13>, attention_global_pp_kernel<HD, 0, 14>,
+            attention_global_pp_kernel<HD, 0, 15>};
+        static k::LdsOptIn once[16];
+        once[pp_var].ensure((const void*)variants[pp_var], pp_lds, "attention_global: the device refuses the kernel's LDS size");
+        hipLaunchKernelGGL(variants[pp_var], dim3(B * heads * (TOKENS / 256)), dim3(512), pp_lds, s, qkv, rel_h, rel_w, out, heads);
+        return;
+    }
+    if (HD == 64 && pingpong && !ablate && pp_abl == 4 && pp_var == 3) {       // slot stamps of variant 3
+        auto ppk = attention_global_pp_kernel<HD, 4, 3>;
+        static k::LdsOptIn once;
+        once.ensure((const void*)ppk, pp_lds, "attention_global: the device refuses the kernel's LDS size");
+        hipLaunchKernelGGL(ppk, dim3(B * heads * (TOKENS / 256)), dim3(512), pp_lds, s, qkv, rel_h, rel_w, out, heads);
+        return;
+    }
     if (HD == 64 && pingpong && !ablate && pp_abl >= 1 && pp_abl <= 4) {
         auto ppk = pp_abl == 1 ? attention_global_pp_kernel<HD, 1> : pp_abl == 2 ? attention_global_pp_kernel<HD, 2>
                    : pp_abl == 3 ? attention_global_pp_kernel<HD, 3> : attention_global_pp_kernel<HD, 4>;
@@ -711,8 +801,8 @@ void launch_global(const half_t* qkv, const half_t* rel_h, const half_t* rel_w, 
 #endif
     if (pingpong) {
         static k::LdsOptIn once;       // one per template instance; state per device (lanes and replicas launch concurrently)
-        once.ensure((const void*)attention_global_pp_kernel<HD, 0>, pp_lds, "attention_global: the device refuses the kernel's LDS size");
-        hipLaunchKernelGGL((attention_global_pp_kernel<HD, 0>), dim3(B * heads * (TOKENS / 256)), dim3(512), pp_lds, s, qkv,
+        once.ensure((const void*)attention_global_pp_kernel<HD, 0, kPPVariant>, pp_lds, "attention_global: the device refuses the kernel's LDS size");
+        hipLaunchKernelGGL((attention_global_pp_kernel<HD, 0, kPPVariant>), dim3(B * heads * (TOKENS / 256)), dim3(512), pp_lds, s, qkv,
                            rel_h, rel_w, out, heads);
         return;
     }

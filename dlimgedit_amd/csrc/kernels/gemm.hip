@@ -1165,9 +1165,6 @@ constexpr TileCfg kTiles[] = {
     {256, 256, 1, 1.60f},   // 9: ping-pong kernel (gemm_pp_kernel): 8 waves in two groups one barrier apart, BK 64
                             //    (4096^3: 1300 TFLOP/s at the 1.4 GHz the chip holds under that load)
     {128, 256, 1, 0.00f},   // 10: 128 x 256 ping-pong kernel (gemm_pp128_kernel), one read slot + one MFMA slot per K tile
-    {128, 256, 2, 0.00f},   // 11: 4 waves 2x2 (64x128 each) on 16x16x32, BK 32, 3 stages, 75 KB LDS: TWO workgroups per CU, so
-                            //     one's prologue / epilogue runs beside the other's main loop (forced only until measured)
-    {256, 128, 2, 0.00f},   // 12: as 11 with 128x64 wave tiles
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -1253,8 +1250,6 @@ void gemm(const GemmArgs& a, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
     case 8: return launch16<128, 128, 2, 2, 4, 2>(a, s, t);
     case 9: return launch_pp(a, s, t);
     case 10: return launch_pp128(a, s, t);
-    case 11: return launch16<128, 256, 2, 2, 3, 2>(a, s, t);
-    case 12: return launch16<256, 128, 2, 2, 3, 2>(a, s, t);
     default: throw_error("gemm: no tile configuration fits this shape");
     }
 }

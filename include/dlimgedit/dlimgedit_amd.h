@@ -46,8 +46,9 @@ DLIMG_API int dlimg_amd_copy_to_host(dlimg_Environment env, void* dst_host, void
  * dev_masks[i] (width*height bytes each, device memory).  Views carry DEVICE pixel pointers.
  * points: count x {x,y}.  Asynchronous: returns once the request is accepted; call dlimg_amd_synchronize to wait.
  * Independent single-image requests are coalesced into batched passes of DLIMGEDIT_COALESCE images (default 2, 1 = off;
- * dynamic batching -- the results are bit-identical to single-image passes); a request that is still waiting for a
- * partner is launched by the next request or by dlimg_amd_synchronize. */
+ * dynamic batching -- the results are bit-identical to single-image passes) and launched in waves of one pass per
+ * execution lane; requests that are still waiting are launched by a later request that completes the wave or by
+ * dlimg_amd_synchronize, which deals them evenly over the lanes. */
 DLIMG_API int dlimg_amd_encode_and_mask(dlimg_Environment env, dlimg_ImageView const* dev_images, int count,
                                         int const* points, uint8_t* const* dev_masks);
 /* Encode only / decode only variants of the above, for per-stage rates. */
@@ -130,6 +131,9 @@ DLIMG_API int dlimg_amd_birefnet_prepare_image(uint8_t const* pixels, int width,
 DLIMG_API int dlimg_amd_birefnet_process_mask(float const* logits, int width, int height, uint8_t* out_mask);
 DLIMG_API int dlimg_amd_resize_mask(uint8_t const* mask, int width, int height, int stride, int out_w, int out_h,
                                     uint8_t* out_mask);
+/* Times `iters` back-to-back launches of an encoder attention kernel (global != 0: the 4096-token kernel, else the 14x14
+ * windowed one) on device-resident random data of `batch` images; returns the average ms per launch. */
+DLIMG_API int dlimg_amd_bench_attention(int global, int batch, int heads, int hd, int iters, double* out_ms);
 /* Times `iters` launches of the GEMM on device-resident random operands; returns average ms per launch.
  * flavour 0: f16 output; 1: LayerNorm folded in; 2: bias + fp32 residual in place; 3: 2 + f16 copy of the result + row statistics;
  * 4: f16 output with bias. */

@@ -25,8 +25,16 @@ import os
 if os.environ.get("DLIMGEDIT_ATTN_PP_ABLATE") == "4":
     o = np.ascontiguousarray(out)                      # [4096][D] f16
     rows = []
-    for b in range(0, heads * 16, 3):                  # blocks with blockIdx % 3 == 0: (qblk, head) = (b % 16, b // 16)
-        qblk, head = b % 16, b // 16
+    nwg = heads * 16
+
+    def xcd_remap(b):                                  # as device_common.hpp (the kernel maps blockIdx -> logical block)
+        q, r = nwg // 8, nwg % 8
+        xcd, k = b % 8, b // 8
+        return (xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q) + k
+
+    for b in range(0, nwg, 3):                         # blocks with blockIdx % 3 == 0 hold stamps
+        bid = xcd_remap(b)
+        qblk, head = bid % 16, bid // 16
         r0 = o[qblk * 256, head * hd:head * hd + 32].view(np.uint64).astype(np.float64)      # A: tm tmb tx txb, B: ...
         r1 = o[qblk * 256 + 1, head * hd:head * hd + 16].view(np.uint64).astype(np.float64)
         rows.append(np.concatenate([r0, r1]))
