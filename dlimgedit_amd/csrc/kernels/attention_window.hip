@@ -13,11 +13,12 @@
 // Slots are numbered ty*16 + tx (tx = 14, 15 are dummies), which makes 224 = 7*32 slots and lets
 // every MFMA accumulator register know its key's (ty, tx) at compile time.
 // Per wave:   G   = rel_pos . Q^T   (MFMA, 27 rows each for h and w)  -> per-lane bias registers
-//             S^T = K . Q^T + bias/scale   (swapped operands: a lane owns one query column)
-//             softmax over the 224 key slots entirely in registers (+ one exchange between halves)
-//             O   = P . V   with the accumulator tiles re-used directly as the A operand and V read
-//                           through ds_read_b64_tr_b16 from its row-major LDS image.
-// LDS: the rel-pos scratch of the prologue aliases the K/V images (75 KB total -> 2 workgroups per CU).
+//             S^T = K . Q^T + bias/scale   (swapped operands: a lane owns one query column), computed twice:
+//                   once for the exact row maximum, once more tile by tile for the probabilities
+//             O^T = V^T . P^T   with the S^T accumulator tile as the B operand as it stands and V^T read
+//                   through ds_read_b64_tr_b16 from V's row-major LDS image; lane = query, so 1 / rowsum is lane-local
+//             O leaves through an LDS slab as whole 128-byte rows.
+// LDS: the rel-pos scratch of the prologue and the output slabs alias the K / V images (75 KB -> 2 workgroups per CU).
 #include "device_common.hpp"
 #include "kernels.hpp"
 
@@ -48,8 +49,10 @@ DLIMG_DEVICE WinSlot win_slot(int slot, int wy, int wx) {
     return s;
 }
 
+// Registers: head dimension 64 is held to 128 VGPRs (4 waves per SIMD = two 7-wave workgroups per CU; LDS 75 KB each);
+// head dimension 80 needs 82 KB of LDS per workgroup, so one per CU whatever the registers.
 template <int HD>
-__global__ __launch_bounds__(448) void attention_window_kernel(const half_t* __restrict__ qkv,
+__global__ __launch_bounds__(448, HD == 64 ? 4 : 2) void attention_window_kernel(const half_t* __restrict__ qkv,
                                                                const float* __restrict__ qkv_bias,
                                                                const float* __restrict__ rel_h,
                                                                const float* __restrict__ rel_w,
@@ -120,8 +123,8 @@ __global__ __launch_bounds__(448) void attention_window_kernel(const half_t* __r
     // ---- decomposed rel-pos: G[r][i] = rel[r] . q_i  via MFMA, gathered into per-lane registers ----
     float* g = lds_g + wave * 32 * G_STRIDE;
     const int ty_q = qslot >> 4, tx_q = qslot & 15;
-    float bh[WS];       // bias from the key's row, index = key ty
-    float bw[8];        // bias from the key's column, index e <-> tx = (e&3) + 8*(e>>2) + 4*hi
+    float bh[WS];       // bias / scale from the key's row, index = key ty
+    float bw[8];        // bias / scale from the key's column, index e <-> tx = (e&3) + 8*(e>>2) + 4*hi
     {
         // both tables' fragments are requested before the first MFMA: one memory latency, not two
         half8_t rfh[KS], rfw[KS];
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(448) void attention_window_kernel(const half_t* __r
         for (int r = 0; r < 16; ++r) g[l31 * G_STRIDE + acc_row(r, hi)] = acc[r];
         __syncthreads();
 #pragma unroll
-        for (int ky = 0; ky < WS; ++ky) bh[ky] = g[l31 * G_STRIDE + ty_q + (WS - 1) - ky];
+        for (int ky = 0; ky < WS; ++ky) bh[ky] = g[l31 * G_STRIDE + ty_q + (WS - 1) - ky] * sqrtf((float)HD);
         __syncthreads();
         acc = zero16();
 #pragma unroll
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(448) void attention_window_kernel(const half_t* __r
         for (int e = 0; e < 8; ++e) {
             const int tx = (e & 3) + 8 * (e >> 2) + 4 * hi;
             // dummy key columns (tx >= 14) are removed from the softmax by a -inf bias
-            bw[e] = tx < WS ? g[l31 * G_STRIDE + tx_q + (WS - 1) - tx] : -INFINITY;
+            bw[e] = tx < WS ? g[l31 * G_STRIDE + tx_q + (WS - 1) - tx] * sqrtf((float)HD) : -INFINITY;
         }
         __syncthreads();        // scratch is dead; K / V images may be written over it
     }
@@ -182,58 +185,80 @@ __global__ __launch_bounds__(448) void attention_window_kernel(const half_t* __r
     __syncthreads();
 
     const float scale = rsqrtf((float)HD);
-    const float inv_scale = sqrtf((float)HD);
 
-    // ---- S^T = K . Q^T, accumulators initialised with bias/scale -----------------------------------
-    float16_t s[7];
-#pragma unroll
-    for (int jt = 0; jt < 7; ++jt) {
+    // ---- S^T tile jt (32 key slots x this wave's 32 queries) = K . Q^T on top of bias / scale ------------------
+    // Two passes over the seven key tiles instead of keeping all 224 scores of a query in registers (112 VGPRs):
+    //   pass 1   scores -> running maximum, nothing kept
+    //   pass 2   scores again -> p = exp2((s - m) c) -> row sum, f16 -> O^T += V^T . P^T tile by tile
+    // The 28 extra MFMAs are ~0.5 us of matrix time; what they buy is a kernel of <= 128 VGPRs (head dimension 64), i.e.
+    // TWO workgroups per CU: this kernel is a chain of dependent latencies (global loads, LDS round trips, barriers;
+    // 12 us per workgroup for 1 us of MFMA work) and a second resident workgroup runs in the gaps of the first.  One
+    // exact maximum per query, fixed summation order: deterministic, no online rescaling.
+    auto score_tile = [&](int jt) {
+        float16_t t;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ty = jt * 2 + (r >> 3);
             const int e = (r & 3) + 4 * ((r >> 2) & 1);
-            s[jt][r] = (bh[ty] + bw[e]) * inv_scale;
+            t[r] = bh[ty] + bw[e];                 // both already divided by the softmax scale
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             half8_t kf = *reinterpret_cast<const half8_t*>(lds_k + (jt * 32 + l31) * K_STRIDE + ks * 16 + hi * 8);
-            s[jt] = mfma32(kf, qf[ks], s[jt]);
+            t = mfma32(kf, qf[ks], t);
         }
-    }
-
-    // ---- softmax over the 224 key slots of this lane's query --------------------------------------
+        return t;
+    };
+    // Head dimension 80 cannot have two workgroups per CU anyway (82 KB of LDS each): it keeps the scores of the first
+    // pass (112 registers) instead of recomputing them.
+    constexpr bool TWO_PASS = HD == 64;
+    float16_t kept[TWO_PASS ? 1 : 7];
     float m = -INFINITY;
 #pragma unroll
-    for (int jt = 0; jt < 7; ++jt)
+    for (int jt = 0; jt < 7; ++jt) {
+        const float16_t t = score_tile(jt);
+        if (!TWO_PASS) kept[jt] = t;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) m = fmaxf(m, s[jt][r]);
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, t[r]);
+        // the loops are fully unrolled (bias registers are indexed by the tile); without a fence per tile the scheduler
+        // hoists the fragment reads of all seven tiles to the front and the kernel no longer fits 128 registers
+        __builtin_amdgcn_sched_barrier(0);
+    }
     m = fmaxf(m, swap_halves(m));
     const float c = scale * 1.44269504088896341f;
-    float l = 0.f;
+    const float mc = -m * c;
+    // The second pass must really recompute: seen through, the compiler keeps the 112 scores of the first pass alive
+    // (common subexpressions) and the kernel is back at 180 registers.  The bias registers are made opaque here, so
+    // nothing computed from them before this point is known to equal anything computed after it.
+    if (TWO_PASS) {
 #pragma unroll
-    for (int jt = 0; jt < 7; ++jt)
+        for (int i = 0; i < WS; ++i) asm volatile("" : "+v"(bh[i]));
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float p = __builtin_amdgcn_exp2f((s[jt][r] - m) * c);
-            s[jt][r] = p;
-            l += p;
-        }
-    l += swap_halves(l);
-    const float inv_l = 1.0f / l;
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(bw[i]));
+    }
 
-    // ---- O = P . V : accumulator tiles become A operands; V^T fragments by hardware transpose read ----
-    // in each 16-lane group, lane 4q+p points at key row q, columns 4p..4p+3 of a 4-key x 16-column block
+    // ---- O^T = V^T . P^T : the S^T accumulator tile is the B operand as it stands (lane = query); V^T fragments by
+    // hardware transpose read.  In each 16-lane group, lane 4q+p points at key row q, columns 4p..4p+3 of a 4-key x
+    // 16-column block.  Lane = query for the result too, so the normalisation by the row sum is lane-local.
     const half_t* vb = lds_v + ((hi * 4 + ((lane & 15) >> 2)) * V_STRIDE) + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
     float16_t o[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) o[dt] = zero16();
+    float l = 0.f;
 #pragma unroll
     for (int jt = 0; jt < 7; ++jt) {
+        float16_t t = TWO_PASS ? score_tile(jt) : kept[TWO_PASS ? 0 : jt];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(t[r], c, mc));
+            t[r] = pv;
+            l += pv;
+        }
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             half8_t pf;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) pf[e] = (half_t)(s[jt][st * 8 + e] * inv_l);
+            for (int e = 0; e < 8; ++e) pf[e] = (half_t)t[st * 8 + e];
             const int key0 = jt * 32 + st * 16;         // element e <-> key0 + 4*hi + 8*(e>>2) + (e&3)
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
@@ -242,21 +267,44 @@ __global__ __launch_bounds__(448) void attention_window_kernel(const half_t* __r
                 const short4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_t*)(vp + 8 * V_STRIDE));
                 const half4_t h0 = __builtin_bit_cast(half4_t, v0), h1 = __builtin_bit_cast(half4_t, v1);
                 half8_t vf = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-                o[dt] = mfma32(pf, vf, o[dt]);
+                o[dt] = mfma32(vf, pf, o[dt]);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
+    l += swap_halves(l);
+    const float inv_l = 1.0f / l;
 
-    // ---- store: register r <-> query slot wave*32 + acc_row(r, hi), lane <-> d ---------------------
+    // ---- store.  O^T[d][query]: lane = query, registers = 4-runs of d.  Written straight from here a store
+    // instruction would touch 32 rows with 8 bytes each; instead the wave's 32 x HD block goes through an LDS slab (the
+    // K image is dead once every wave has left the loop above) and leaves as whole rows, 16 bytes per lane.
+    __syncthreads();
+    constexpr int ROWB = HD * 2 + 16;                    // slab row in bytes (padded: the 8-byte writes of a wave spread over the banks)
+    static_assert(7 * 32 * ROWB <= SLOTS * K_STRIDE * 2, "output slabs must fit in the K image");
+    char* slab = smem + wave * 32 * ROWB;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const WinSlot os = win_slot(wave * 32 + acc_row(r, hi), wy, wx);
-        if (os.dummy || os.pad) continue;
-        half_t* orow = out + ((size_t)img * 4096 + os.token) * D + head * HD;
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const int d = dt * 32 + l31;
-            if (d < HD) orow[d] = (half_t)o[dt][r];
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int d0 = dt * 32 + 8 * g4 + 4 * hi;
+            if (d0 < HD) {
+                const half4_t v = {(half_t)(o[dt][g4 * 4 + 0] * inv_l), (half_t)(o[dt][g4 * 4 + 1] * inv_l),
+                                   (half_t)(o[dt][g4 * 4 + 2] * inv_l), (half_t)(o[dt][g4 * 4 + 3] * inv_l)};
+                *reinterpret_cast<half4_t*>(slab + l31 * ROWB + d0 * 2) = v;
+            }
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slab is private to the wave: wave-local ordering is enough
+    constexpr int NIT = (32 * CHUNKS + 63) / 64;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = it * 64 + lane;
+        const int row = idx / CHUNKS, ch = idx % CHUNKS;
+        if (row < 32) {
+            const WinSlot os = win_slot(wave * 32 + row, wy, wx);
+            if (!os.dummy && !os.pad) {
+                const float4_t v = *reinterpret_cast<const float4_t*>(slab + row * ROWB + ch * 16);
+                *reinterpret_cast<float4_t*>(out + ((size_t)img * 4096 + os.token) * D + head * HD + ch * 8) = v;
+            }
         }
     }
 }
