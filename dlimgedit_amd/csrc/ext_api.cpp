@@ -206,19 +206,18 @@ void run_device_steps(EnvironmentImpl& env, EnvironmentImpl::PendingStep const* 
     m.masks_on_device(jobs.data(), count);
 }
 
-// Launches what is waiting.  Requests are launched in WAVES of one pass per lane: once lanes x `coalesce` requests wait,
-// every lane gets one pass of `coalesce` images; with `all` (dlimg_amd_synchronize) the rest is dealt over the lanes as
-// evenly as possible (pass sizes differ by at most one).  A burst of K requests therefore ends with every lane holding
-// the same number of images (K = 20, four lanes, two per pass: 2 + 2 + 1 on every lane) instead of two lanes finishing
-// a whole pass after the others.  pending_mutex held by the caller.
+// Launches what is waiting: one pass of `coalesce` images on the next lane as soon as that many requests wait; with `all`
+// (dlimg_amd_synchronize) the rest is dealt over the lanes as evenly as possible (pass sizes differ by at most one).
+// [Holding requests back until a whole wave of lanes x coalesce had arrived was measured and gained nothing on a burst of
+// 20 requests, while it delays the first launch.]  pending_mutex held by the caller.
 void flush_device_steps(EnvironmentImpl& env, bool all) {
     const size_t width = (size_t)std::max(1, env.coalesce);
     const size_t lanes = (size_t)std::max(1, env.effective_lane_count(0));
-    const size_t wave = width * lanes;
     size_t done = 0;
     try {
-        while (env.pending.size() - done >= wave) {
-            for (size_t l = 0; l < lanes; ++l, done += width) run_device_steps(env, env.pending.data() + done, (int)width);
+        while (env.pending.size() - done >= width) {
+            run_device_steps(env, env.pending.data() + done, (int)width);
+            done += width;
         }
         if (all && done < env.pending.size()) {
             const size_t rest = env.pending.size() - done;

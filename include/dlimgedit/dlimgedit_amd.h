@@ -46,9 +46,8 @@ DLIMG_API int dlimg_amd_copy_to_host(dlimg_Environment env, void* dst_host, void
  * dev_masks[i] (width*height bytes each, device memory).  Views carry DEVICE pixel pointers.
  * points: count x {x,y}.  Asynchronous: returns once the request is accepted; call dlimg_amd_synchronize to wait.
  * Independent single-image requests are coalesced into batched passes of DLIMGEDIT_COALESCE images (default 2, 1 = off;
- * dynamic batching -- the results are bit-identical to single-image passes) and launched in waves of one pass per
- * execution lane; requests that are still waiting are launched by a later request that completes the wave or by
- * dlimg_amd_synchronize, which deals them evenly over the lanes. */
+ * dynamic batching -- the results are bit-identical to single-image passes); a request that is still waiting for a
+ * partner is launched by the next request or by dlimg_amd_synchronize (which deals what is left evenly over the lanes). */
 DLIMG_API int dlimg_amd_encode_and_mask(dlimg_Environment env, dlimg_ImageView const* dev_images, int count,
                                         int const* points, uint8_t* const* dev_masks);
 /* Encode only / decode only variants of the above, for per-stage rates. */
