@@ -264,6 +264,9 @@ def main() -> None:
             "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": None, "traffic_static": traffic_static,
             "mode": "all lanes, as the timed region: a GEMM shares the chip with the other lanes' kernels while it is clocked",
             "launches": gl["launches"], "avg_launch_us": 1e3 * gl["ms"] / max(1, gl["launches"]),
+            "concurrent_gemm_launches": gl["ms"] / (result["ms_per_step"] * args.steps),
+            "concurrency_note": "sum of the GEMM launches' durations / wall time of the profiled steps: how many GEMM kernels are "
+                                "in flight on average while one of them is being clocked (each holds a share of the CUs)",
             "flops_per_launch": gl["work"] / max(1, gl["launches"]),
             "achieved_single_lane": achieved_alone, "frac_single_lane": achieved_alone / MFMA_F16_PEAK_TFLOPS,
             "avg_launch_us_single_lane": 1e3 * g["ms"] / max(1, g["launches"]),

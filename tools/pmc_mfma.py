@@ -38,7 +38,8 @@ def main():
             a["launches"] += 1
             a["ns"] += dur
         a[counter] = a.get(counter, 0.0) + value
-    out = {"command": "python bench.py --steps 5 --warmup 1 --no-cpu-baseline under rocprofv3 --pmc (kernels serialised)",
+    out = {"command": (sys.argv[3] if len(sys.argv) > 3 else "python bench.py --steps 5 --warmup 1 --no-cpu-baseline")
+                      + " under rocprofv3 --pmc (kernels serialised)",
            "note": "SQ_INSTS_VALU_MFMA_MOPS_F16 = 512 FLOP per unit; peak 2.5 PFLOP/s dense f16", "per_kernel": {}}
     tot_flop = tot_ns = 0.0
     for g, a in acc.items():

@@ -47,7 +47,8 @@ def main():
             "write_bytes_per_launch": 1024.0 * kb_w / max(n_w, 1),
         }
     doc = {
-        "command": "python bench.py --steps 5 --warmup 1 --no-cpu-baseline (separate --pmc passes for FETCH_SIZE and WRITE_SIZE)",
+        "command": (sys.argv[4] if len(sys.argv) > 4 else "python bench.py --steps 5 --warmup 1 --no-cpu-baseline")
+                   + " (separate rocprofv3 --pmc passes for FETCH_SIZE and WRITE_SIZE)",
         "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced reads); "
                 "counters are in KB; includes Infinity-Cache hits",
         "per_kernel": per_kernel,
