@@ -20,15 +20,12 @@ constexpr int NTOK_IMG = 4096;
 // ---------------------------------------------------------------------------------------------
 // Prompt encoder: SamOnnxModel._embed_points applied to the two packed points
 // (segmentation.cpp:135-152 packs them; labels 1/-1 for a point, 2/3 for a box).
-__global__ __launch_bounds__(256) void prompt_tokens_kernel(const float* __restrict__ coords,
-                                                            const float* __restrict__ labels,
-                                                            const float* __restrict__ gauss,
-                                                            const float* __restrict__ point_embed,
-                                                            const float* __restrict__ not_a_point,
-                                                            const float* __restrict__ iou_token,
-                                                            const float* __restrict__ mask_tokens,
-                                                            float* __restrict__ tokens, float* __restrict__ tokens_copy) {
-    const int p = blockIdx.x, c = threadIdx.x;
+DLIMG_DEVICE void prompt_tokens_block(int p, const float* __restrict__ coords, const float* __restrict__ labels,
+                                      const float* __restrict__ gauss, const float* __restrict__ point_embed,
+                                      const float* __restrict__ not_a_point, const float* __restrict__ iou_token,
+                                      const float* __restrict__ mask_tokens, float* __restrict__ tokens,
+                                      float* __restrict__ tokens_copy) {
+    const int c = threadIdx.x;
     float* t = tokens + (size_t)p * TOK * DIM;
     float* t2 = tokens_copy + (size_t)p * TOK * DIM;      // the decoder's running queries start as a copy
     t[c] = t2[c] = iou_token[c];
@@ -290,7 +287,7 @@ __global__ __launch_bounds__(256) void mask_logits_kernel(const float* __restric
 // at one prompt against 9.4 us for this one, 27 against 35 us at five prompts -- scalar weight loads and LDS reads
 // share one counter and serialise.  Not kept.)
 constexpr int TL_MAX_ROWS = 112;              // 16 prompts x 7 tokens per launch
-constexpr int TL_MAX_OPS = 3;
+constexpr int TL_MAX_OPS = 5;
 constexpr int TL_PROMPT_SLICE = 2;           // prompts per workgroup of the fused attention-output kernels
 constexpr int TL_ROW_SLICE = 14;            // rows per workgroup of token_linears_kernel (two prompts)
 
@@ -516,12 +513,29 @@ __global__ __launch_bounds__(256) void token_merge_out_kernel(const float* __res
 // ---------------------------------------------------------------------------------------------
 // Image side, start of a decode: keys = embedding + no_mask_embed (has_mask_input == 0, segmentation.cpp:43-45) as fp32
 // and f16 (the A operand of the image-side projections), for all prompts.
-__global__ __launch_bounds__(256) void decoder_keys_init_kernel(const float* const* __restrict__ emb,
-                                                                const float* __restrict__ no_mask,
-                                                                float* __restrict__ keys, half_t* __restrict__ keys_h,
-                                                                size_t n4_per_prompt, int P) {
+// One launch starts a decode: workgroups 0 .. P-1 build the prompts' tokens (prompt_tokens_block), the others the keys.
+// The two have nothing to do with each other except that both are the first step of their chain -- and every launch of
+// the decoder costs its 5-9 us of dependent latency.
+struct DecoderStart {
+    const float* coords; const float* labels; const float* gauss; const float* point_embed; const float* not_a_point;
+    const float* iou_token; const float* mask_tokens; float* tokens; float* tokens_copy;
+    const float* const* emb; const float* no_mask; float* keys; half_t* keys_h; size_t n4_per_prompt; int P;
+};
+__global__ __launch_bounds__(256) void decoder_start_kernel(DecoderStart a) {
+    if ((int)blockIdx.x < a.P) {
+        prompt_tokens_block(blockIdx.x, a.coords, a.labels, a.gauss, a.point_embed, a.not_a_point, a.iou_token, a.mask_tokens,
+                            a.tokens, a.tokens_copy);
+        return;
+    }
+    const float* const* __restrict__ emb = a.emb;
+    const float* __restrict__ no_mask = a.no_mask;
+    float* __restrict__ keys = a.keys;
+    half_t* __restrict__ keys_h = a.keys_h;
+    const size_t n4_per_prompt = a.n4_per_prompt;
+    const int P = a.P;
     const size_t total = n4_per_prompt * P;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t nblk = gridDim.x - P;
+    for (size_t i = (blockIdx.x - P) * (size_t)blockDim.x + threadIdx.x; i < total; i += nblk * blockDim.x) {
         const size_t p = i / n4_per_prompt, j = i % n4_per_prompt;
         float4_t v = reinterpret_cast<const float4_t*>(emb[p])[j];
         v += reinterpret_cast<const float4_t*>(no_mask)[j % (DIM / 4)];
@@ -550,12 +564,17 @@ __global__ __launch_bounds__(256) void decoder_keys_norm_kernel(float* __restric
 
 namespace k {
 
-void prompt_tokens(const float* coords, const float* labels, const float* gauss, const float* point_embed,
+void decoder_start(const float* coords, const float* labels, const float* gauss, const float* point_embed,
                    const float* not_a_point, const float* iou_token, const float* mask_tokens, float* tokens,
-                   float* tokens_copy, int P, hipStream_t s) {
+                   float* tokens_copy, const float* const* emb_dev, const float* no_mask, float* keys, half_t* keys_h, int P,
+                   hipStream_t s) {
     if (P <= 0) return;
-    hipLaunchKernelGGL(prompt_tokens_kernel, dim3(P), dim3(256), 0, s, coords, labels, gauss, point_embed, not_a_point,
-                       iou_token, mask_tokens, tokens, tokens_copy);
+    const size_t n4 = (size_t)NTOK_IMG * DIM / 4;
+    const size_t total = n4 * P;
+    const int key_blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    DecoderStart a{coords, labels, gauss, point_embed, not_a_point, iou_token, mask_tokens, tokens, tokens_copy,
+                   emb_dev, no_mask, keys, keys_h, n4, P};
+    hipLaunchKernelGGL(decoder_start_kernel, dim3(P + key_blocks), dim3(256), 0, s, a);
 }
 
 size_t token_to_image_scratch_floats(int P) { return (size_t)P * HEADS * TOK * T2I_PARTS * 18; }
@@ -622,15 +641,6 @@ void token_to_image_partials(const float* q, const half_t* K, int ldk, const hal
         throw_error("token_to_image_attention: K/V rows must be 16-byte aligned");
     hipLaunchKernelGGL(token_to_image_partial_kernel, dim3(P * HEADS * T2I_GROUPS), dim3(T2I_THREADS), 0, s, q, K, ldk, V,
                        ldv, scratch);
-}
-
-void decoder_keys_init(const float* const* emb_dev, const float* no_mask, float* keys, half_t* keys_h, int P,
-                       hipStream_t s) {
-    if (P <= 0) return;
-    const size_t n4 = (size_t)NTOK_IMG * DIM / 4;
-    const size_t total = n4 * P;
-    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(decoder_keys_init_kernel, dim3(grid), dim3(256), 0, s, emb_dev, no_mask, keys, keys_h, n4, P);
 }
 
 void decoder_keys_norm(float* keys, const float* w, const float* b, float eps, half_t* keys_h, int P, hipStream_t s) {

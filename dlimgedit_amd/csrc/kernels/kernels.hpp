@@ -116,10 +116,13 @@ void attention_global(const half_t* qkv, const half_t* rel_h, const half_t* rel_
                       int heads, int hd, hipStream_t);
 
 // ---- mask decoder (token side is tiny: fp32 VALU kernels) ------------------------------------
-// tokens [P,7,256]: iou token, 4 mask tokens, 2 prompt tokens from (coords [P,2,2], labels [P,2])
-void prompt_tokens(const float* coords, const float* labels, const float* gauss, const float* point_embed,
+// First launch of a decode.  tokens [P,7,256]: iou token, 4 mask tokens, 2 prompt tokens from (coords [P,2,2], labels
+// [P,2]); tokens_copy: the decoder's running queries start as a copy.  Image side: keys = emb[p] + no_mask (fp32 + f16)
+// for all prompts; emb_dev: DEVICE array of P pointers.
+void decoder_start(const float* coords, const float* labels, const float* gauss, const float* point_embed,
                    const float* not_a_point, const float* iou_token, const float* mask_tokens, float* tokens,
-                   float* tokens_copy, int P, hipStream_t s);
+                   float* tokens_copy, const float* const* emb_dev, const float* no_mask, float* keys, half_t* keys_h, int P,
+                   hipStream_t s);
 // floats of workspace for the per-key-group partial results of token_to_image_partials
 size_t token_to_image_scratch_floats(int P);
 // image attends to tokens: q [P,4096,ldq] f16, k,v [P,7,128] f32 -> out [P,4096,128] f16
@@ -146,7 +149,7 @@ struct TokenLinear {
     int N = 0;
     int relu = 0;
 };
-// up to 3 layers over the same rows (<= 112) in one launch
+// up to 5 layers over the same rows (<= 112) in one launch
 void token_linears(const TokenLinear* ops, int count, int rows, hipStream_t);
 // self-attention among the 7 tokens of each prompt + its output projection `out` (K = 256) in one launch
 void token_self_attention_out(const float* q, const float* k, const float* v, const TokenLinear& out, int P, hipStream_t);
@@ -154,8 +157,6 @@ void token_self_attention_out(const float* q, const float* k, const float* v, co
 void token_to_image_partials(const float* q, const half_t* K, int ldk, const half_t* V, int ldv, float* scratch, int P,
                              hipStream_t);
 void token_merge_out(const float* scratch, const TokenLinear& out, int P, hipStream_t);
-// image side: keys = emb[p] + no_mask (fp32 + f16) for all prompts; emb_dev: DEVICE array of P pointers
-void decoder_keys_init(const float* const* emb_dev, const float* no_mask, float* keys, half_t* keys_h, int P, hipStream_t);
 // keys = LayerNorm(keys) in place + f16(keys)
 void decoder_keys_norm(float* keys, const float* w, const float* b, float eps, half_t* keys_h, int P, hipStream_t);
 // hyper-network MLPs (4 x 256->256->256->32) and IoU head (256->256->256->4) on the output tokens

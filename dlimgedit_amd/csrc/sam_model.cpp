@@ -658,6 +658,9 @@ void SamModel::reserve_decoder(int count) {
     tq_.reserve(T * 256);
     tk_.reserve(T * 256);
     tv_.reserve(T * 256);
+    sq_.reserve(T * 256);
+    sk_.reserve(T * 256);
+    sv_.reserve(T * 256);
     tatt_.reserve(T * 256);
     tsa_.reserve(T * 256);
     tt2i_.reserve(T * 256);
@@ -696,11 +699,10 @@ void SamModel::decode_chunk(float const* const* emb, float const* coords, float 
         HIP_CHECK(hipMemcpyAsync(coords_.get(), pin, (size_t)P * 8 * sizeof(float), hipMemcpyHostToDevice, s));
         HIP_CHECK(hipEventRecord(prompt_done_[ring], s));
         float const* const* emb_dev = reinterpret_cast<float const* const*>(coords_.get() + (size_t)P * 6);
-        k::prompt_tokens(coords_.get(), coords_.get() + (size_t)P * 4, W.pe_gauss_.get(), W.pe_point_.get(),
+        // prompt tokens, and keys = image_embedding + no_mask_embed (has_mask_input == 0, segmentation.cpp:43-45)
+        k::decoder_start(coords_.get(), coords_.get() + (size_t)P * 4, W.pe_gauss_.get(), W.pe_point_.get(),
                          W.pe_not_a_point_.get(), W.iou_token_.get(), W.mask_tokens_.get(), tokens_.get(), queries_.get(),
-                         P, s);
-        // keys = image_embedding + no_mask_embed (has_mask_input == 0, segmentation.cpp:43-45)
-        k::decoder_keys_init(emb_dev, W.pe_no_mask_.get(), keys_.get(), keys_h_.get(), P, s);
+                         emb_dev, W.pe_no_mask_.get(), keys_.get(), keys_h_.get(), P, s);
 
         // Token side.  `cur` is the running token matrix as its consumers read it: un-normalised rows plus the
         // LayerNorm that belongs in front of them (applied on the fly by whoever reads, kernels/decoder.hip).
@@ -731,12 +733,14 @@ void SamModel::decode_chunk(float const* const* emb, float const* coords, float 
 
         for (int i = 0; i < 2; ++i) {
             DecoderLayer const& L = W.dec_[i];
-            // (1) self attention of the tokens; the first layer has no PE and no residual
-            k::TokenLinear qkv[3] = {lin(rows_of(cur, i != 0), 256, L.self_attn.q, {}, tq_.get(), 0),
-                                     lin(rows_of(cur, i != 0), 256, L.self_attn.k, {}, tk_.get(), 0),
-                                     lin(cur, 256, L.self_attn.v, {}, tv_.get(), 0)};
-            k::token_linears(qkv, 3, T, s);
-            k::token_self_attention_out(tq_.get(), tk_.get(), tv_.get(),
+            // (1) self attention of the tokens; the first layer has no PE and no residual.  The q / k / v projections of
+            // the second layer were computed by the first layer's step (4) launch (same input rows).
+            if (i == 0) {
+                k::TokenLinear qkv[3] = {lin(cur, 256, L.self_attn.q, {}, sq_.get(), 0), lin(cur, 256, L.self_attn.k, {}, sk_.get(), 0),
+                                         lin(cur, 256, L.self_attn.v, {}, sv_.get(), 0)};
+                k::token_linears(qkv, 3, T, s);
+            }
+            k::token_self_attention_out(sq_.get(), sk_.get(), sv_.get(),
                                         lin({}, 256, L.self_attn.o, i == 0 ? k::TokenRows{} : cur, tsa_.get(), 0), P, s);
             const k::TokenRows q1 = normed(tsa_.get(), L.ln1);
             // (2) tokens -> image: [K | Q of step 4 | V] = [(keys + pos) Wk | (keys + pos) Wq | keys Wv]
@@ -752,10 +756,20 @@ void SamModel::decode_chunk(float const* const* emb, float const* coords, float 
             k::TokenLinear m2 = lin(plain(tmlp_.get()), 2048, L.mlp2, q2, queries_.get(), 0);
             k::token_linears(&m2, 1, T, s);
             const k::TokenRows q3 = normed(queries_.get(), L.ln3);
-            // (4) image -> tokens
-            k::TokenLinear kv[2] = {lin(rows_of(q3, true), 256, L.i2t_k, {}, tk_.get(), 0),
+            // (4) image -> tokens.  Everything else that reads the same rows q3 rides in this launch: the next layer's
+            // self-attention projections, or (last layer) the query projection of the final token -> image attention.
+            k::TokenLinear kv[5] = {lin(rows_of(q3, true), 256, L.i2t_k, {}, tk_.get(), 0),
                                     lin(q3, 256, L.i2t_v, {}, tv_.get(), 0)};
-            k::token_linears(kv, 2, T, s);
+            int n_ops = 2;
+            if (i == 0) {
+                DecoderLayer const& N = W.dec_[1];
+                kv[n_ops++] = lin(rows_of(q3, true), 256, N.self_attn.q, {}, sq_.get(), 0);
+                kv[n_ops++] = lin(rows_of(q3, true), 256, N.self_attn.k, {}, sk_.get(), 0);
+                kv[n_ops++] = lin(q3, 256, N.self_attn.v, {}, sv_.get(), 0);
+            } else {
+                kv[n_ops++] = lin(rows_of(q3, true), 256, W.final_q_, {}, sq_.get(), 0);
+            }
+            k::token_linears(kv, n_ops, T, s);
             k::image_to_token_attention(kqv_h_.get() + 128, 384, tk_.get(), tv_.get(), att_img_h_.get(), P, s);
             k::GemmArgs g;
             g.A = att_img_h_.get(); g.lda = 128; g.W = L.i2t_o.w.get(); g.ldw = 128; g.bias = L.i2t_o.b.get();
@@ -769,9 +783,7 @@ void SamModel::decode_chunk(float const* const* emb, float const* coords, float 
         }
         // final token -> image attention
         img_gemm(W.final_kv_, W.final_pos_kv_);
-        k::TokenLinear fq = lin(rows_of(cur, true), 256, W.final_q_, {}, tq_.get(), 0);
-        k::token_linears(&fq, 1, T, s);
-        k::token_to_image_partials(tq_.get(), kqv_h_.get(), 256, kqv_h_.get() + 128, 256, t2i_part_.get(), P, s);
+        k::token_to_image_partials(sq_.get(), kqv_h_.get(), 256, kqv_h_.get() + 128, 256, t2i_part_.get(), P, s);
         k::token_merge_out(t2i_part_.get(), lin({}, 128, W.final_o_, cur, tsa_.get(), 0), P, s);
         const k::TokenRows qf = normed(tsa_.get(), W.ln_final_);
 

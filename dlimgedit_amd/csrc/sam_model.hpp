@@ -224,7 +224,7 @@ class SamModel {
     int dec_count_ = 0;
     DeviceBuffer<float> keys_, up1_f32_, up_, logits_, iou_, hyper_;
     DeviceBuffer<half_t> keys_h_, kqv_h_, att_img_h_, up1_h_;
-    DeviceBuffer<float> coords_, tokens_, queries_, tq_, tk_, tv_, tatt_, tsa_, tt2i_, tmlp_, t2i_part_;
+    DeviceBuffer<float> coords_, tokens_, queries_, tq_, tk_, tv_, sq_, sk_, sv_, tatt_, tsa_, tt2i_, tmlp_, t2i_part_;
     std::vector<std::unique_ptr<MaskSlot>> mask_slots_;     // all ever made (owned), guarded by done_mutex_
     std::vector<MaskSlot*> mask_free_;                      // those not handed out, guarded by done_mutex_
     PinnedBuffer prompt_pinned_;
