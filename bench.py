@@ -311,6 +311,20 @@ def main() -> None:
         result["encoder_only"] = {"value": B * args.steps / (time.perf_counter() - t0), "unit": "images/s",
                                   "note": "pre-processing + ViT encoder + neck, inputs resident in HBM, all lanes"}
 
+    # ---- the two pixel kernels against the HBM rate (north_star: "HBM GB/s for the pre/post kernels"): one image per
+    # launch sits on the launch floor (`stages` above), so they are also clocked with 16 images / masks per launch
+    if rank == 0 and world == 1:
+        pre_b, post_b = 4 * 1024 * 1024 + 4096 * 768 * 2, 256 * 256 * 4 + 1024 * 1024      # algorithmic bytes per image / mask
+        hk = {"unit": "GB/s", "peak": HBM_PEAK_GBS, "clock": "HIP events around 50 back-to-back launches on one stream",
+              "bytes_per_image": {"pre": pre_b, "post": post_b}}
+        for n in (1, 16):
+            pre_ms, post_ms = ext.bench_prepost(n, 50)
+            hk[f"batch{n}"] = {"pre_us": 1e3 * pre_ms, "pre_gbs": n * pre_b / (pre_ms * 1e-3) / 1e9,
+                               "pre_frac": n * pre_b / (pre_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "post_us": 1e3 * post_ms, "post_gbs": n * post_b / (post_ms * 1e-3) / 1e9,
+                               "post_frac": n * post_b / (post_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        result["hbm_kernels"] = hk
+
     # ---- the drop-in ABI itself: host buffers in and out (PCIe inclusive), rank 0, N = 1 only
     if rank == 0 and world == 1 and not args.no_abi_path:
         import threading

@@ -392,6 +392,7 @@ class ext:
                 "dlimg_amd_birefnet_process_mask": ([vp, ci, ci, vp], ci),
                 "dlimg_amd_resize_mask": ([vp, ci, ci, ci, ci, ci, vp], ci),
                 "dlimg_amd_bench_attention": ([ci, ci, ci, ci, ci, C.POINTER(C.c_double)], ci),
+                "dlimg_amd_bench_prepost": ([ci, ci, C.POINTER(C.c_double), C.POINTER(C.c_double)], ci),
                 "dlimg_amd_bench_gemm": ([ci, ci, ci, ci, ci, ci, C.POINTER(C.c_double)], ci),
                 "dlimg_amd_bench_gemm_streams": ([ci, ci, ci, ci, ci, ci, ci, ci, ci, C.POINTER(C.c_double)], ci),
                 "dlimg_amd_bench_gemm_stamps": ([ci, ci, ci, ci, ci, ci, ci, ci, ci, C.POINTER(C.c_double), vp, ci], ci),
@@ -410,7 +411,7 @@ class ext:
                "dlimg_amd_take_stage_stats", "dlimg_amd_test_preprocess", "dlimg_amd_test_postprocess",
                "dlimg_amd_test_gemm", "dlimg_amd_test_gemm_ln", "dlimg_amd_test_layernorm", "dlimg_amd_test_attention", "dlimg_amd_test_resize",
                "dlimg_amd_birefnet_prepare_image", "dlimg_amd_birefnet_process_mask", "dlimg_amd_resize_mask",
-               "dlimg_amd_bench_attention", "dlimg_amd_bench_gemm", "dlimg_amd_bench_gemm_streams", "dlimg_amd_bench_gemm_stamps")
+               "dlimg_amd_bench_attention", "dlimg_amd_bench_prepost", "dlimg_amd_bench_gemm", "dlimg_amd_bench_gemm_streams", "dlimg_amd_bench_gemm_stamps")
 
     @staticmethod
     def _ptr(a: Optional[np.ndarray]):
@@ -645,6 +646,13 @@ class ext:
         out = np.empty((out_h, out_w), dtype=np.uint8)
         _check(cls._l().dlimg_amd_resize_mask(mask.ctypes.data, w, h, mask.strides[0], out_w, out_h, out.ctypes.data))
         return out
+
+    @classmethod
+    def bench_prepost(cls, batch: int = 16, iters: int = 50) -> Tuple[float, float]:
+        """(ms per launch of the pre-processing kernel, of the post-processing kernel) on `batch` images / masks."""
+        pre, post = C.c_double(), C.c_double()
+        _check(cls._l().dlimg_amd_bench_prepost(batch, iters, C.byref(pre), C.byref(post)))
+        return pre.value, post.value
 
     @classmethod
     def bench_attention(cls, is_global: bool, heads: int = 12, hd: int = 64, batch: int = 1, iters: int = 50) -> float:

@@ -81,6 +81,8 @@ class EnvironmentImpl {
     // batching, as a serving host would do): with two images per pass the N = 768 GEMMs (patch, proj, fc2) reach 96
     // tiles of the 256 x 256 kernel instead of 96 of the 128 x 256 one.  Results are bit-identical to single-image
     // passes (kernels/gemm.hip, tile choice).  DLIMGEDIT_COALESCE = 1 switches it off; dlimg_amd_synchronize flushes.
+    // process_images_for_segmentation calls in flight (any thread): the pass size adapts to it (segmentation.cpp)
+    std::atomic<int> batch_calls_in_flight{0};
     struct PendingStep { dlimg_ImageView view; int x, y; uint8_t* mask; };
     std::mutex pending_mutex;
     std::vector<PendingStep> pending;

@@ -72,9 +72,8 @@ void encode_device_images(SamModel& model, dlimg_ImageView const* imgs, int coun
         check_image(imgs[i]);
         if (std::max(imgs[i].width, imgs[i].height) != kImageSize)
             throw Exception("device-resident images must have their longest side at 1024 pixels");
-        model.preprocess_device_image(i, count, imgs[i].pixels, imgs[i].width, imgs[i].height, imgs[i].stride,
-                                      imgs[i].channels);
     }
+    model.preprocess_device_images(imgs, count);
     model.encode(count);
 }
 
@@ -564,6 +563,56 @@ DLIMG_API int dlimg_amd_resize_mask(uint8_t const* mask, int width, int height, 
         k::resize_srgb(src.get(), width, height, stride, 1, ax, ay, dlut.get(), nullptr, tmp.get(), dst.get(), nullptr);
         HIP_CHECK(hipDeviceSynchronize());
         download(out_mask, dst.get(), (size_t)out_w * out_h);
+    });
+}
+
+DLIMG_API int dlimg_amd_bench_prepost(int batch, int iters, double* out_pre_ms, double* out_post_ms) {
+    return guarded([&] {
+        require_gpu();
+        DLIMG_ASSERT(batch > 0 && batch <= 16 && iters > 0 && out_pre_ms && out_post_ms);
+        const size_t img_bytes = (size_t)kImageSize * kImageSize * 4;
+        std::vector<uint8_t> himg(img_bytes);
+        uint32_t seed = 99u;
+        for (auto& v : himg) { seed = seed * 1664525u + 1013904223u; v = (uint8_t)(seed >> 24); }
+        std::vector<float> hlog((size_t)4 * kLowRes * kLowRes);
+        for (auto& v : hlog) { seed = seed * 1664525u + 1013904223u; v = ((seed >> 8) & 0xffff) / 32768.0f - 1.0f; }
+        std::vector<float> hiou = {0.1f, 0.7f, 0.5f, 0.3f};
+        DeviceBuffer<uint8_t> imgs(batch * img_bytes), masks((size_t)batch * kImageSize * kImageSize);
+        DeviceBuffer<half_t> patches((size_t)batch * kTokens * kPatchK);
+        DeviceBuffer<float> logits((size_t)batch * 4 * kLowRes * kLowRes), iou((size_t)batch * 4);
+        for (int i = 0; i < batch; ++i) {
+            HIP_CHECK(hipMemcpy(imgs.get() + i * img_bytes, himg.data(), img_bytes, hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy(logits.get() + (size_t)i * hlog.size(), hlog.data(), hlog.size() * 4, hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy(iou.get() + (size_t)i * 4, hiou.data(), 16, hipMemcpyHostToDevice));
+        }
+        std::vector<k::PreImage> pre(batch);
+        std::vector<k::PostJob> post(batch);
+        for (int i = 0; i < batch; ++i) {
+            pre[i] = k::PreImage{imgs.get() + i * img_bytes, kImageSize, kImageSize, kImageSize * 4, 4,
+                                 patches.get() + (size_t)i * kTokens * kPatchK};
+            post[i] = k::PostJob{logits.get() + (size_t)i * 4 * kLowRes * kLowRes, iou.get() + (size_t)i * 4,
+                                 masks.get() + (size_t)i * kImageSize * kImageSize, kImageSize, kImageSize, kImageSize, kImageSize};
+        }
+        hipStream_t st;
+        HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        auto time = [&](auto&& launch) {
+            for (int i = 0; i < 3; ++i) launch();
+            HIP_CHECK(hipEventRecord(e0, st));
+            for (int i = 0; i < iters; ++i) launch();
+            HIP_CHECK(hipEventRecord(e1, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            float ms = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            return (double)ms / iters;
+        };
+        *out_pre_ms = time([&] { k::preprocess_batch(pre.data(), batch, st); });
+        *out_post_ms = time([&] { k::postprocess_masks(post.data(), batch, st); });
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        (void)hipStreamDestroy(st);
     });
 }
 

@@ -36,8 +36,17 @@ __host__ __device__ inline ChannelMap channel_map(int channels) {
     }
 }
 
-__global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restrict__ img, int w, int h, int stride,
-                                                         int channels, half_t* __restrict__ out) {
+// Up to 16 images per launch (blockIdx.y = image): the images of one batched pass share a launch, and at 16 images the
+// kernel moves 168 MB, enough to be measured against the HBM rate instead of the launch floor (bench.py, hbm_kernels).
+constexpr int PRE_MAX_JOBS = 16;
+struct PreJob { const uint8_t* img; half_t* out; int w, h, stride, channels; };
+struct PreJobs { PreJob j[PRE_MAX_JOBS]; };
+
+__global__ __launch_bounds__(256) void preprocess_kernel(PreJobs jobs) {
+    const PreJob job = jobs.j[blockIdx.y];
+    const uint8_t* __restrict__ img = job.img;
+    half_t* __restrict__ out = job.out;
+    const int w = job.w, h = job.h, stride = job.stride, channels = job.channels;
     const int lane = lane_id();
     const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);       // patch pair index, 2048 per image
     const int iy = lane >> 2, p = (lane >> 1) & 1, half = lane & 1;
@@ -229,13 +238,27 @@ inline int grid_for(size_t work_items, int cap = 2048) {
 
 namespace k {
 
+void preprocess_batch(const PreImage* images, int count, hipStream_t s) {
+    for (int base = 0; base < count; base += PRE_MAX_JOBS) {
+        const int n = count - base < PRE_MAX_JOBS ? count - base : PRE_MAX_JOBS;
+        PreJobs jobs{};
+        for (int i = 0; i < n; ++i) {
+            const PreImage& im = images[base + i];
+            if (!im.img || !im.patches) throw_error("preprocess: null buffer");
+            if (im.w <= 0 || im.h <= 0 || im.w > 1024 || im.h > 1024) throw_error("preprocess: image must be 1..1024 pixels per side");
+            const int bytes = im.channels > 4 ? 4 : im.channels;
+            if (!(im.channels == 1 || im.channels == 3 || im.channels == 4 || im.channels == 5 || im.channels == 6))
+                throw_error("preprocess: unsupported channel order");
+            if (im.stride < im.w * bytes) throw_error("preprocess: stride smaller than one row of pixels");
+            jobs.j[i] = PreJob{im.img, im.patches, im.w, im.h, im.stride, im.channels};
+        }
+        hipLaunchKernelGGL(preprocess_kernel, dim3(512, n), dim3(256), 0, s, jobs);
+    }
+}
+
 void preprocess(const uint8_t* img, int w, int h, int stride, int channels, half_t* patches, hipStream_t s) {
-    if (w <= 0 || h <= 0 || w > 1024 || h > 1024) throw_error("preprocess: image must be 1..1024 pixels per side");
-    const int bytes = channels > 4 ? 4 : channels;
-    if (!(channels == 1 || channels == 3 || channels == 4 || channels == 5 || channels == 6))
-        throw_error("preprocess: unsupported channel order");
-    if (stride < w * bytes) throw_error("preprocess: stride smaller than one row of pixels");
-    hipLaunchKernelGGL(preprocess_kernel, dim3(512), dim3(256), 0, s, img, w, h, stride, channels, patches);
+    const PreImage one{img, w, h, stride, channels, patches};
+    preprocess_batch(&one, 1, s);
 }
 
 void layernorm(const float* x, const float* w, const float* b, float eps, int rows, int D, int act, float* out_f32,

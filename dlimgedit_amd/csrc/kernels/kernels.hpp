@@ -91,6 +91,9 @@ void layernorm(const float* x, const float* w, const float* b, float eps, int ro
 // matrix [4096, 768]: row = patch (py*64+px), column = c*256 + iy*16 + ix, value
 // (float(u8) - mean[c]) / std[c]; pixels outside h x w (zero padding of the graph) are 0.
 void preprocess(const uint8_t* img, int w, int h, int stride, int channels, half_t* patches, hipStream_t);
+// the same for several images in one launch (the images of a batched pass)
+struct PreImage { const uint8_t* img; int w, h, stride, channels; half_t* patches; };
+void preprocess_batch(const PreImage* images, int count, hipStream_t);
 
 // ---- K17 longest-side resize (stb_image_resize equivalent; tables from csrc/resize_tables.cpp) ------------
 struct ResizeAxis { const int* first; const int* count; const float* coef; int taps; int out; };   // device pointers

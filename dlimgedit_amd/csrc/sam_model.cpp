@@ -425,6 +425,20 @@ void SamModel::preprocess_device_image(int slot, int batch, uint8_t const* dev_p
     });
 }
 
+void SamModel::preprocess_device_images(dlimg_ImageView const* views, int batch) {
+    DLIMG_ASSERT(views != nullptr && batch > 0);
+    reserve_encoder(batch);
+    std::vector<k::PreImage> images(batch);
+    double bytes = 0;
+    for (int i = 0; i < batch; ++i) {
+        const int px = views[i].channels > 4 ? 4 : views[i].channels;
+        images[i] = k::PreImage{views[i].pixels, views[i].width, views[i].height, views[i].stride, views[i].channels,
+                                patches_.get() + (size_t)i * kTokens * kPatchK};
+        bytes += (double)views[i].width * views[i].height * px + (double)kTokens * kPatchK * 2;
+    }
+    timed(ST_PRE, bytes, [&] { k::preprocess_batch(images.data(), batch, stream_); });
+}
+
 // Packs `rows` rows of `row_bytes` bytes into the next entry of the pinned staging ring and returns it; *copied is the
 // event the caller records behind its copy out of the entry (the entry is not touched again before that event).
 uint8_t* SamModel::stage_rows(uint8_t const* pixels, size_t row_bytes, int rows, int stride, hipEvent_t* copied) {

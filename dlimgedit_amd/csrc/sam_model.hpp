@@ -8,6 +8,8 @@
 #pragma once
 
 #include "common.hpp"
+
+#include <dlimgedit/dlimgedit.h>
 #include "kernels/kernels.hpp"
 #include "resize_tables.hpp"
 #include "weights.hpp"
@@ -131,6 +133,8 @@ class SamModel {
                                  int rw, int rh);
     // Device-resident image variant (used by the batch benchmark so PCIe is outside the timed region).
     void preprocess_device_image(int slot, int batch, uint8_t const* dev_pixels, int w, int h, int stride, int channels);
+    // All `batch` slots from device-resident images in ONE launch (views carry device pixel pointers).
+    void preprocess_device_images(dlimg_ImageView const* views, int batch);
     // Runs the encoder on `batch` uploaded images; embeddings [batch][4096][256] fp32 in embeddings() and, where
     // emb_dst[i] is given, in that device buffer too (batch 1: written there directly).
     void encode(int batch, float* const* emb_dst = nullptr);

@@ -159,15 +159,24 @@ void SegmentationImpl::process_batch(EnvironmentImpl& env, SegmentationImpl* con
     }
     (void)G;
     static const bool trace = std::getenv("DLIMGEDIT_TIMING") != nullptr;     // diagnostic: host time of the two phases
-    // Images per batched encoder pass.  Results do not depend on it (tiles are chosen per image, kernels/gemm.hip);
-    // throughput does: lanes that start together run the same kernels in lockstep, so a few larger passes on fewer
-    // lanes beat many single-image passes (8 images, ViT-B: 15.2 ms as 8 x 1, 12.5 ms as 2 x 4).  Default: half of the
-    // GPU's share per pass, at most 4; DLIMGEDIT_ENCODE_BATCH overrides (1..16).
+    // Images per batched encoder pass.  Results do not depend on it (kernels/gemm.hip: the tiles a pass may use compute
+    // the same bits); throughput does: every lane should get a pass, and passes of two or more images run the N = 768
+    // GEMMs on 256 x 256 tiles (8 images through one host thread, ViT-B: 601 images/s as 2 x 4, 649 as 8 x 1, 674 as
+    // 4 x 2).  Default: the GPU's share spread over its lanes, at most 4 per pass -- unless other threads have batch calls
+    // in flight, which keep the other lanes busy anyway: then fewer, larger passes win (4 threads x 8 images: 685 images/s
+    // with passes of 2, 736 with passes of 4).  DLIMGEDIT_ENCODE_BATCH overrides (1..16).
     static const int forced_chunk = [] {
         const char* e = std::getenv("DLIMGEDIT_ENCODE_BATCH");
         const int v = e ? std::atoi(e) : 0;
         return v < 0 ? 0 : (v > 16 ? 16 : v);
     }();
+    struct InFlight {
+        std::atomic<int>& n;
+        int before;
+        explicit InFlight(std::atomic<int>& c) : n(c), before(c.fetch_add(1)) {}
+        ~InFlight() { n.fetch_sub(1); }
+    } in_flight(env.batch_calls_in_flight);
+    const bool alone = in_flight.before == 0;    // no other batch call is being worked on right now
     for_each_replica(used, [&](int replica) {
         HIP_CHECK(hipSetDevice(env.device_of(replica)));
         std::vector<Waiting> waiting;
@@ -178,7 +187,11 @@ void SegmentationImpl::process_batch(EnvironmentImpl& env, SegmentationImpl* con
             for (int i = 0; i < count; ++i)
                 if (replica_of[i] == replica) mine.push_back(i);
             // chunks of up to `chunk` images: one batched pass per chunk on the next lane
-            const size_t chunk = forced_chunk ? (size_t)forced_chunk : std::min<size_t>(4, (mine.size() + 1) / 2);
+            const size_t lanes = (size_t)std::max(1, env.effective_lane_count(replica));
+            const size_t spread = std::max<size_t>(1, (mine.size() + lanes - 1) / lanes);     // one pass per lane
+            const size_t chunk = forced_chunk ? (size_t)forced_chunk
+                                 : alone      ? std::min<size_t>(4, spread)
+                                              : std::min<size_t>(4, std::max(spread, (mine.size() + 1) / 2));
             for (size_t base = 0; base < mine.size(); base += chunk) {
                 const int n = (int)std::min<size_t>(chunk, mine.size() - base);
                 std::vector<float*> emb(n);

@@ -130,6 +130,11 @@ DLIMG_API int dlimg_amd_birefnet_prepare_image(uint8_t const* pixels, int width,
 DLIMG_API int dlimg_amd_birefnet_process_mask(float const* logits, int width, int height, uint8_t* out_mask);
 DLIMG_API int dlimg_amd_resize_mask(uint8_t const* mask, int width, int height, int stride, int out_w, int out_h,
                                     uint8_t* out_mask);
+/* Times the two pixel kernels of the path alone on `batch` (1..16) device-resident 1024x1024 RGBA images / mask requests in
+ * ONE launch each: K1 pre-processing (4 MiB u8 in, 6 MiB f16 patch matrix out per image) and K16 post-processing (256 KiB
+ * of fp32 logits in, 1 MiB u8 mask out per mask); average ms per launch.  At one image these kernels sit on the launch
+ * floor; at 16 they move 168 MB / 21 MB and can be read against the HBM rate. */
+DLIMG_API int dlimg_amd_bench_prepost(int batch, int iters, double* out_pre_ms, double* out_post_ms);
 /* Times `iters` back-to-back launches of an encoder attention kernel (global != 0: the 4096-token kernel, else the 14x14
  * windowed one) on device-resident random data of `batch` images; returns the average ms per launch. */
 DLIMG_API int dlimg_amd_bench_attention(int global, int batch, int heads, int hd, int iters, double* out_ms);

@@ -76,7 +76,8 @@ def _planes(seed, n=4):
     return np.stack(out)
 
 
-@pytest.mark.parametrize("w,h", [(1024, 1024), (1800, 1200), (512, 512), (640, 960), (1024, 768), (91, 37), (5, 3)])
+@pytest.mark.parametrize("w,h", [(1024, 1024), (1800, 1200), (512, 512), (640, 960), (1024, 768), (91, 37), (5, 3), (1024, 683),
+                                 (681, 1024), (1024, 2)])
 def test_postprocess_bit_exact(ext, w, h):
     """Two-stage bilinear + crop + threshold equals the oracle's masks bit for bit."""
     O = _oracle()
