@@ -85,6 +85,10 @@ EnvironmentImpl::EnvironmentImpl(dlimg_Options const& options) : backend(options
         const int v = std::atoi(e);
         coalesce = v < 1 ? 1 : (v > 8 ? 8 : v);
     }
+    if (const char* e = std::getenv("DLIMGEDIT_STEP_DEPTH")) {
+        const int v = std::atoi(e);
+        step_depth = v < 1 ? 1 : (v > 64 ? 64 : v);
+    }
     single_lane_.store(forced_single_lane_);
     for (int d : devices) {
         if (d < 0 || d >= device_count())
@@ -95,6 +99,11 @@ EnvironmentImpl::EnvironmentImpl(dlimg_Options const& options) : backend(options
         r->pool = std::make_shared<EmbeddingPool>(d);
         replicas_.push_back(std::move(r));
     }
+}
+
+EnvironmentImpl::~EnvironmentImpl() {
+    for (auto& lane : step_passes)
+        for (auto& pass : lane) (void)hipEventDestroy(pass.done);
 }
 
 std::string EnvironmentImpl::find_sam_weights() const {

@@ -16,6 +16,7 @@
 #include <dlimgedit/dlimgedit.h>
 
 #include <atomic>
+#include <deque>
 #include <filesystem>
 #include <memory>
 #include <string>
@@ -52,6 +53,7 @@ class EnvironmentImpl {
     static int device_count() noexcept;
 
     explicit EnvironmentImpl(dlimg_Options const& options);
+    ~EnvironmentImpl();
 
     // Replicas: one per entry of the device list (the same GPU may be listed more than once; each entry is an
     // independent replica with its own weights -- used by the tests to exercise the multi-device code on one GPU).
@@ -83,10 +85,19 @@ class EnvironmentImpl {
     // passes (kernels/gemm.hip, tile choice).  DLIMGEDIT_COALESCE = 1 switches it off; dlimg_amd_synchronize flushes.
     // process_images_for_segmentation calls in flight (any thread): the pass size adapts to it (segmentation.cpp)
     std::atomic<int> batch_calls_in_flight{0};
+    // Passes are handed to the lane with the least work in flight, and at most `step_depth` passes wait on a lane's
+    // stream; what arrives beyond that stays in `pending` until a lane has room (looked at on the next call) or until
+    // dlimg_amd_synchronize deals it out so that every lane ends up with the same number of images: a burst that is not
+    // a multiple of lanes x coalesce then finishes on all lanes together instead of leaving some idle at the end.
+    // DLIMGEDIT_STEP_DEPTH (1..64, default 2).
     struct PendingStep { dlimg_ImageView view; int x, y; uint8_t* mask; };
+    struct StepPass { hipEvent_t done; int images; };
     std::mutex pending_mutex;
     std::vector<PendingStep> pending;
+    std::vector<std::deque<StepPass>> step_passes;     // per lane of replica 0, oldest first (pending_mutex)
     int coalesce = 2;
+    int step_depth = 2;
+    int step_cursor = 0;                               // lane after the one used last (pending_mutex)
 
   private:
     struct SamLanes {

@@ -179,10 +179,11 @@ DLIMG_API int dlimg_amd_encode_only(dlimg_Environment env, dlimg_ImageView const
 namespace dlimg {
 namespace {
 
-// One batched pass of the device-resident hot path over `steps` on the next lane: pre-process, encode, decode one point
-// prompt per image (single-mask mode), masks to the callers' device buffers.  Enqueues only.
-void run_device_steps(EnvironmentImpl& env, EnvironmentImpl::PendingStep const* steps, int count) {
-    SamModel& m = env.next_lane(0);
+// One batched pass of the device-resident hot path over `steps` on lane `lane` of replica 0: pre-process, encode, decode
+// one point prompt per image (single-mask mode), masks to the callers' device buffers.  Enqueues only, and notes the pass
+// in env.step_passes.  pending_mutex held by the caller.
+void run_device_steps(EnvironmentImpl& env, int lane, EnvironmentImpl::PendingStep const* steps, int count) {
+    SamModel& m = env.lane(0, lane);
     std::lock_guard<std::mutex> lock(m.mutex());
     HIP_CHECK(hipSetDevice(m.device()));
     std::vector<dlimg_ImageView> views(count);
@@ -203,29 +204,78 @@ void run_device_steps(EnvironmentImpl& env, EnvironmentImpl::PendingStep const* 
         jobs[i] = k::PostJob{m.logits() + (size_t)i * 4 * kLowRes * kLowRes, m.iou() + (size_t)i * 4, steps[i].mask,
                              rs[i].original.width, rs[i].original.height, rs[i].resized.width, rs[i].resized.height};
     m.masks_on_device(jobs.data(), count);
+    env.step_passes[lane].push_back(EnvironmentImpl::StepPass{m.completion(), count});
 }
 
-// Launches what is waiting: one pass of `coalesce` images on the next lane as soon as that many requests wait; with `all`
-// (dlimg_amd_synchronize) the rest is dealt over the lanes as evenly as possible (pass sizes differ by at most one).
+// Forgets the passes that have finished and returns the lanes requests are spread over.
+int retire_device_steps(EnvironmentImpl& env) {
+    const int lanes = std::max(1, env.effective_lane_count(0));
+    if ((int)env.step_passes.size() < env.lane_count(0)) env.step_passes.resize(env.lane_count(0));
+    for (size_t l = 0; l < env.step_passes.size(); ++l) {
+        auto& q = env.step_passes[l];
+        while (!q.empty() && env.lane(0, (int)l).poll_and_recycle(q.front().done)) q.pop_front();
+    }
+    return lanes;
+}
+
+// The lane with the fewest passes in flight; among equals the one after the lane used last, so that the lanes take turns
+// even where completion cannot be observed (under rocprofv3's kernel trace hipEventQuery reports every pass as finished).
+int least_busy_lane(EnvironmentImpl& env, int lanes) {
+    int best = -1;
+    for (int i = 0; i < lanes; ++i) {
+        const int l = (env.step_cursor + i) % lanes;
+        if (best < 0 || env.step_passes[l].size() < env.step_passes[best].size()) best = l;
+    }
+    env.step_cursor = (best + 1) % lanes;
+    return best;
+}
+
+// Launches what is waiting (environment.hpp, PendingStep).  Without `all`: one pass of `coalesce` images at a time on
+// the lane with the fewest passes in flight, as long as that lane has fewer than `step_depth`.  With `all`
+// (dlimg_amd_synchronize): every waiting request, dealt so that the images in flight per lane end up level, in passes of
+// at most `coalesce` images whose sizes differ by at most one on a lane.
 // [Holding requests back until a whole wave of lanes x coalesce had arrived was measured and gained nothing on a burst of
 // 20 requests, while it delays the first launch.]  pending_mutex held by the caller.
 void flush_device_steps(EnvironmentImpl& env, bool all) {
+    if (env.pending.empty()) return;
     const size_t width = (size_t)std::max(1, env.coalesce);
-    const size_t lanes = (size_t)std::max(1, env.effective_lane_count(0));
+    const int lanes = retire_device_steps(env);
     size_t done = 0;
     try {
         while (env.pending.size() - done >= width) {
-            run_device_steps(env, env.pending.data() + done, (int)width);
+            const int best = least_busy_lane(env, lanes);
+            if ((int)env.step_passes[best].size() >= env.step_depth) break;
+            run_device_steps(env, best, env.pending.data() + done, (int)width);
             done += width;
         }
         if (all && done < env.pending.size()) {
-            const size_t rest = env.pending.size() - done;
-            const size_t passes = std::min(lanes, rest);
-            for (size_t p = 0; p < passes; ++p) {
-                const size_t n = rest / passes + (p < rest % passes ? 1 : 0);
-                run_device_steps(env, env.pending.data() + done, (int)n);
-                done += n;
+            std::vector<size_t> load(lanes, 0), share(lanes, 0);
+            for (int l = 0; l < lanes; ++l)
+                for (auto const& pass : env.step_passes[l]) load[l] += (size_t)pass.images;
+            for (size_t i = done; i < env.pending.size(); ++i) {
+                int best = -1;
+                for (int k = 0; k < lanes; ++k) {
+                    const int l = (env.step_cursor + k) % lanes;
+                    if (best < 0 || load[l] < load[best]) best = l;
+                }
+                env.step_cursor = (best + 1) % lanes;
+                ++load[best];
+                ++share[best];
             }
+            // round by round over the lanes, so that no lane's stream is filled long before the others'
+            std::vector<size_t> passes(lanes);
+            size_t rounds = 0;
+            for (int l = 0; l < lanes; ++l) {
+                passes[l] = (share[l] + width - 1) / width;
+                rounds = std::max(rounds, passes[l]);
+            }
+            for (size_t r = 0; r < rounds; ++r)
+                for (int l = 0; l < lanes; ++l) {
+                    if (r >= passes[l]) continue;
+                    const size_t n = share[l] / passes[l] + (r < share[l] % passes[l] ? 1 : 0);
+                    run_device_steps(env, l, env.pending.data() + done, (int)n);
+                    done += n;
+                }
         }
     } catch (...) {
         env.pending.clear();         // a failed pass must not be retried by the next call
@@ -255,7 +305,7 @@ DLIMG_API int dlimg_amd_encode_and_mask(dlimg_Environment env, dlimg_ImageView c
             std::vector<EnvironmentImpl::PendingStep> steps(count);
             for (int i = 0; i < count; ++i)
                 steps[i] = EnvironmentImpl::PendingStep{dev_images[i], points[i * 2], points[i * 2 + 1], dev_masks[i]};
-            run_device_steps(e, steps.data(), count);
+            run_device_steps(e, least_busy_lane(e, retire_device_steps(e)), steps.data(), count);
             return;
         }
         for (int i = 0; i < count; ++i)
@@ -286,6 +336,8 @@ DLIMG_API int dlimg_amd_synchronize(dlimg_Environment env) {
             flush_device_steps(e, true);
         }
         for_each_lane(e, [](SamModel& m) { m.synchronize(); });
+        std::lock_guard<std::mutex> lock(e.pending_mutex);
+        retire_device_steps(e);
     });
 }
 

@@ -392,6 +392,17 @@ void SamModel::wait_and_recycle(hipEvent_t e) {
     HIP_CHECK(err);
 }
 
+bool SamModel::poll_and_recycle(hipEvent_t e) {
+    const hipError_t err = hipEventQuery(e);
+    if (err == hipErrorNotReady) return false;
+    {
+        std::lock_guard<std::mutex> lock(done_mutex_);
+        done_pool_.push_back(e);
+    }
+    HIP_CHECK(err);
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------------
 // encoder
 

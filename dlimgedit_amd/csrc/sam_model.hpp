@@ -178,6 +178,7 @@ class SamModel {
     // Event recorded behind everything enqueued so far; wait for it WITHOUT mutex(), then give it back.
     hipEvent_t completion();
     void wait_and_recycle(hipEvent_t e);      // no mutex needed
+    bool poll_and_recycle(hipEvent_t e);      // no mutex needed: true (and the event is taken back) once it has completed
 
     void set_profiling(bool on);
     StageStats take_stats();
