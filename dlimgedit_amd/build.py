@@ -32,6 +32,7 @@ SOURCES = [
     "kernels/attention_window.hip",
     "kernels/attention_global.hip",
     "kernels/decoder.hip",
+    "kernels/decoder_image.hip",
     "kernels/postprocess.hip",
     "kernels/resize.hip",
     "kernels/objects.hip",

@@ -20,121 +20,31 @@ constexpr int NTOK_IMG = 4096;
 // ---------------------------------------------------------------------------------------------
 // Prompt encoder: SamOnnxModel._embed_points applied to the two packed points
 // (segmentation.cpp:135-152 packs them; labels 1/-1 for a point, 2/3 for a box).
-DLIMG_DEVICE void prompt_tokens_block(int p, const float* __restrict__ coords, const float* __restrict__ labels,
-                                      const float* __restrict__ gauss, const float* __restrict__ point_embed,
-                                      const float* __restrict__ not_a_point, const float* __restrict__ iou_token,
-                                      const float* __restrict__ mask_tokens, float* __restrict__ tokens,
-                                      float* __restrict__ tokens_copy) {
-    const int c = threadIdx.x;
-    float* t = tokens + (size_t)p * TOK * DIM;
-    float* t2 = tokens_copy + (size_t)p * TOK * DIM;      // the decoder's running queries start as a copy
-    t[c] = t2[c] = iou_token[c];
+// Column c of the 7 token rows of prompt p: iou token, 4 mask tokens, the 2 prompt points.
+DLIMG_DEVICE void prompt_token_column(const k::DecoderPrompts& pr, int p, int c, const float* __restrict__ gauss,
+                                      const float* __restrict__ point_embed, const float* __restrict__ not_a_point,
+                                      const float* __restrict__ iou_token, const float* __restrict__ mask_tokens,
+                                      float (&out)[7]) {
+    out[0] = iou_token[c];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) t[(1 + m) * DIM + c] = t2[(1 + m) * DIM + c] = mask_tokens[m * DIM + c];
+    for (int m = 0; m < 4; ++m) out[1 + m] = mask_tokens[m * DIM + c];
     const int kf = c & 127;
+#pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const float x = (coords[(p * 2 + i) * 2 + 0] + 0.5f) / 1024.0f;
-        const float y = (coords[(p * 2 + i) * 2 + 1] + 0.5f) / 1024.0f;
+        const float x = (pr.coords[(p * 2 + i) * 2 + 0] + 0.5f) / 1024.0f;
+        const float y = (pr.coords[(p * 2 + i) * 2 + 1] + 0.5f) / 1024.0f;
         float v = __fadd_rn(__fmul_rn(2.0f * x - 1.0f, gauss[kf]), __fmul_rn(2.0f * y - 1.0f, gauss[128 + kf]));
         v = 6.283185307179586f * v;
         float e = c < 128 ? sinf(v) : cosf(v);
-        const float lab = labels[p * 2 + i];
+        const float lab = pr.labels[p * 2 + i];
         if (lab == -1.0f) e = not_a_point[c];
 #pragma unroll
         for (int k4 = 0; k4 < 4; ++k4)
             if (lab == (float)k4) e += point_embed[k4 * DIM + c];
-        t[(5 + i) * DIM + c] = t2[(5 + i) * DIM + c] = e;
+        out[5 + i] = e;
     }
 }
 
-constexpr int RCHUNK = 8;      // rows a wave accumulates at a time in the token linears
-
-// ---------------------------------------------------------------------------------------------
-// Tokens attend to the 4096 image positions (8 heads x 16), in two steps so that the 4096 keys of a head are spread
-// over 8 workgroups (one workgroup per head streams 0.5 MB through a single CU and takes 44 us):
-//   partial: workgroup = (prompt, head, key group of 512); a thread takes 2 keys (requested up front), then query
-//            by query scores them, does the softmax against the wave's maximum (one exponential per score, no
-//            rescale) and its part of P.V; butterfly inside each wave -> per-wave (max, sum, output[16]) in `part`
-//   merge  : token_merge_out_kernel folds the 8 group partials in a fixed order and applies the output projection
-constexpr int T2I_GROUPS = 8;                                  // key groups per head
-constexpr int T2I_THREADS = 256;
-constexpr int T2I_KEYS = NTOK_IMG / T2I_GROUPS / T2I_THREADS;  // keys per thread
-constexpr int T2I_WAVES = T2I_THREADS / 64;
-constexpr int T2I_PARTS = T2I_GROUPS;                          // partial triples per (prompt, head, query)
-
-__global__ __launch_bounds__(T2I_THREADS) void token_to_image_partial_kernel(const float* __restrict__ q,
-                                                                             const half_t* __restrict__ K, int ldk,
-                                                                             const half_t* __restrict__ V, int ldv,
-                                                                             float* __restrict__ part) {
-    __shared__ float sq[TOK * 16];
-    __shared__ float wpart[TOK][T2I_WAVES][18];
-    const int grp = blockIdx.x % T2I_GROUPS, h = (blockIdx.x / T2I_GROUPS) % HEADS, p = blockIdx.x / (T2I_GROUPS * HEADS);
-    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
-    if (tid < TOK * 16) sq[tid] = q[((size_t)p * TOK + tid / 16) * INNER + h * 16 + (tid & 15)] * 0.25f;   // 16^-0.5
-    const size_t key0 = (size_t)p * NTOK_IMG + (size_t)grp * (NTOK_IMG / T2I_GROUPS);
-    const half_t* kb = K + key0 * ldk + h * 16;
-    const half_t* vb = V + key0 * ldv + h * 16;
-    half8_t kreg[T2I_KEYS][2], vreg[T2I_KEYS][2];
-#pragma unroll
-    for (int i = 0; i < T2I_KEYS; ++i) {
-        const size_t j = (size_t)i * T2I_THREADS + tid;
-        kreg[i][0] = *reinterpret_cast<const half8_t*>(kb + j * ldk);
-        kreg[i][1] = *reinterpret_cast<const half8_t*>(kb + j * ldk + 8);
-        vreg[i][0] = *reinterpret_cast<const half8_t*>(vb + j * ldv);
-        vreg[i][1] = *reinterpret_cast<const half8_t*>(vb + j * ldv + 8);
-    }
-    __syncthreads();
-    float* dst = part + ((((size_t)p * HEADS + h) * TOK) * T2I_PARTS + grp) * 18;
-#pragma unroll 1
-    for (int t = 0; t < TOK; ++t) {
-        // keep K / V as the f16 they arrived in: otherwise the conversions to float are hoisted out of the query loop
-#pragma unroll
-        for (int i = 0; i < T2I_KEYS; ++i)
-            asm volatile("" : "+v"(kreg[i][0]), "+v"(kreg[i][1]), "+v"(vreg[i][0]), "+v"(vreg[i][1]));
-        float sc[T2I_KEYS];
-#pragma unroll
-        for (int i = 0; i < T2I_KEYS; ++i) {
-            float s = 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) s = fmaf(sq[t * 16 + e], (float)kreg[i][e >> 3][e & 7], s);
-            sc[i] = s;
-        }
-        float m = sc[0];
-#pragma unroll
-        for (int i = 1; i < T2I_KEYS; ++i) m = fmaxf(m, sc[i]);
-        const float M = wave_max(m);
-        float l = 0.f, o[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[e] = 0.f;
-#pragma unroll
-        for (int i = 0; i < T2I_KEYS; ++i) {
-            const float pj = __expf(sc[i] - M);
-            l += pj;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[e] = fmaf(pj, (float)vreg[i][e >> 3][e & 7], o[e]);
-        }
-        const float ls = wave_sum(l);
-        float* d = wpart[t][wave];
-        if (lane == 0) { d[0] = M; d[1] = ls; }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float x = wave_sum(o[e]);
-            if (lane == 0) d[2 + e] = x;
-        }
-    }
-    // the four waves' partials of every query are folded here, in wave order: one triple per workgroup leaves
-    __syncthreads();
-    if (tid < TOK * 18) {
-        const int t = tid / 18, e = tid % 18;
-        float M = wpart[t][0][0];
-#pragma unroll
-        for (int w = 1; w < T2I_WAVES; ++w) M = fmaxf(M, wpart[t][w][0]);
-        float acc = 0.f;
-#pragma unroll
-        for (int w = 0; w < T2I_WAVES; ++w) acc += (e == 0 ? 0.f : wpart[t][w][e]) * __expf(wpart[t][w][0] - M);
-        dst[(size_t)t * T2I_PARTS * 18 + e] = e == 0 ? M : acc;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // Image positions attend to the 7 tokens.  Thread = (image token, head).
@@ -182,68 +92,6 @@ __global__ __launch_bounds__(256) void image_to_token_kernel(const half_t* __res
     half_t* orow = out + row * INNER + h * 16;
     *reinterpret_cast<half8_t*>(orow) = o0;
     *reinterpret_cast<half8_t*>(orow + 8) = o1;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Hyper-network MLPs + IoU head.  grid (P, 5): y = 0..3 mask token MLPs (-> 32), y = 4 IoU head (-> 4).
-// One wave per output neuron at a time: the 64 lanes read one 1-KB weight row with a single 16-byte load each
-// (a thread per neuron reads 64 rows per instruction, one line each), multiply with the activations in LDS and fold
-// with the DPP wave sum; 16 waves share the 256 neurons of a layer.
-constexpr int HEAD_THREADS = 1024;
-static_assert(DIM == 64 * 4, "one float4 of the weight row per lane");
-
-template <int N_OUT>
-DLIMG_DEVICE void head_layer(const float* x /*LDS*/, const float* __restrict__ w, const float* __restrict__ b, int n_out,
-                             bool relu, float* y) {
-    constexpr int WAVES = HEAD_THREADS / 64, ROWS = (N_OUT + WAVES - 1) / WAVES;
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
-    const float4_t v = reinterpret_cast<const float4_t*>(x)[lane];
-    float4_t wr[ROWS];
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) {             // every row of this wave is requested before the first is used
-        const int n = wave + r * WAVES;
-        wr[r] = float4_t{0.f, 0.f, 0.f, 0.f};
-        if (n < n_out) wr[r] = reinterpret_cast<const float4_t*>(w + (size_t)n * DIM)[lane];
-    }
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-        const int n = wave + r * WAVES;
-        const float acc = wave_sum((v[0] * wr[r][0] + v[1] * wr[r][1]) + (v[2] * wr[r][2] + v[3] * wr[r][3]));
-        if (lane == 0 && n < n_out) {
-            const float out = acc + b[n];
-            y[n] = relu ? fmaxf(out, 0.f) : out;
-        }
-    }
-}
-
-__global__ __launch_bounds__(HEAD_THREADS) void output_heads_kernel(k::TokenRows queries, k::HeadWeights hw,
-                                                                    float* __restrict__ hyper, float* __restrict__ iou) {
-    __shared__ __attribute__((aligned(16))) float x0[DIM], x1[DIM], x2[DIM];
-    __shared__ float2_t stat[1];
-    const int p = blockIdx.x, mi = blockIdx.y;
-    const int tok = mi < 4 ? 1 + mi : 0;
-    const size_t row = (size_t)p * TOK + tok;
-    // the token after norm_final_attn: statistics of its row by wave 0, normalised while it is staged
-    if (queries.ln_w && threadIdx.x < 64) {
-        const float4_t v = reinterpret_cast<const float4_t*>(queries.x + row * DIM)[threadIdx.x];
-        const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / DIM);
-        const float4_t d = v - mean;
-        const float var = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / DIM);
-        if (threadIdx.x == 0) stat[0] = float2_t{mean, 1.0f / sqrtf(var + queries.eps)};
-    }
-    __syncthreads();
-    if (threadIdx.x < DIM) {
-        float v = queries.x[row * DIM + threadIdx.x];
-        if (queries.ln_w) v = (v - stat[0][0]) * stat[0][1] * queries.ln_w[threadIdx.x] + queries.ln_b[threadIdx.x];
-        x0[threadIdx.x] = v;
-    }
-    __syncthreads();
-    head_layer<DIM>(x0, hw.w[mi][0], hw.b[mi][0], DIM, true, x1);
-    __syncthreads();
-    head_layer<DIM>(x1, hw.w[mi][1], hw.b[mi][1], DIM, true, x2);
-    __syncthreads();
-    float* dst = mi < 4 ? hyper + ((size_t)p * 4 + mi) * 32 : iou + (size_t)p * 4;
-    head_layer<32>(x2, hw.w[mi][2], hw.b[mi][2], mi < 4 ? 32 : 4, false, dst);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -321,66 +169,138 @@ DLIMG_DEVICE float token_row_load1(const k::TokenRows& m, const float2_t* stat, 
     return v;
 }
 
-// One output column per wave: Y[r][n] = act(in[r] . W[n] + b[n]) + resid[r][n] for all rows.
-// lds_in: rows of the input already in LDS ([rows][K] fp32; K <= 256) or null (then `op.in` is read from memory)
-// w_first: the wave's first 64 float4 of its weight row, requested by the caller before its own prologue (the row is
-// cold in the caches: its latency then runs behind the statistics / attention work instead of after it)
-DLIMG_DEVICE float4_t token_weight_prefetch(const k::TokenLinear& op, int first_col) {
+// Rows [row0, row0 + rows) of a token matrix as its consumers see them (LayerNorm, addend) into LDS [rows][256].  What a
+// launch of the token side costs is its chain of dependent round trips to L2 (1-2 us each), so every load of the step is
+// issued before the first wait.  blockDim.x == 256: thread = column; statistics a wave per row (token_row_stats' arithmetic).
+template <int MAXR>
+DLIMG_DEVICE void stage_token_rows(const k::TokenRows& m, int row0, int rows, float* x_lds, float2_t* stat_lds) {
+    const int c = threadIdx.x, lane = lane_id(), wave = c >> 6;
+    float xv[MAXR], av[MAXR];
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+        xv[r] = r < rows ? m.x[(size_t)(row0 + r) * DIM + c] : 0.f;
+        av[r] = (m.add && r < rows) ? m.add[(size_t)(row0 + r) * DIM + c] : 0.f;
+    }
+    const float lw = m.ln_w ? m.ln_w[c] : 1.f, lb = m.ln_w ? m.ln_b[c] : 0.f;
+    if (m.ln_w) {
+        constexpr int PER_WAVE = (MAXR + 3) / 4;
+        float4_t sv[PER_WAVE];
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i) {
+            const int r = wave + 4 * i;
+            sv[i] = r < rows ? reinterpret_cast<const float4_t*>(m.x + (size_t)(row0 + r) * DIM)[lane] : float4_t{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i) {
+            const int r = wave + 4 * i;
+            const float4_t v = sv[i];
+            const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / DIM);
+            const float4_t d = v - mean;
+            const float var = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / DIM);
+            if (lane == 0 && r < rows) stat_lds[r] = float2_t{mean, 1.0f / sqrtf(var + m.eps)};
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r)
+        if (r < rows) {
+            float v = xv[r];
+            if (m.ln_w) v = (v - stat_lds[r][0]) * stat_lds[r][1] * lw + lb;
+            x_lds[r * DIM + c] = v + av[r];
+        }
+    __syncthreads();
+}
+
+// One output column per wave: Y[r][n] = act(in[r] . W[n] + b[n]) + resid[r][n] for all rows of a slice (<= 16).
+// lds_in: rows of the input already in LDS ([rows][K] fp32; K <= 256) or null (then `op.in` is read from memory).
+// TokenColumn: what the wave needs from memory for its column, requested by the caller BEFORE its own prologue so that the
+// latency runs behind the statistics / attention work instead of after it: the first 64 float4 of the weight row (cold in
+// the caches), the bias, and -- lane L for row row0 + L, which is the lane that finishes and stores that row -- the
+// residual entry with its LayerNorm scale / shift.  [Before r03 lane 0 fetched bias and residual after the sums: one more
+// round trip to L2 per call, which a workgroup that runs several columns per wave pays several times over.]
+struct TokenColumn { float4_t w; float bias, rx, radd, rlw, rlb; };
+static_assert(TL_ROW_SLICE <= 16, "lane L of a wave finishes row L of the slice");
+DLIMG_DEVICE TokenColumn token_column_prefetch(const k::TokenLinear& op, int first_col, int row0, int row1) {
     const int lane = lane_id();
     const int n = first_col + (threadIdx.x >> 6);
-    if (n >= op.N || lane >= (op.K >> 2)) return float4_t{0.f, 0.f, 0.f, 0.f};
-    return reinterpret_cast<const float4_t*>(op.W + (size_t)n * op.K)[lane];
+    TokenColumn c{float4_t{0.f, 0.f, 0.f, 0.f}, 0.f, 0.f, 0.f, 1.f, 0.f};
+    if (n >= op.N) return c;
+    if (lane < (op.K >> 2)) c.w = reinterpret_cast<const float4_t*>(op.W + (size_t)n * op.K)[lane];
+    if (op.b) c.bias = op.b[n];
+    if (op.resid.x) {
+        const int r = min(row0 + lane, row1 - 1);
+        c.rx = op.resid.x[(size_t)r * DIM + n];
+        if (op.resid.add) c.radd = op.resid.add[(size_t)r * DIM + n];
+        if (op.resid.ln_w) { c.rlw = op.resid.ln_w[n]; c.rlb = op.resid.ln_b[n]; }
+    }
+    return c;
 }
-DLIMG_DEVICE void token_linear_columns(const k::TokenLinear& op, int rows, int first_col, const float* lds_in,
-                                       const float2_t* stat_in, const float2_t* stat_res, float4_t w_first, int row0 = 0) {
+// NR = rows of the slice, 7 or 14 (whole prompts): a compile-time count, so that the rows' loads and sums are straight-line
+// code.  [With a run-time bound every row sat behind its own branch and waited for its own load.]
+template <int NR>
+DLIMG_DEVICE void token_linear_columns(const k::TokenLinear& op, int first_col, const float* lds_in, const float2_t* stat_in,
+                                       const float2_t* stat_res, const TokenColumn& col, int row0) {
+    static_assert(NR % TOK == 0 && NR <= 16, "slices are whole prompts");
     const int lane = lane_id();
     const int n = first_col + (threadIdx.x >> 6);
     if (n >= op.N) return;
     const int K4 = op.K >> 2;
     const float4_t* wr = reinterpret_cast<const float4_t*>(op.W + (size_t)n * op.K);
-    for (int r0 = row0; r0 < rows; r0 += RCHUNK) {
-        float acc[RCHUNK];
+    float mine = 0.f;                       // the finished sum of row row0 + lane
 #pragma unroll
-        for (int r = 0; r < RCHUNK; ++r) acc[r] = 0.f;
+    for (int c0 = 0; c0 < NR; c0 += TOK) {
+        float acc[TOK];
+#pragma unroll
+        for (int r = 0; r < TOK; ++r) acc[r] = 0.f;
         for (int k4 = lane; k4 < K4; k4 += 64) {
-            const float4_t w = k4 == lane ? w_first : wr[k4];
+            const float4_t w = k4 == lane ? col.w : wr[k4];
+            float4_t x[TOK];
 #pragma unroll
-            for (int r = 0; r < RCHUNK; ++r) {
-                if (r0 + r < rows) {
-                    float4_t x;
-                    if (lds_in) x = reinterpret_cast<const float4_t*>(lds_in + (size_t)(r0 + r - row0) * op.K)[k4];
-                    else if (op.K == DIM) x = token_row_load4(op.in, stat_in, r0 + r, k4);
-                    else x = reinterpret_cast<const float4_t*>(op.in.x + (size_t)(r0 + r) * op.K)[k4];
-                    acc[r] = fmaf(x[0], w[0], fmaf(x[1], w[1], fmaf(x[2], w[2], fmaf(x[3], w[3], acc[r]))));
-                }
+            for (int r = 0; r < TOK; ++r) {
+                if (lds_in) x[r] = reinterpret_cast<const float4_t*>(lds_in + (size_t)(c0 + r) * op.K)[k4];
+                else if (op.K == DIM) x[r] = token_row_load4(op.in, stat_in, row0 + c0 + r, k4);
+                else x[r] = reinterpret_cast<const float4_t*>(op.in.x + (size_t)(row0 + c0 + r) * op.K)[k4];
             }
+#pragma unroll
+            for (int r = 0; r < TOK; ++r)
+                acc[r] = fmaf(x[r][0], w[0], fmaf(x[r][1], w[1], fmaf(x[r][2], w[2], fmaf(x[r][3], w[3], acc[r]))));
         }
 #pragma unroll
-        for (int r = 0; r < RCHUNK; ++r) {
-            float v = wave_sum(acc[r]);
-            if (lane == 0 && r0 + r < rows) {
-                v += op.b ? op.b[n] : 0.f;
-                if (op.relu) v = fmaxf(v, 0.f);
-                if (op.resid.x) v += token_row_load1(op.resid, stat_res, r0 + r, n);
-                op.Y[(size_t)(r0 + r) * op.N + n] = v;
-            }
+        for (int r = 0; r < TOK; ++r) {
+            const float v = wave_sum(acc[r]);
+            if (lane == c0 + r) mine = v;
         }
     }
+    if (lane < NR) {
+        const int r = row0 + lane;
+        float v = mine + col.bias;
+        if (op.relu) v = fmaxf(v, 0.f);
+        if (op.resid.x) {
+            float x = col.rx;
+            if (op.resid.ln_w) x = (x - stat_res[r][0]) * stat_res[r][1] * col.rlw + col.rlb;
+            v += x + col.radd;
+        }
+        op.Y[(size_t)r * op.N + n] = v;
+    }
 }
+// the body once for each slice size
+#define DLIMG_FOR_SLICE_ROWS(count, ...)                                   \
+    if ((count) == TL_ROW_SLICE) { constexpr int NR = TL_ROW_SLICE; __VA_ARGS__ } \
+    else { constexpr int NR = TOK; __VA_ARGS__ }
 
 __global__ __launch_bounds__(256) void token_linears_kernel(LinJob job) {
     __shared__ float2_t stat_in[TL_MAX_ROWS], stat_res[TL_MAX_ROWS];
     int o = 0, first = blockIdx.x * 4;
     while (o + 1 < job.count && first >= job.op[o].N) { first -= job.op[o].N; ++o; }      // N is a multiple of 4
     const k::TokenLinear& op = job.op[o];
-    const float4_t w_first = token_weight_prefetch(op, first);
     // rows are dealt to blockIdx.y in slices of TL_ROW_SLICE: more prompts are more workgroups, not longer ones
     const int row0 = blockIdx.y * TL_ROW_SLICE, row1 = min(job.rows, row0 + TL_ROW_SLICE);
+    const TokenColumn w_first = token_column_prefetch(op, first, row0, row1);
     const bool ln_in = op.in.ln_w && op.K == DIM, ln_res = op.resid.x && op.resid.ln_w;
     if (ln_in) token_row_stats(op.in, row1, stat_in, row0);
     if (ln_res) token_row_stats(op.resid, row1, stat_res, row0);
     if (ln_in || ln_res) __syncthreads();
-    token_linear_columns(op, row1, first, nullptr, stat_in, stat_res, w_first, row0);
+    DLIMG_FOR_SLICE_ROWS(row1 - row0, token_linear_columns<NR>(op, first, nullptr, stat_in, stat_res, w_first, row0);)
 }
 
 // Deep layers (the token MLP's second linear, K = 2048): one column per wave like token_linears_kernel, but the input
@@ -400,12 +320,16 @@ __global__ __launch_bounds__(256) void token_linear_deep_kernel(k::TokenLinear o
     for (int t = 0; t < TLD_MAX_K / 256; ++t)
         w[t] = (t < trips && n < op.N) ? reinterpret_cast<const float4_t*>(op.W + (size_t)n * op.K)[lane + 64 * t]
                                        : float4_t{0.f, 0.f, 0.f, 0.f};
+    k::TokenLinear tail = op;          // bias and residual of the wave's column, requested with the weights (TokenColumn)
+    tail.K = 0;
+    const TokenColumn col = token_column_prefetch(tail, blockIdx.x * 4, row0, row1);
     const float4_t* src = reinterpret_cast<const float4_t*>(op.in.x + (size_t)row0 * op.K);
     float4_t* dst = reinterpret_cast<float4_t*>(lds);
     for (int i = threadIdx.x; i < (row1 - row0) * K4; i += 256) dst[i] = src[i];
     if (op.resid.x && op.resid.ln_w) token_row_stats(op.resid, row1, stat_res, row0);
     __syncthreads();
     if (n >= op.N) return;
+    float mine = 0.f;
     for (int r = row0; r < row1; ++r) {
         const float4_t* xr = dst + (size_t)(r - row0) * K4;
         float acc = 0.f;
@@ -415,15 +339,128 @@ __global__ __launch_bounds__(256) void token_linear_deep_kernel(k::TokenLinear o
                 const float4_t x = xr[lane + 64 * t];
                 acc = fmaf(x[0], w[t][0], fmaf(x[1], w[t][1], fmaf(x[2], w[t][2], fmaf(x[3], w[t][3], acc))));
             }
-        float v = wave_sum(acc);
-        if (lane == 0) {
-            v += op.b ? op.b[n] : 0.f;
-            if (op.relu) v = fmaxf(v, 0.f);
-            if (op.resid.x) v += token_row_load1(op.resid, stat_res, r, n);
-            op.Y[(size_t)r * op.N + n] = v;
+        const float v = wave_sum(acc);
+        if (lane == r - row0) mine = v;
+    }
+    const int r = row0 + lane;
+    if (r < row1) {
+        float v = mine + col.bias;
+        if (op.relu) v = fmaxf(v, 0.f);
+        if (op.resid.x) {
+            float x = col.rx;
+            if (op.resid.ln_w) x = (x - stat_res[r][0]) * stat_res[r][1] * col.rlw + col.rlb;
+            v += x + col.radd;
         }
+        op.Y[(size_t)r * op.N + n] = v;
     }
 }
+
+// Tokens attend to the 4096 image positions (8 heads x 16), in two steps so that the 4096 keys of a head are spread
+// over 8 workgroups (one workgroup per head streams 0.5 MB through a single CU and takes 44 us):
+//   partial: workgroup = (prompt, head, key group of 512); a thread takes 2 keys (requested up front), then query
+//            by query scores them, does the softmax against the wave's maximum (one exponential per score, no
+//            rescale) and its part of P.V; butterfly inside each wave -> per-wave (max, sum, output[16]) in `part`
+//   merge  : the consumers (token_merge_linear_kernel, output_heads_kernel) fold the 8 group partials in a fixed order
+//            and apply the output projection themselves
+// The query projection (LayerNorm + positional part on the fly, 256 -> 128) can ride in this launch: a workgroup needs
+// the 16 columns of its head for 7 tokens only and computes them with the code (and bits) of token_linears_kernel.
+constexpr int T2I_GROUPS = 8;                                  // key groups per head
+constexpr int T2I_THREADS = 256;
+constexpr int T2I_KEYS = NTOK_IMG / T2I_GROUPS / T2I_THREADS;  // keys per thread
+constexpr int T2I_WAVES = T2I_THREADS / 64;
+constexpr int T2I_PARTS = T2I_GROUPS;                          // partial triples per (prompt, head, query)
+
+__global__ __launch_bounds__(T2I_THREADS) void token_to_image_partial_kernel(const float* __restrict__ q, k::TokenLinear qp,
+                                                                             const half_t* __restrict__ K, int ldk,
+                                                                             const half_t* __restrict__ V, int ldv,
+                                                                             float* __restrict__ part) {
+    __shared__ float sq[TOK * 16];
+    __shared__ float qrows[TOK * INNER];
+    __shared__ __attribute__((aligned(16))) float xrows[TOK * DIM];
+    __shared__ float2_t qstat[TOK];
+    __shared__ float wpart[TOK][T2I_WAVES][18];
+    const int grp = blockIdx.x % T2I_GROUPS, h = (blockIdx.x / T2I_GROUPS) % HEADS, p = blockIdx.x / (T2I_GROUPS * HEADS);
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    const size_t key0 = (size_t)p * NTOK_IMG + (size_t)grp * (NTOK_IMG / T2I_GROUPS);
+    const half_t* kb = K + key0 * ldk + h * 16;
+    const half_t* vb = V + key0 * ldv + h * 16;
+    half8_t kreg[T2I_KEYS][2], vreg[T2I_KEYS][2];
+#pragma unroll
+    for (int i = 0; i < T2I_KEYS; ++i) {
+        const size_t j = (size_t)i * T2I_THREADS + tid;
+        kreg[i][0] = *reinterpret_cast<const half8_t*>(kb + j * ldk);
+        kreg[i][1] = *reinterpret_cast<const half8_t*>(kb + j * ldk + 8);
+        vreg[i][0] = *reinterpret_cast<const half8_t*>(vb + j * ldv);
+        vreg[i][1] = *reinterpret_cast<const half8_t*>(vb + j * ldv + 8);
+    }
+    if (qp.W) {
+        // q = qp(rows of prompt p) for the 16 columns of head h, 4 columns (one per wave) at a time
+        const int row0 = p * TOK;
+        TokenColumn wf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wf[i] = token_column_prefetch(qp, h * 16 + 4 * i, row0, row0 + TOK);
+        stage_token_rows<TOK>(qp.in, row0, TOK, xrows, qstat);
+        qp.Y = qrows - (size_t)row0 * INNER;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) token_linear_columns<TOK>(qp, h * 16 + 4 * i, xrows, nullptr, nullptr, wf[i], row0);
+        __syncthreads();
+        if (tid < TOK * 16) sq[tid] = qrows[(tid / 16) * INNER + h * 16 + (tid & 15)] * 0.25f;               // 16^-0.5
+    } else if (tid < TOK * 16) {
+        sq[tid] = q[((size_t)p * TOK + tid / 16) * INNER + h * 16 + (tid & 15)] * 0.25f;
+    }
+    __syncthreads();
+    float* dst = part + ((((size_t)p * HEADS + h) * TOK) * T2I_PARTS + grp) * 18;
+#pragma unroll 1
+    for (int t = 0; t < TOK; ++t) {
+        // keep K / V as the f16 they arrived in: otherwise the conversions to float are hoisted out of the query loop
+#pragma unroll
+        for (int i = 0; i < T2I_KEYS; ++i)
+            asm volatile("" : "+v"(kreg[i][0]), "+v"(kreg[i][1]), "+v"(vreg[i][0]), "+v"(vreg[i][1]));
+        float sc[T2I_KEYS];
+#pragma unroll
+        for (int i = 0; i < T2I_KEYS; ++i) {
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s = fmaf(sq[t * 16 + e], (float)kreg[i][e >> 3][e & 7], s);
+            sc[i] = s;
+        }
+        float m = sc[0];
+#pragma unroll
+        for (int i = 1; i < T2I_KEYS; ++i) m = fmaxf(m, sc[i]);
+        const float M = wave_max(m);
+        float l = 0.f, o[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] = 0.f;
+#pragma unroll
+        for (int i = 0; i < T2I_KEYS; ++i) {
+            const float pj = __expf(sc[i] - M);
+            l += pj;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[e] = fmaf(pj, (float)vreg[i][e >> 3][e & 7], o[e]);
+        }
+        const float ls = wave_sum(l);
+        float* d = wpart[t][wave];
+        if (lane == 0) { d[0] = M; d[1] = ls; }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float x = wave_sum(o[e]);
+            if (lane == 0) d[2 + e] = x;
+        }
+    }
+    // the four waves' partials of every query are folded here, in wave order: one triple per workgroup leaves
+    __syncthreads();
+    if (tid < TOK * 18) {
+        const int t = tid / 18, e = tid % 18;
+        float M = wpart[t][0][0];
+#pragma unroll
+        for (int w = 1; w < T2I_WAVES; ++w) M = fmaxf(M, wpart[t][w][0]);
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < T2I_WAVES; ++w) acc += (e == 0 ? 0.f : wpart[t][w][e]) * __expf(wpart[t][w][0] - M);
+        dst[(size_t)t * T2I_PARTS * 18 + e] = e == 0 ? M : acc;
+    }
+}
+
 
 // Self-attention among the 7 tokens of every prompt (8 heads x 32), recomputed by every workgroup into LDS, followed by
 // the output projection (one column per wave) with bias and residual: one launch instead of two.
@@ -445,7 +482,7 @@ __global__ __launch_bounds__(256) void token_self_attn_out_kernel(const float* _
     const int row0 = p0 * TOK, row1 = p1 * TOK;
     float* att = lds;                                   // [rows of this slice][256]
     float2_t* stat_res = reinterpret_cast<float2_t*>(att + (size_t)TL_PROMPT_SLICE * TOK * DIM) - row0;     // indexed by global row
-    const float4_t w_first = token_weight_prefetch(op, blockIdx.x * 4);
+    const TokenColumn w_first = token_column_prefetch(op, blockIdx.x * 4, row0, row1);
     const int c = threadIdx.x;
     const float scale = 0.17677669529663687f;           // 32^-0.5
     for (int p = p0; p < p1; ++p) {
@@ -477,67 +514,318 @@ __global__ __launch_bounds__(256) void token_self_attn_out_kernel(const float* _
     }
     if (op.resid.x && op.resid.ln_w) token_row_stats(op.resid, row1, stat_res, row0);
     __syncthreads();
-    token_linear_columns(op, row1, blockIdx.x * 4, att, nullptr, stat_res, w_first, row0);
+    DLIMG_FOR_SLICE_ROWS(row1 - row0, token_linear_columns<NR>(op, blockIdx.x * 4, att, nullptr, stat_res, w_first, row0);)
 }
 
-// The per-key-group partials of the token-to-image attention folded (fixed order) by every workgroup into LDS, followed
-// by the output projection (K = 128) with bias and residual.
-__global__ __launch_bounds__(256) void token_merge_out_kernel(const float* __restrict__ part, k::TokenLinear op, int P) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* att = lds;                                   // [P * 7][128]
-    float2_t* stat_res = reinterpret_cast<float2_t*>(att + (size_t)P * TOK * INNER);
-    const float4_t w_first = token_weight_prefetch(op, blockIdx.x * 4);
-    const int p0 = blockIdx.y * TL_PROMPT_SLICE, p1 = min(P, p0 + TL_PROMPT_SLICE);
-    const int row0 = p0 * TOK, row1 = p1 * TOK;
-    const int total = (p1 - p0) * TOK * INNER;
-    for (int idx = threadIdx.x; idx < total; idx += 256) {       // ((p * TOK + t) * HEADS + h) * 16 + e, p local
-        const int e = idx & 15, h = (idx >> 4) % HEADS, t = (idx / (16 * HEADS)) % TOK, p = p0 + idx / (16 * HEADS * TOK);
-        const float* src = part + ((((size_t)p * HEADS + h) * TOK + t) * T2I_PARTS) * 18;
-        float M = src[0];
+// The rest of the token-to-image attention, done by its CONSUMERS (a launch of its own cost 9-16 us for 0.2 MFLOP):
+//   merge_partials         folds the 8 key-group partials of (prompt, head, token) in a fixed order -> att [rows][128] in LDS
+//   output projection      thread c = output column c: y[r][c] = att[r] . Wo[c] + b[c] + resid[r][c] with Wo TRANSPOSED
+//                          ([128][256], prepared at load) so that a wave reads 256 contiguous bytes per k
+// Every workgroup of the consumer repeats both for the rows it needs (7 x 256 x 128 FMAs at most per prompt, the 128 KB of
+// Wo come out of L2), so the result is the same bits wherever it is computed and nothing has to be exchanged.
+// NR rows starting at token t0 of prompt p0 (wrapping into the next prompts); blockDim.x >= 128.  Thread = (head, element)
+// for the rows r = (tid / 128) + i * (blockDim.x / 128); the 24 values of up to 4 rows are requested before the first is
+// used (one round trip to L2 for 4 rows, not four).
+template <int NR>
+DLIMG_DEVICE void merge_partials(const float* __restrict__ part, int p0, int t0, float* att /*LDS [NR][128]*/) {
+    const int e = threadIdx.x & 15, h = (threadIdx.x >> 4) & (HEADS - 1);
+    const int rstep = blockDim.x >> 7, rfirst = threadIdx.x >> 7;
+    constexpr int GROUP = 4;
+    for (int base = 0; base < NR; base += GROUP * rstep) {
+        float M[GROUP][T2I_PARTS], L[GROUP][T2I_PARTS], O[GROUP][T2I_PARTS];
 #pragma unroll
-        for (int w = 1; w < T2I_PARTS; ++w) M = fmaxf(M, src[w * 18]);
-        float ls = 0.f, os = 0.f;
+        for (int i = 0; i < GROUP; ++i) {
+            const int r = min(base + rfirst + i * rstep, NR - 1);
+            const int p = p0 + (t0 + r) / TOK, t = (t0 + r) % TOK;
+            const float* src = part + ((((size_t)p * HEADS + h) * TOK + t) * T2I_PARTS) * 18;
 #pragma unroll
-        for (int w = 0; w < T2I_PARTS; ++w) {
-            const float f = __expf(src[w * 18] - M);
-            ls += src[w * 18 + 1] * f;
-            os += src[w * 18 + 2 + e] * f;
+            for (int w = 0; w < T2I_PARTS; ++w) {
+                M[i][w] = src[w * 18];
+                L[i][w] = src[w * 18 + 1];
+                O[i][w] = src[w * 18 + 2 + e];
+            }
         }
-        att[idx] = os / ls;
+#pragma unroll
+        for (int i = 0; i < GROUP; ++i) {
+            const int r = base + rfirst + i * rstep;
+            float mx = M[i][0];
+#pragma unroll
+            for (int w = 1; w < T2I_PARTS; ++w) mx = fmaxf(mx, M[i][w]);
+            float ls = 0.f, os = 0.f;
+#pragma unroll
+            for (int w = 0; w < T2I_PARTS; ++w) {
+                const float f = __expf(M[i][w] - mx);
+                ls += L[i][w] * f;
+                os += O[i][w] * f;
+            }
+            if (r < NR) att[r * INNER + h * 16 + e] = os / ls;
+        }
     }
-    if (op.resid.x && op.resid.ln_w) token_row_stats(op.resid, row1, stat_res, row0);
+}
+// one row (the heads kernel): threads 0..127
+DLIMG_DEVICE void merge_partials_one(const float* __restrict__ part, int p, int t, float* att /*LDS [128]*/) {
+    const int e = threadIdx.x & 15, h = (threadIdx.x >> 4) & (HEADS - 1);
+    const float* src = part + ((((size_t)p * HEADS + h) * TOK + t) * T2I_PARTS) * 18;
+    float M[T2I_PARTS], L[T2I_PARTS], O[T2I_PARTS];
+#pragma unroll
+    for (int w = 0; w < T2I_PARTS; ++w) {
+        M[w] = src[w * 18];
+        L[w] = src[w * 18 + 1];
+        O[w] = src[w * 18 + 2 + e];
+    }
+    float mx = M[0];
+#pragma unroll
+    for (int w = 1; w < T2I_PARTS; ++w) mx = fmaxf(mx, M[w]);
+    float ls = 0.f, os = 0.f;
+#pragma unroll
+    for (int w = 0; w < T2I_PARTS; ++w) {
+        const float f = __expf(M[w] - mx);
+        ls += L[w] * f;
+        os += O[w] * f;
+    }
+    att[h * 16 + e] = os / ls;
+}
+// (mean, rstd) of rows held in LDS ([rows][256]); the arithmetic of token_row_stats
+DLIMG_DEVICE void lds_row_stats(const float* y, int rows, float eps, float2_t* stat) {
+    const int lane = lane_id(), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int r = wave; r < rows; r += nw) {
+        const float4_t v = reinterpret_cast<const float4_t*>(y + (size_t)r * DIM)[lane];
+        const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / DIM);
+        const float4_t d = v - mean;
+        const float var = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / DIM);
+        if (lane == 0) stat[r] = float2_t{mean, 1.0f / sqrtf(var + eps)};
+    }
+}
+
+// Token-to-image attention finished (merge + output projection + residual -> out.Y, written by the first column block) and
+// the NEXT linear (`next`, K = 256, whose input is the LayerNorm of those rows) applied to it: a workgroup = 16 columns
+// of `next` for the rows of one prompt.  [Kept small on purpose: code that runs once is fetched cold, and a 43 KB body --
+// 32 columns, two prompts, everything unrolled -- took 24 us where this one takes half.]
+constexpr int TML_COLS = 16;
+constexpr size_t TML_LDS = (size_t)(INNER * DIM + TL_ROW_SLICE * INNER + TL_ROW_SLICE * DIM) * 4 + 2 * TL_ROW_SLICE * 8;
+template <int NR>
+DLIMG_DEVICE void token_merge_linear_body(const float* __restrict__ part, const k::TokenLinear& out,
+                                          const float* __restrict__ out_wt, const k::TokenLinear& next, int p0, float* lds) {
+    float* wt = lds;                                     // [128][256]: the whole transposed output projection (128 KB)
+    float* att = wt + INNER * DIM;                       // [rows][128]
+    float* y = att + TL_ROW_SLICE * INNER;               // [rows][256]
+    float2_t* stat_res = reinterpret_cast<float2_t*>(y + TL_ROW_SLICE * DIM);
+    float2_t* stat_in = stat_res + TL_ROW_SLICE;
+    const int row0 = p0 * TOK, row1 = row0 + NR;
+    const int first = blockIdx.x * TML_COLS;
+    const int c = threadIdx.x, lane = lane_id(), wave = c >> 6;
+    // everything this workgroup reads is requested here: Wo as DMA into LDS (no registers), the wave's columns of `next`,
+    // the residual rows; the partials follow in merge_partials
+    for (int k = wave; k < INNER; k += 4) glds16(out_wt + (size_t)k * DIM + lane * 4, wt + k * DIM);
+    TokenColumn wf[TML_COLS / 4];
+#pragma unroll
+    for (int i = 0; i < TML_COLS / 4; ++i) wf[i] = token_column_prefetch(next, first + 4 * i, row0, row1);
+    float res[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) res[r] = out.resid.x ? out.resid.x[(size_t)(row0 + r) * DIM + c] : 0.f;
+    const bool res_ln = out.resid.x && out.resid.ln_w;
+    const float rw = res_ln ? out.resid.ln_w[c] : 1.f, rb = res_ln ? out.resid.ln_b[c] : 0.f;
+    const float ob = out.b ? out.b[c] : 0.f;
+    const float nw = next.in.ln_w ? next.in.ln_w[c] : 1.f, nb = next.in.ln_w ? next.in.ln_b[c] : 0.f;
+    float nadd[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) nadd[r] = next.in.add ? next.in.add[(size_t)(row0 + r) * DIM + c] : 0.f;
+    merge_partials<NR>(part, p0, 0, att);
+    if (res_ln) token_row_stats(out.resid, row1, stat_res - row0, row0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    token_linear_columns(op, row1, blockIdx.x * 4, att, nullptr, stat_res, w_first, row0);
+    // output projection: thread = column, k in order
+    float acc[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] = 0.f;
+#pragma unroll 2
+    for (int k4 = 0; k4 < INNER / 4; ++k4) {
+        float w[4];
+        float4_t a[NR];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = wt[(4 * k4 + i) * DIM + c];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) a[r] = reinterpret_cast<const float4_t*>(att)[r * (INNER / 4) + k4];
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[r] = fmaf(a[r][i], w[i], acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        float v = acc[r] + ob;
+        if (out.resid.x) v += res_ln ? (res[r] - stat_res[r][0]) * stat_res[r][1] * rw + rb : res[r];
+        y[r * DIM + c] = v;
+        if (blockIdx.x == 0) out.Y[(size_t)(row0 + r) * DIM + c] = v;
+    }
+    __syncthreads();
+    if (next.in.ln_w) {
+        lds_row_stats(y, NR, next.in.eps, stat_in);
+        __syncthreads();
+    }
+    if (next.in.ln_w || next.in.add) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            float v = y[r * DIM + c];
+            if (next.in.ln_w) v = (v - stat_in[r][0]) * stat_in[r][1] * nw + nb;
+            y[r * DIM + c] = v + nadd[r];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < TML_COLS / 4; ++i) token_linear_columns<NR>(next, first + 4 * i, y, nullptr, nullptr, wf[i], row0);
+}
+__global__ __launch_bounds__(256) void token_merge_linear_kernel(const float* __restrict__ part, k::TokenLinear out,
+                                                                 const float* __restrict__ out_wt, k::TokenLinear next, int P) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    token_merge_linear_body<TOK>(part, out, out_wt, next, blockIdx.y, lds);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Hyper-network MLPs + IoU head.  grid (P, 5): y = 0..3 mask token MLPs (-> 32), y = 4 IoU head (-> 4).
+// One wave per output neuron at a time: the 64 lanes read one 1-KB weight row with a single 16-byte load each
+// (a thread per neuron reads 64 rows per instruction, one line each), multiply with the activations in LDS and fold
+// with the DPP wave sum; 16 waves share the 256 neurons of a layer.
+constexpr int HEAD_THREADS = 1024;
+static_assert(DIM == 64 * 4, "one float4 of the weight row per lane");
+
+template <int N_OUT>
+DLIMG_DEVICE void head_layer(const float* x /*LDS*/, const float* __restrict__ w, const float* __restrict__ b, int n_out,
+                             bool relu, float* y) {
+    constexpr int WAVES = HEAD_THREADS / 64, ROWS = (N_OUT + WAVES - 1) / WAVES;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const float4_t v = reinterpret_cast<const float4_t*>(x)[lane];
+    float4_t wr[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {             // every row of this wave is requested before the first is used
+        const int n = wave + r * WAVES;
+        wr[r] = float4_t{0.f, 0.f, 0.f, 0.f};
+        if (n < n_out) wr[r] = reinterpret_cast<const float4_t*>(w + (size_t)n * DIM)[lane];
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int n = wave + r * WAVES;
+        const float acc = wave_sum((v[0] * wr[r][0] + v[1] * wr[r][1]) + (v[2] * wr[r][2] + v[3] * wr[r][3]));
+        if (lane == 0 && n < n_out) {
+            const float out = acc + b[n];
+            y[n] = relu ? fmaxf(out, 0.f) : out;
+        }
+    }
+}
+
+// The workgroup first finishes the final token-to-image attention for ITS token (merge of the partials, output projection,
+// residual: see merge_partials) and applies norm_final_attn to it.
+__global__ __launch_bounds__(HEAD_THREADS) void output_heads_kernel(const float* __restrict__ part, k::TokenLinear out,
+                                                                    const float* __restrict__ out_wt, k::TokenRows norm,
+                                                                    k::HeadWeights hw, float* __restrict__ hyper,
+                                                                    float* __restrict__ iou) {
+    __shared__ __attribute__((aligned(16))) float x0[DIM], x1[DIM], x2[DIM], att[INNER];
+    __shared__ float opart[4][DIM];
+    __shared__ float2_t stat[1], stat_res[1];
+    const int p = blockIdx.x, mi = blockIdx.y;
+    const int tok = mi < 4 ? 1 + mi : 0;
+    const int row = p * TOK + tok;
+    // one round trip: this thread's 32 weights of the output projection (column c, k quarter kq), the partials, the residual
+    const int c = threadIdx.x & (DIM - 1), kq = threadIdx.x >> 8;
+    float w[INNER / 4];
+#pragma unroll
+    for (int k = 0; k < INNER / 4; ++k) w[k] = out_wt[(size_t)(kq * (INNER / 4) + k) * DIM + c];
+    float res = 0.f, rw = 1.f, rb = 0.f;
+    if (out.resid.x && kq == 0) {
+        res = out.resid.x[(size_t)row * DIM + c];
+        if (out.resid.ln_w) { rw = out.resid.ln_w[c]; rb = out.resid.ln_b[c]; }
+    }
+    const float ob = (out.b && kq == 0) ? out.b[c] : 0.f;
+    if (threadIdx.x < INNER) merge_partials_one(part, p, tok, att);
+    if (out.resid.x && out.resid.ln_w && (threadIdx.x >> 6) == 15) {       // statistics of the residual row: the last wave
+        const int lane = lane_id();
+        const float4_t v = reinterpret_cast<const float4_t*>(out.resid.x + (size_t)row * DIM)[lane];
+        const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / DIM);
+        const float4_t d = v - mean;
+        const float var = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / DIM);
+        if (lane == 0) stat_res[0] = float2_t{mean, 1.0f / sqrtf(var + out.resid.eps)};
+    }
+    __syncthreads();
+    {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < INNER / 4; ++k) acc = fmaf(att[kq * (INNER / 4) + k], w[k], acc);
+        opart[kq][c] = acc;
+    }
+    __syncthreads();
+    if (kq == 0) {
+        float v = ((opart[0][c] + opart[1][c]) + (opart[2][c] + opart[3][c])) + ob;
+        if (out.resid.x) v += out.resid.ln_w ? (res - stat_res[0][0]) * stat_res[0][1] * rw + rb : res;
+        x1[c] = v;
+    }
+    __syncthreads();
+    // the token after norm_final_attn: statistics of its row by wave 0, normalised while it is staged
+    if (threadIdx.x < 64) lds_row_stats(x1, 1, norm.eps, stat);
+    __syncthreads();
+    if (threadIdx.x < DIM)
+        x0[threadIdx.x] = (x1[threadIdx.x] - stat[0][0]) * stat[0][1] * norm.ln_w[threadIdx.x] + norm.ln_b[threadIdx.x];
+    __syncthreads();
+    head_layer<DIM>(x0, hw.w[mi][0], hw.b[mi][0], DIM, true, x1);
+    __syncthreads();
+    head_layer<DIM>(x1, hw.w[mi][1], hw.b[mi][1], DIM, true, x2);
+    __syncthreads();
+    float* dst = mi < 4 ? hyper + ((size_t)p * 4 + mi) * 32 : iou + (size_t)p * 4;
+    head_layer<32>(x2, hw.w[mi][2], hw.b[mi][2], mi < 4 ? 32 : 4, false, dst);
 }
 
 // ---------------------------------------------------------------------------------------------
 // Image side, start of a decode: keys = embedding + no_mask_embed (has_mask_input == 0, segmentation.cpp:43-45) as fp32
 // and f16 (the A operand of the image-side projections), for all prompts.
-// One launch starts a decode: workgroups 0 .. P-1 build the prompts' tokens (prompt_tokens_block), the others the keys.
-// The two have nothing to do with each other except that both are the first step of their chain -- and every launch of
-// the decoder costs its 5-9 us of dependent latency.
+// One launch starts a decode: workgroups 0 .. P-1 write the prompts' tokens (the positional part every later step adds),
+// the next `lin_blocks` apply the first linears of the token side (q / k / v of the first self-attention) to those same
+// rows, which they rebuild in LDS instead of waiting for them, and the rest initialise the keys.  The three have nothing
+// to do with each other except that all are the first step of their chain -- and every launch of the decoder costs its
+// 5-9 us of dependent latency.  The prompts travel as kernel arguments: no host-to-device copy in front of a decode.
 struct DecoderStart {
-    const float* coords; const float* labels; const float* gauss; const float* point_embed; const float* not_a_point;
-    const float* iou_token; const float* mask_tokens; float* tokens; float* tokens_copy;
-    const float* const* emb; const float* no_mask; float* keys; half_t* keys_h; size_t n4_per_prompt; int P;
+    k::DecoderPrompts prompts;
+    const float* gauss; const float* point_embed; const float* not_a_point; const float* iou_token; const float* mask_tokens;
+    float* tokens;
+    LinJob first;
+    int lin_blocks, lin_cols;
+    const float* no_mask; float* keys; half_t* keys_h; size_t n4_per_prompt; int P;
 };
 __global__ __launch_bounds__(256) void decoder_start_kernel(DecoderStart a) {
+    __shared__ __attribute__((aligned(16))) float rows[TL_ROW_SLICE * DIM];
+    const int c = threadIdx.x;
     if ((int)blockIdx.x < a.P) {
-        prompt_tokens_block(blockIdx.x, a.coords, a.labels, a.gauss, a.point_embed, a.not_a_point, a.iou_token, a.mask_tokens,
-                            a.tokens, a.tokens_copy);
+        float v[TOK];
+        prompt_token_column(a.prompts, blockIdx.x, c, a.gauss, a.point_embed, a.not_a_point, a.iou_token, a.mask_tokens, v);
+#pragma unroll
+        for (int t = 0; t < TOK; ++t) a.tokens[((size_t)blockIdx.x * TOK + t) * DIM + c] = v[t];
         return;
     }
-    const float* const* __restrict__ emb = a.emb;
+    if ((int)blockIdx.x < a.P + a.lin_blocks) {
+        const int bid = blockIdx.x - a.P;
+        int o = 0, first = (bid % a.lin_cols) * 4;
+        while (o + 1 < a.first.count && first >= a.first.op[o].N) { first -= a.first.op[o].N; ++o; }
+        const k::TokenLinear& op = a.first.op[o];
+        const int row0 = (bid / a.lin_cols) * TL_ROW_SLICE, row1 = min(a.first.rows, row0 + TL_ROW_SLICE);
+        const TokenColumn w_first = token_column_prefetch(op, first, row0, row1);
+        for (int p = row0 / TOK; p * TOK < row1; ++p) {
+            float v[TOK];
+            prompt_token_column(a.prompts, p, c, a.gauss, a.point_embed, a.not_a_point, a.iou_token, a.mask_tokens, v);
+#pragma unroll
+            for (int t = 0; t < TOK; ++t) rows[(p * TOK + t - row0) * DIM + c] = v[t];
+        }
+        __syncthreads();
+        DLIMG_FOR_SLICE_ROWS(row1 - row0, token_linear_columns<NR>(op, first, rows, nullptr, nullptr, w_first, row0);)
+        return;
+    }
     const float* __restrict__ no_mask = a.no_mask;
     float* __restrict__ keys = a.keys;
     half_t* __restrict__ keys_h = a.keys_h;
     const size_t n4_per_prompt = a.n4_per_prompt;
-    const int P = a.P;
+    const int P = a.P, skip = a.P + a.lin_blocks;
     const size_t total = n4_per_prompt * P;
-    const size_t nblk = gridDim.x - P;
-    for (size_t i = (blockIdx.x - P) * (size_t)blockDim.x + threadIdx.x; i < total; i += nblk * blockDim.x) {
+    const size_t nblk = gridDim.x - skip;
+    for (size_t i = (blockIdx.x - skip) * (size_t)blockDim.x + threadIdx.x; i < total; i += nblk * blockDim.x) {
         const size_t p = i / n4_per_prompt, j = i % n4_per_prompt;
-        float4_t v = reinterpret_cast<const float4_t*>(emb[p])[j];
+        float4_t v = reinterpret_cast<const float4_t*>(a.prompts.emb[p])[j];
         v += reinterpret_cast<const float4_t*>(no_mask)[j % (DIM / 4)];
         reinterpret_cast<float4_t*>(keys)[i] = v;
         reinterpret_cast<half4_t*>(keys_h)[i] = half4_t{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
@@ -564,17 +852,31 @@ __global__ __launch_bounds__(256) void decoder_keys_norm_kernel(float* __restric
 
 namespace k {
 
-void decoder_start(const float* coords, const float* labels, const float* gauss, const float* point_embed,
-                   const float* not_a_point, const float* iou_token, const float* mask_tokens, float* tokens,
-                   float* tokens_copy, const float* const* emb_dev, const float* no_mask, float* keys, half_t* keys_h, int P,
-                   hipStream_t s) {
+void decoder_start(const DecoderPrompts& prompts, const float* gauss, const float* point_embed, const float* not_a_point,
+                   const float* iou_token, const float* mask_tokens, float* tokens, const TokenLinear* first, int n_first,
+                   const float* no_mask, float* keys, half_t* keys_h, int P, hipStream_t s) {
     if (P <= 0) return;
+    if (P > kDecoderMaxPrompts || n_first < 0 || n_first > TL_MAX_OPS) throw_error("decoder_start: too many prompts or layers");
     const size_t n4 = (size_t)NTOK_IMG * DIM / 4;
     const size_t total = n4 * P;
     const int key_blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    DecoderStart a{coords, labels, gauss, point_embed, not_a_point, iou_token, mask_tokens, tokens, tokens_copy,
-                   emb_dev, no_mask, keys, keys_h, n4, P};
-    hipLaunchKernelGGL(decoder_start_kernel, dim3(P + key_blocks), dim3(256), 0, s, a);
+    DecoderStart a{};
+    a.prompts = prompts;
+    a.gauss = gauss; a.point_embed = point_embed; a.not_a_point = not_a_point; a.iou_token = iou_token; a.mask_tokens = mask_tokens;
+    a.tokens = tokens;
+    a.first.count = n_first;
+    a.first.rows = P * TOK;
+    int cols = 0;
+    for (int i = 0; i < n_first; ++i) {
+        if (first[i].K != DIM || first[i].N <= 0 || first[i].N % 4 || first[i].in.ln_w || first[i].in.add || first[i].resid.x)
+            throw_error("decoder_start: the first linears take the plain 256-wide token rows");
+        a.first.op[i] = first[i];
+        cols += first[i].N / 4;
+    }
+    a.lin_cols = cols > 0 ? cols : 1;
+    a.lin_blocks = cols * ((P * TOK + TL_ROW_SLICE - 1) / TL_ROW_SLICE);
+    a.no_mask = no_mask; a.keys = keys; a.keys_h = keys_h; a.n4_per_prompt = n4; a.P = P;
+    hipLaunchKernelGGL(decoder_start_kernel, dim3(P + a.lin_blocks + key_blocks), dim3(256), 0, s, a);
 }
 
 size_t token_to_image_scratch_floats(int P) { return (size_t)P * HEADS * TOK * T2I_PARTS * 18; }
@@ -624,22 +926,32 @@ void token_self_attention_out(const float* q, const float* kx, const float* v, c
                        v, out, P);
 }
 
-void token_merge_out(const float* scratch, const TokenLinear& out, int P, hipStream_t s) {
+void token_merge_linear(const float* scratch, const TokenLinear& out, const float* out_wt, const TokenLinear& next, int P,
+                        hipStream_t s) {
     if (P <= 0) return;
-    if (P * TOK > TL_MAX_ROWS || out.K != INNER || out.N % 4) throw_error("token_merge_out: unsupported shape");
-    const size_t lds = (size_t)P * TOK * INNER * 4 + (size_t)P * TOK * 8;
+    if (P * TOK > TL_MAX_ROWS || out.K != INNER || out.N != DIM || out.resid.add || next.K != DIM || next.N % TML_COLS ||
+        next.resid.x)
+        throw_error("token_merge_linear: unsupported shape");
     static k::LdsOptIn opt_in;
-    opt_in.ensure((const void*)token_merge_out_kernel, 160 * 1024, "token_merge_out: the device refuses the kernel's LDS size");
-    hipLaunchKernelGGL(token_merge_out_kernel, dim3(out.N / 4, (P + TL_PROMPT_SLICE - 1) / TL_PROMPT_SLICE), dim3(256), lds, s, scratch, out,
-                       P);
+    opt_in.ensure((const void*)token_merge_linear_kernel, TML_LDS, "token_merge_linear: the device refuses the kernel's LDS size");
+    hipLaunchKernelGGL(token_merge_linear_kernel, dim3(next.N / TML_COLS, P), dim3(256),
+                       TML_LDS, s, scratch, out, out_wt, next, P);
 }
 
-void token_to_image_partials(const float* q, const half_t* K, int ldk, const half_t* V, int ldv, float* scratch, int P,
-                             hipStream_t s) {
+void token_to_image_partials(const float* q, const TokenLinear* q_proj, const half_t* K, int ldk, const half_t* V, int ldv,
+                             float* scratch, int P, hipStream_t s) {
     if (P <= 0) return;
     if (ldk % 8 || ldv % 8 || (((uintptr_t)K | (uintptr_t)V) & 15))
         throw_error("token_to_image_attention: K/V rows must be 16-byte aligned");
-    hipLaunchKernelGGL(token_to_image_partial_kernel, dim3(P * HEADS * T2I_GROUPS), dim3(T2I_THREADS), 0, s, q, K, ldk, V,
+    TokenLinear qp{};
+    if (q_proj) {
+        if (q_proj->K != DIM || q_proj->N != INNER || q_proj->resid.x || q_proj->relu)
+            throw_error("token_to_image_attention: the query projection is 256 -> 128 without residual");
+        qp = *q_proj;
+    } else if (!q) {
+        throw_error("token_to_image_attention: neither queries nor their projection given");
+    }
+    hipLaunchKernelGGL(token_to_image_partial_kernel, dim3(P * HEADS * T2I_GROUPS), dim3(T2I_THREADS), 0, s, q, qp, K, ldk, V,
                        ldv, scratch);
 }
 
@@ -649,9 +961,11 @@ void decoder_keys_norm(float* keys, const float* w, const float* b, float eps, h
     hipLaunchKernelGGL(decoder_keys_norm_kernel, dim3(rows / 4), dim3(256), 0, s, keys, w, b, eps, keys_h, rows);
 }
 
-void output_heads(const TokenRows& queries, const HeadWeights& hw, float* hyper, float* iou, int P, hipStream_t s) {
+void output_heads(const float* scratch, const TokenLinear& out, const float* out_wt, const TokenRows& norm,
+                  const HeadWeights& hw, float* hyper, float* iou, int P, hipStream_t s) {
     if (P <= 0) return;
-    hipLaunchKernelGGL(output_heads_kernel, dim3(P, 5), dim3(HEAD_THREADS), 0, s, queries, hw, hyper, iou);
+    if (out.K != INNER || out.N != DIM || !norm.ln_w) throw_error("output_heads: unsupported shape");
+    hipLaunchKernelGGL(output_heads_kernel, dim3(P, 5), dim3(HEAD_THREADS), 0, s, scratch, out, out_wt, norm, hw, hyper, iou);
 }
 
 void mask_logits(const float* up, const float* hyper, float* logits, int P, hipStream_t s) {

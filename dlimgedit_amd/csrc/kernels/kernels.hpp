@@ -119,13 +119,6 @@ void attention_global(const half_t* qkv, const half_t* rel_h, const half_t* rel_
                       int heads, int hd, hipStream_t);
 
 // ---- mask decoder (token side is tiny: fp32 VALU kernels) ------------------------------------
-// First launch of a decode.  tokens [P,7,256]: iou token, 4 mask tokens, 2 prompt tokens from (coords [P,2,2], labels
-// [P,2]); tokens_copy: the decoder's running queries start as a copy.  Image side: keys = emb[p] + no_mask (fp32 + f16)
-// for all prompts; emb_dev: DEVICE array of P pointers.
-void decoder_start(const float* coords, const float* labels, const float* gauss, const float* point_embed,
-                   const float* not_a_point, const float* iou_token, const float* mask_tokens, float* tokens,
-                   float* tokens_copy, const float* const* emb_dev, const float* no_mask, float* keys, half_t* keys_h, int P,
-                   hipStream_t s);
 // floats of workspace for the per-key-group partial results of token_to_image_partials
 size_t token_to_image_scratch_floats(int P);
 // image attends to tokens: q [P,4096,ldq] f16, k,v [P,7,128] f32 -> out [P,4096,128] f16
@@ -152,20 +145,45 @@ struct TokenLinear {
     int N = 0;
     int relu = 0;
 };
+// The prompts of one decode (at most 16 per launch), passed to the first kernel by value: coords [P][2][2] in the
+// 1024-pixel frame, labels [P][2], and per prompt the DEVICE address of its image embedding ([4096][256] fp32).
+constexpr int kDecoderMaxPrompts = 16;
+struct DecoderPrompts {
+    float coords[kDecoderMaxPrompts * 4];
+    float labels[kDecoderMaxPrompts * 2];
+    const float* emb[kDecoderMaxPrompts];
+};
+// First launch of a decode.  tokens [P,7,256]: iou token, 4 mask tokens, 2 prompt tokens (the positional part later steps
+// add); `first` (n_first <= 5 layers, K = 256, no LayerNorm / residual; their `in` is ignored) are applied to those same
+// rows in this launch.  Image side: keys = emb[p] + no_mask (fp32 + f16) for all prompts.
+void decoder_start(const DecoderPrompts& prompts, const float* gauss, const float* point_embed, const float* not_a_point,
+                   const float* iou_token, const float* mask_tokens, float* tokens, const TokenLinear* first, int n_first,
+                   const float* no_mask, float* keys, half_t* keys_h, int P, hipStream_t s);
 // up to 5 layers over the same rows (<= 112) in one launch
 void token_linears(const TokenLinear* ops, int count, int rows, hipStream_t);
 // self-attention among the 7 tokens of each prompt + its output projection `out` (K = 256) in one launch
 void token_self_attention_out(const float* q, const float* k, const float* v, const TokenLinear& out, int P, hipStream_t);
-// token-to-image attention in two launches: per-key-group partials, then their fold + the output projection (K = 128)
-void token_to_image_partials(const float* q, const half_t* K, int ldk, const half_t* V, int ldv, float* scratch, int P,
-                             hipStream_t);
-void token_merge_out(const float* scratch, const TokenLinear& out, int P, hipStream_t);
+// token-to-image attention.  partials: per key group (max, sum, output) of every (prompt, head, token); the queries
+// are q [P,7,128], or are computed in the launch as q_proj (256 -> 128, LayerNorm / positional part on the fly).  The
+// fold of the partials + output projection `out` (128 -> 256, out_wt = its weight transposed [128][256]) + residual is
+// done by the consumer's launch: token_merge_linear (writes out.Y and applies `next`, a K = 256 layer whose input is
+// next.in's LayerNorm of out.Y) or output_heads.
+void token_to_image_partials(const float* q, const TokenLinear* q_proj, const half_t* K, int ldk, const half_t* V, int ldv,
+                             float* scratch, int P, hipStream_t);
+void token_merge_linear(const float* scratch, const TokenLinear& out, const float* out_wt, const TokenLinear& next, int P,
+                        hipStream_t);
+// The image positions' half of a two-way block in one launch (kernels/decoder_image.hip):
+// keys <- LayerNorm(keys + attention(q -> token k / v) Wo + bias), fp32 in place + f16 copy.  q: f16 [P*4096][ldq] (128 wide),
+// tk / tv: fp32 [P][7][128], W: f16 [256][128].
+void image_update(const half_t* q, int ldq, const float* tk, const float* tv, const half_t* W, const float* bias,
+                  const float* ln_w, const float* ln_b, float eps, float* keys, half_t* keys_h, int P, hipStream_t);
 // keys = LayerNorm(keys) in place + f16(keys)
 void decoder_keys_norm(float* keys, const float* w, const float* b, float eps, half_t* keys_h, int P, hipStream_t);
-// hyper-network MLPs (4 x 256->256->256->32) and IoU head (256->256->256->4) on the output tokens
+// hyper-network MLPs (4 x 256->256->256->32) and IoU head (256->256->256->4) on the output tokens: the launch finishes the
+// final token-to-image attention (scratch, out, out_wt as above) for the five tokens it needs and applies `norm` to them
 struct HeadWeights { const float* w[5][3]; const float* b[5][3]; };
-void output_heads(const TokenRows& queries /*[P,7,256]*/, const HeadWeights& hw, float* hyper /*[P,4,32]*/,
-                  float* iou /*[P,4]*/, int P, hipStream_t);
+void output_heads(const float* scratch, const TokenLinear& out, const float* out_wt, const TokenRows& norm /*ln_w, ln_b, eps*/,
+                  const HeadWeights& hw, float* hyper /*[P,4,32]*/, float* iou /*[P,4]*/, int P, hipStream_t);
 // low-res logits [P,4,256,256] from the upscaled embedding in quad order and the hyper vectors.
 // up: [P*65536, 32] f32, row = ((y*64+x)*4 + dy1*2+dx1)*4 + dy2*2+dx2  (pixel Y = 4y+2dy1+dy2, X likewise)
 void mask_logits(const float* up, const float* hyper, float* logits, int P, hipStream_t);

@@ -77,6 +77,14 @@ struct Loader {
         l.out = out;
         l.in = in;
     }
+    // [out][in] weight as [in][out]
+    void transposed_f(std::string const& prefix, int out, int in, DeviceBuffer<float>& dst) {
+        HostTensor const& w = file.get(prefix + ".w", {out, in});
+        std::vector<float> t((size_t)out * in);
+        for (int n = 0; n < out; ++n)
+            for (int i = 0; i < in; ++i) t[(size_t)i * out + n] = w.data[(size_t)n * in + i];
+        f32_host(t, dst);
+    }
     void norm(std::string const& prefix, int dim, NormW& n) {
         f32(prefix + ".w", {dim}, n.w);
         f32(prefix + ".b", {dim}, n.b);
@@ -229,6 +237,7 @@ SamWeights::SamWeights(std::string const& weight_path, int device_index) : devic
         ld.norm(p + ".ln4", 256, L.ln4);
         ld.linear_f(p + ".t2i.q", 128, 256, L.t2i_q);
         ld.linear_f(p + ".t2i.o", 256, 128, L.t2i_o);
+        ld.transposed_f(p + ".t2i.o", 256, 128, L.t2i_o_t);
         ld.fused_h({p + ".t2i.k", p + ".i2t.q", p + ".t2i.v"}, 128, 256, L.img_kqv);
         pos_term(L.img_kqv, 256, L.pos_kqv);
         ld.linear_f(p + ".mlp.fc1", 2048, 256, L.mlp1);
@@ -239,6 +248,7 @@ SamWeights::SamWeights(std::string const& weight_path, int device_index) : devic
     }
     ld.linear_f("dec.final.q", 128, 256, final_q_);
     ld.linear_f("dec.final.o", 256, 128, final_o_);
+    ld.transposed_f("dec.final.o", 256, 128, final_o_t_);
     ld.fused_h({"dec.final.k", "dec.final.v"}, 128, 256, final_kv_);
     pos_term(final_kv_, 128, final_pos_kv_);
     ld.norm("dec.ln_final", 256, ln_final_);
@@ -713,27 +723,16 @@ void SamModel::decode_chunk(float const* const* emb, float const* coords, float 
     float* iou_out = iou_.get() + (size_t)first * 4;
 
     auto body = [&] {
-        // prompt -> device (through pinned memory so the copy is stream-ordered): coords [P][4], labels [P][2] and the
-        // P embedding pointers in one copy
-        const unsigned ring = prompt_seq_++ % kPromptRing;
-        HIP_CHECK(hipEventSynchronize(prompt_done_[ring]));     // the copy issued kPromptRing decodes ago has run
-        float* pin = static_cast<float*>(prompt_pinned_.get()) + (size_t)ring * dec_count_ * 8;
-        std::memcpy(pin, coords, (size_t)P * 4 * sizeof(float));
-        std::memcpy(pin + (size_t)P * 4, labels, (size_t)P * 2 * sizeof(float));
-        std::memcpy(pin + (size_t)P * 6, emb, (size_t)P * sizeof(float const*));
-        HIP_CHECK(hipMemcpyAsync(coords_.get(), pin, (size_t)P * 8 * sizeof(float), hipMemcpyHostToDevice, s));
-        HIP_CHECK(hipEventRecord(prompt_done_[ring], s));
-        float const* const* emb_dev = reinterpret_cast<float const* const*>(coords_.get() + (size_t)P * 6);
-        // prompt tokens, and keys = image_embedding + no_mask_embed (has_mask_input == 0, segmentation.cpp:43-45)
-        k::decoder_start(coords_.get(), coords_.get() + (size_t)P * 4, W.pe_gauss_.get(), W.pe_point_.get(),
-                         W.pe_not_a_point_.get(), W.iou_token_.get(), W.mask_tokens_.get(), tokens_.get(), queries_.get(),
-                         emb_dev, W.pe_no_mask_.get(), keys_.get(), keys_h_.get(), P, s);
+        // prompts travel as kernel arguments of the first launch
+        k::DecoderPrompts prompts{};
+        std::memcpy(prompts.coords, coords, (size_t)P * 4 * sizeof(float));
+        std::memcpy(prompts.labels, labels, (size_t)P * 2 * sizeof(float));
+        for (int i = 0; i < P; ++i) prompts.emb[i] = emb[i];
 
         // Token side.  `cur` is the running token matrix as its consumers read it: un-normalised rows plus the
         // LayerNorm that belongs in front of them (applied on the fly by whoever reads, kernels/decoder.hip).
         float const* qpe = tokens_.get();
         k::TokenRows cur;
-        cur.x = queries_.get();
         auto rows_of = [&](k::TokenRows r, bool with_pe) { if (with_pe) r.add = qpe; return r; };
         auto lin = [&](k::TokenRows in, int K, LinearF const& l, k::TokenRows resid, float* Y, int relu) {
             k::TokenLinear op;
@@ -756,28 +755,32 @@ void SamModel::decode_chunk(float const* const* emb, float const* coords, float 
             k::gemm(g, s);
         };
 
+        // First launch: prompt tokens (= the positional part `qpe` of every later query), keys = image_embedding +
+        // no_mask_embed (has_mask_input == 0, segmentation.cpp:43-45), and the q / k / v projections of the first
+        // self-attention, whose input ARE the prompt tokens (no PE, no LayerNorm in front of the first block).
+        {
+            DecoderLayer const& L = W.dec_[0];
+            k::TokenLinear qkv[3] = {lin({}, 256, L.self_attn.q, {}, sq_.get(), 0), lin({}, 256, L.self_attn.k, {}, sk_.get(), 0),
+                                     lin({}, 256, L.self_attn.v, {}, sv_.get(), 0)};
+            k::decoder_start(prompts, W.pe_gauss_.get(), W.pe_point_.get(), W.pe_not_a_point_.get(), W.iou_token_.get(),
+                             W.mask_tokens_.get(), tokens_.get(), qkv, 3, W.pe_no_mask_.get(), keys_.get(), keys_h_.get(), P, s);
+        }
         for (int i = 0; i < 2; ++i) {
             DecoderLayer const& L = W.dec_[i];
-            // (1) self attention of the tokens; the first layer has no PE and no residual.  The q / k / v projections of
-            // the second layer were computed by the first layer's step (4) launch (same input rows).
-            if (i == 0) {
-                k::TokenLinear qkv[3] = {lin(cur, 256, L.self_attn.q, {}, sq_.get(), 0), lin(cur, 256, L.self_attn.k, {}, sk_.get(), 0),
-                                         lin(cur, 256, L.self_attn.v, {}, sv_.get(), 0)};
-                k::token_linears(qkv, 3, T, s);
-            }
+            // (1) self attention of the tokens; the first layer has no residual.  The q / k / v projections were computed
+            // by the launch that produced their input rows (decoder_start, or the first layer's step (4)).
             k::token_self_attention_out(sq_.get(), sk_.get(), sv_.get(),
                                         lin({}, 256, L.self_attn.o, i == 0 ? k::TokenRows{} : cur, tsa_.get(), 0), P, s);
             const k::TokenRows q1 = normed(tsa_.get(), L.ln1);
-            // (2) tokens -> image: [K | Q of step 4 | V] = [(keys + pos) Wk | (keys + pos) Wq | keys Wv]
+            // (2) tokens -> image: [K | Q of step 4 | V] = [(keys + pos) Wk | (keys + pos) Wq | keys Wv]; the query
+            // projection runs inside the attention launch, the fold + output projection inside the MLP's first launch
             img_gemm(L.img_kqv, L.pos_kqv);
-            k::TokenLinear tq = lin(rows_of(q1, true), 256, L.t2i_q, {}, tq_.get(), 0);
-            k::token_linears(&tq, 1, T, s);
-            k::token_to_image_partials(tq_.get(), kqv_h_.get(), 384, kqv_h_.get() + 256, 384, t2i_part_.get(), P, s);
-            k::token_merge_out(t2i_part_.get(), lin({}, 128, L.t2i_o, q1, tt2i_.get(), 0), P, s);
+            const k::TokenLinear tq = lin(rows_of(q1, true), 256, L.t2i_q, {}, nullptr, 0);
+            k::token_to_image_partials(nullptr, &tq, kqv_h_.get(), 384, kqv_h_.get() + 256, 384, t2i_part_.get(), P, s);
             const k::TokenRows q2 = normed(tt2i_.get(), L.ln2);
             // (3) token MLP
-            k::TokenLinear m1 = lin(q2, 256, L.mlp1, {}, tmlp_.get(), 1);
-            k::token_linears(&m1, 1, T, s);
+            k::token_merge_linear(t2i_part_.get(), lin({}, 128, L.t2i_o, q1, tt2i_.get(), 0), L.t2i_o_t.get(),
+                                  lin(q2, 256, L.mlp1, {}, tmlp_.get(), 1), P, s);
             k::TokenLinear m2 = lin(plain(tmlp_.get()), 2048, L.mlp2, q2, queries_.get(), 0);
             k::token_linears(&m2, 1, T, s);
             const k::TokenRows q3 = normed(queries_.get(), L.ln3);
@@ -795,22 +798,13 @@ void SamModel::decode_chunk(float const* const* emb, float const* coords, float 
                 kv[n_ops++] = lin(rows_of(q3, true), 256, W.final_q_, {}, sq_.get(), 0);
             }
             k::token_linears(kv, n_ops, T, s);
-            k::image_to_token_attention(kqv_h_.get() + 128, 384, tk_.get(), tv_.get(), att_img_h_.get(), P, s);
-            k::GemmArgs g;
-            g.A = att_img_h_.get(); g.lda = 128; g.W = L.i2t_o.w.get(); g.ldw = 128; g.bias = L.i2t_o.b.get();
-            g.resid = keys_.get(); g.ldr = 256; g.resid_mod = M; g.out_f32 = keys_.get(); g.ldc32 = 256;
-            g.M = M; g.N = 256; g.K = 128;
-            g.shared_gpu = shared_gpu_;
-            g.unit_rows = kTokens;
-            k::gemm(g, s);
-            k::decoder_keys_norm(keys_.get(), L.ln4.w.get(), L.ln4.b.get(), kDecLnEps, keys_h_.get(), P, s);
+            k::image_update(kqv_h_.get() + 128, 384, tk_.get(), tv_.get(), L.i2t_o.w.get(), L.i2t_o.b.get(), L.ln4.w.get(),
+                            L.ln4.b.get(), kDecLnEps, keys_.get(), keys_h_.get(), P, s);
             cur = q3;
         }
-        // final token -> image attention
+        // final token -> image attention; its fold + output projection + norm_final_attn happen in output_heads
         img_gemm(W.final_kv_, W.final_pos_kv_);
-        k::token_to_image_partials(sq_.get(), kqv_h_.get(), 256, kqv_h_.get() + 128, 256, t2i_part_.get(), P, s);
-        k::token_merge_out(t2i_part_.get(), lin({}, 128, W.final_o_, cur, tsa_.get(), 0), P, s);
-        const k::TokenRows qf = normed(tsa_.get(), W.ln_final_);
+        k::token_to_image_partials(sq_.get(), nullptr, kqv_h_.get(), 256, kqv_h_.get() + 128, 256, t2i_part_.get(), P, s);
 
         // upscaling: ConvT(256->64) -> LN2d -> GELU -> ConvT(64->32) -> GELU, sub-pixels kept in quad order
         k::GemmArgs g;
@@ -834,7 +828,8 @@ void SamModel::decode_chunk(float const* const* emb, float const* coords, float 
                 hw.w[m][j] = W.heads_[m][j].w.get();
                 hw.b[m][j] = W.heads_[m][j].b.get();
             }
-        k::output_heads(qf, hw, hyper_.get(), iou_out, P, s);
+        k::output_heads(t2i_part_.get(), lin({}, 128, W.final_o_, cur, nullptr, 0), W.final_o_t_.get(), normed(nullptr, W.ln_final_),
+                        hw, hyper_.get(), iou_out, P, s);
         k::mask_logits(up_.get(), hyper_.get(), logits_out, P, s);
     };
     timed(ST_DECODER, 3.62e9 * P, body);

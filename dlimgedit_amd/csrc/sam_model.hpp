@@ -60,6 +60,7 @@ struct DecoderLayer {
     TokenAttention self_attn;
     NormW ln1, ln2, ln3, ln4;
     LinearF t2i_q, t2i_o;            // token side of token->image attention
+    DeviceBuffer<float> t2i_o_t;     // t2i_o.w transposed: [128][256] (kernels/decoder.hip, out_projection_columns)
     LinearH img_kqv;                 // [t2i.k ; i2t.q ; t2i.v] fused: one GEMM over the keys
     DeviceBuffer<float> pos_kqv;     // [4096, 384] pos . [Wk ; Wq]^T, zeros for the v columns (which take no pos)
     LinearF mlp1, mlp2;
@@ -85,6 +86,7 @@ struct SamWeights {
     DeviceBuffer<float> iou_token_, mask_tokens_;
     std::array<DecoderLayer, 2> dec_;
     LinearF final_q_, final_o_;
+    DeviceBuffer<float> final_o_t_;       // final_o_.w transposed: [128][256]
     LinearH final_kv_;                    // [final.k ; final.v]
     DeviceBuffer<float> final_pos_kv_;    // [4096, 256] pos . Wk^T | 0
     NormW ln_final_;

@@ -13,7 +13,7 @@ def main():
     sym = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
     rows = db.execute(f"select s.kernel_name, d.start, d.end from {kd} d join {sym} s on d.kernel_id=s.id "
                       f"order by d.start").fetchall()
-    starts = [i for i, r in enumerate(rows) if "prompt_tokens" in r[0]]
+    starts = [i for i, r in enumerate(rows) if "decoder_start" in r[0] or "prompt_tokens" in r[0]]
     a, b = starts[-back - 1], starts[-back]
     t0, prev_end, busy = rows[a][1], rows[a][1], 0.0
     for name, s, e in rows[a:b]:
