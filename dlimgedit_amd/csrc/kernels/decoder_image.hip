@@ -185,6 +185,192 @@ __global__ __launch_bounds__(256) void image_update_kernel(ImageUpdate a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Up-scaling path and mask product in one launch:
+//   logits[p][mk][Y][X] = hyper[p][mk] . GELU(ConvT2(GELU(LN2d(ConvT1(keys)))))[pixel]
+// Both transposed convolutions (kernel 2, stride 2) are GEMMs over the image positions whose output columns are the four
+// sub-pixels times the output channels (SamWeights: rows of W1 = s1 * 64 + co, rows of W2 = s2 * 32 + c2).  A wave takes 16
+// image positions through all of it:
+//   stage A  [16][256] x W1^T -> 4 sub-pixels x 64 channels per position (v_mfma_f32_16x16x32_f16, W1 in LDS)
+//   stage B  + bias, LayerNorm over the 64 channels of a sub-pixel (16 values in the lane, the rest in the three other lane
+//            groups), GELU, f16: in the accumulator layout these ARE the A fragments of stage C, with the k-permutation
+//            k = (2 kk + i / 4) * 16 + 4 g + i % 4 that the W2 fragments are read with
+//   stage C  per sub-pixel s1: [16][64] x W2^T -> 4 sub-pixels s2 x 32 channels, + bias, GELU, and the product with the four
+//            hyper vectors of the prompt; lane group g ends up with mask g of every pixel (a 4 x 4 transpose-and-add over
+//            the lane groups: three exchanges per pixel) and stores it
+// Replaces two GEMMs, a LayerNorm launch and mask_logits, and with them 4 + 4 + 2 + 2 + 8 + 8 MB of HBM traffic per prompt
+// for intermediate results (up1 fp32, up1 f16, up2 fp32): the kernel reads the keys (2 MB) and writes the logits (1 MB).
+constexpr int UP_ROWS = 64;
+constexpr int UP_W1STRIDE = DIM + 8;          // halves per row of W1 in LDS (528 B)
+constexpr int UP_W2STRIDE = 64 + 8;           // halves per row of W2 in LDS (144 B)
+constexpr int UP_CONST = 256 + 64 + 64 + 128 + 128;      // b1 | ln_w | ln_b | b2 | hyper
+constexpr size_t UP_LDS = (size_t)DIM * UP_W1STRIDE * 2 + (size_t)128 * UP_W2STRIDE * 2 + UP_CONST * 4;
+
+struct Upscale {
+    const half_t* keys_h;                      // [P*4096][256]
+    const half_t* W1; const float* b1;         // [256][256], [256]
+    const float* ln_w; const float* ln_b; float eps;
+    const half_t* W2; const float* b2;         // [128][64], [128]
+    const float* hyper;                        // [P][4][32]
+    float* logits;                             // [P][4][256][256]
+};
+
+__global__ __launch_bounds__(256) void upscale_logits_kernel(Upscale a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t* w1 = reinterpret_cast<half_t*>(smem);
+    half_t* w2 = w1 + (size_t)DIM * UP_W1STRIDE;
+    float* cst = reinterpret_cast<float*>(w2 + (size_t)128 * UP_W2STRIDE);
+    const float* c_b1 = cst;
+    const float* c_lw = cst + 256;
+    const float* c_lb = cst + 320;
+    const float* c_b2 = cst + 384;
+    const float* c_hy = cst + 512;
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const size_t row0 = (size_t)blockIdx.x * UP_ROWS;
+    const int p = (int)(row0 / NTOK_IMG);
+    const size_t row = row0 + wave * 16 + m;
+
+    // the wave's own 16 rows of the keys, as A fragments: k = 32 kk + 8 g .. + 7
+    half8_t a1[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) a1[kk] = *reinterpret_cast<const half8_t*>(a.keys_h + row * DIM + 32 * kk + 8 * g);
+    // weights and constants -> LDS (W1: 8192 chunks of 16 bytes, 32 per thread in two rounds)
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        half8_t wr[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ch = tid + 256 * (16 * round + i);
+            wr[i] = *reinterpret_cast<const half8_t*>(a.W1 + (size_t)(ch >> 5) * DIM + (ch & 31) * 8);
+        }
+        if (round == 0) {
+            half8_t w2r[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ch = tid + 256 * i;
+                w2r[i] = *reinterpret_cast<const half8_t*>(a.W2 + (size_t)(ch >> 3) * 64 + (ch & 7) * 8);
+            }
+            const float v_b1 = a.b1[tid];
+            const float v_ln = tid < 64 ? a.ln_w[tid] : (tid < 128 ? a.ln_b[tid - 64] : a.b2[tid - 128]);
+            const float v_hy = tid < 128 ? a.hyper[(size_t)p * 128 + tid] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ch = tid + 256 * i;
+                *reinterpret_cast<half8_t*>(w2 + (size_t)(ch >> 3) * UP_W2STRIDE + (ch & 7) * 8) = w2r[i];
+            }
+            cst[tid] = v_b1;
+            cst[256 + tid] = v_ln;                 // ln_w | ln_b | b2 are contiguous
+            if (tid < 128) cst[512 + tid] = v_hy;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ch = tid + 256 * (16 * round + i);
+            *reinterpret_cast<half8_t*>(w1 + (size_t)(ch >> 5) * UP_W1STRIDE + (ch & 31) * 8) = wr[i];
+        }
+    }
+    __syncthreads();
+
+    // stage A: acc1[jt][r] = up1[row m][column jt * 16 + 4 g + r], column = s1 * 64 + co
+    f32x4 acc1[16];
+#pragma unroll
+    for (int jt = 0; jt < 16; ++jt) acc1[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+        const half_t* wl = w1 + (size_t)m * UP_W1STRIDE + 8 * g;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int jt = 0; jt < 16; ++jt) {
+                const half8_t b = *reinterpret_cast<const half8_t*>(wl + (size_t)jt * 16 * UP_W1STRIDE + 32 * kk);
+                acc1[jt] = mfma16(b, a1[kk], acc1[jt]);
+            }
+    }
+
+    const int tok = (int)(row % NTOK_IMG), ty = tok >> 6, tx = tok & 63;
+    float* out = a.logits + ((size_t)p * 4 + g) * 65536;
+    const half_t* w2l = w2 + (size_t)m * UP_W2STRIDE + 4 * g;
+#pragma unroll
+    for (int s1 = 0; s1 < 4; ++s1) {
+        // stage B: LayerNorm2d over the 64 channels of sub-pixel s1, GELU, f16 -> A fragments of stage C
+        f32x4 v[4];
+        float sum = 0.f;
+#pragma unroll
+        for (int jl = 0; jl < 4; ++jl) {
+            const float4_t bv = reinterpret_cast<const float4_t*>(c_b1)[(4 * s1 + jl) * 4 + g];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[jl][r] = acc1[4 * s1 + jl][r] + bv[r];
+                sum += v[jl][r];
+            }
+        }
+        const float mean = sum_over_groups(sum) / 64.0f;
+        float sq = 0.f;
+#pragma unroll
+        for (int jl = 0; jl < 4; ++jl)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[jl][r] -= mean;
+                sq = fmaf(v[jl][r], v[jl][r], sq);
+            }
+        const float rstd = 1.0f / sqrtf(sum_over_groups(sq) / 64.0f + a.eps);
+        half8_t a2[2];
+#pragma unroll
+        for (int jl = 0; jl < 4; ++jl) {
+            const float4_t wv = reinterpret_cast<const float4_t*>(c_lw)[jl * 4 + g];
+            const float4_t bv = reinterpret_cast<const float4_t*>(c_lb)[jl * 4 + g];
+            float4_t y;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = v[jl][r] * rstd * wv[r] + bv[r];
+            y = gelu4(y);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a2[jl >> 1][(jl & 1) * 4 + r] = (half_t)y[r];
+        }
+        // stage C: acc2[jt2][r] = up2[(row, s1)][column jt2 * 16 + 4 g + r], column = s2 * 32 + c2
+        f32x4 acc2[8];
+#pragma unroll
+        for (int jt2 = 0; jt2 < 8; ++jt2) acc2[jt2] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int jt2 = 0; jt2 < 8; ++jt2) {
+                const half_t* src = w2l + (size_t)jt2 * 16 * UP_W2STRIDE + 32 * kk;
+                const half4_t lo = *reinterpret_cast<const half4_t*>(src), hi = *reinterpret_cast<const half4_t*>(src + 16);
+                const half8_t b = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                acc2[jt2] = mfma16(b, a2[kk], acc2[jt2]);
+            }
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            float4_t u[2];
+#pragma unroll
+            for (int jl = 0; jl < 2; ++jl) {
+                const float4_t bv = reinterpret_cast<const float4_t*>(c_b2)[(2 * s2 + jl) * 4 + g];
+                u[jl] = gelu4(float4_t{acc2[2 * s2 + jl][0] + bv[0], acc2[2 * s2 + jl][1] + bv[1], acc2[2 * s2 + jl][2] + bv[2],
+                                       acc2[2 * s2 + jl][3] + bv[3]});
+            }
+            float part[4];
+#pragma unroll
+            for (int mk = 0; mk < 4; ++mk) {
+                float d = 0.f;
+#pragma unroll
+                for (int jl = 0; jl < 2; ++jl) {
+                    const float4_t hv = reinterpret_cast<const float4_t*>(c_hy)[mk * 8 + jl * 4 + g];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) d = fmaf(u[jl][r], hv[r], d);
+                }
+                part[mk] = d;
+            }
+            // sum over the four lane groups, group g keeping mask g: exchange with g ^ 2, then with g ^ 1
+            const bool hi_pair = (g & 2) != 0, odd = (g & 1) != 0;
+            const float k0 = (hi_pair ? part[2] : part[0]) + __shfl_xor(hi_pair ? part[0] : part[2], 32, 64);
+            const float k1 = (hi_pair ? part[3] : part[1]) + __shfl_xor(hi_pair ? part[1] : part[3], 32, 64);
+            const float total = (odd ? k1 : k0) + __shfl_xor(odd ? k0 : k1, 16, 64);
+            const int Y = 4 * ty + 2 * (s1 >> 1) + (s2 >> 1), X = 4 * tx + 2 * (s1 & 1) + (s2 & 1);
+            out[Y * 256 + X] = total;
+        }
+    }
+}
+
 }  // namespace
 
 namespace k {
@@ -198,6 +384,17 @@ void image_update(const half_t* q, int ldq, const float* tk, const float* tv, co
     opt_in.ensure((const void*)image_update_kernel, IU_LDS, "image_update: the device refuses the kernel's LDS size");
     ImageUpdate a{q, ldq, tk, tv, W, bias, ln_w, ln_b, eps, keys, keys_h};
     hipLaunchKernelGGL(image_update_kernel, dim3(P * NTOK_IMG / IU_ROWS), dim3(256), IU_LDS, s, a);
+}
+
+
+void upscale_logits(const half_t* keys_h, const half_t* W1, const float* b1, const float* ln_w, const float* ln_b, float eps,
+                    const half_t* W2, const float* b2, const float* hyper, float* logits, int P, hipStream_t s) {
+    if (P <= 0) return;
+    if (((uintptr_t)keys_h | (uintptr_t)W1 | (uintptr_t)W2) & 15) throw_error("upscale_logits: operands must be 16-byte aligned");
+    static k::LdsOptIn opt_in;
+    opt_in.ensure((const void*)upscale_logits_kernel, UP_LDS, "upscale_logits: the device refuses the kernel's LDS size");
+    Upscale a{keys_h, W1, b1, ln_w, ln_b, eps, W2, b2, hyper, logits};
+    hipLaunchKernelGGL(upscale_logits_kernel, dim3(P * NTOK_IMG / UP_ROWS), dim3(256), UP_LDS, s, a);
 }
 
 }  // namespace k

@@ -74,35 +74,6 @@ template <int BKT> DLIMG_DEVICE half8_t read_frag(const char* lds, int row, int 
     return *reinterpret_cast<const half8_t*>(lds + row * (BKT * 2) + ((chunk ^ swz<BKT>(row)) << 4));
 }
 
-// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz-Stegun 7.1.28:
-//   erf(z) = 1 - 1 / (1 + a1 z + ... + a6 z^6)^16,  z >= 0,  |err| <= 3e-7
-// so with q = 1 / P(|x|)^16 (sqrt 2 folded into the coefficients):  GELU(x) = max(x, 0) - 0.5 |x| q  (both signs).
-// One reciprocal and no exponential per value, and everything else on two values at a time (v_pk_fma_f32 /
-// v_pk_mul_f32): fc1's epilogue is VALU-bound (12.6 M outputs on the CUs its tiles occupy; the 7.1.26 form with
-// exp2 + rcp on single values cost 6.7 k of the tile's 11 k epilogue cycles).  Against the fp64 erf form the fp32
-// evaluation is within 7.1e-7 absolute over |x| <= 12; P^16 overflowing to inf for |x| > ~25 gives q = 0, the limit.
-DLIMG_DEVICE float2_t gelu_pair(float2_t x) {
-    const float2_t ax = {fabsf(x[0]), fabsf(x[1])};
-    float2_t p = ax * 5.38297500e-6f + 4.88906359e-5f;       // a6 / 8, a5 / (4 sqrt 2)
-    p = p * ax + 3.80035750e-5f;                               // a4 / 4
-    p = p * ax + 3.27762634e-3f;                               // a3 / (2 sqrt 2)
-    p = p * ax + 2.11410062e-2f;                               // a2 / 2
-    p = p * ax + 4.98673463e-2f;                               // a1 / sqrt 2
-    p = p * ax + 1.0f;
-    p = p * p;
-    p = p * p;
-    p = p * p;
-    p = p * p;
-    const float2_t q = {__builtin_amdgcn_rcpf(p[0]), __builtin_amdgcn_rcpf(p[1])};       // 1 ulp is plenty
-    const float2_t pos = {fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f)};
-    return pos - (ax * 0.5f) * q;
-}
-DLIMG_DEVICE float4_t gelu4(float4_t v) {
-    const float2_t lo = gelu_pair(float2_t{v[0], v[1]}), hi = gelu_pair(float2_t{v[2], v[3]});
-    return float4_t{lo[0], lo[1], hi[0], hi[1]};
-}
-DLIMG_DEVICE float gelu_fast(float x) { return gelu_pair(float2_t{x, x})[0]; }
-
 // Epilogue flavours: compile-time, so the plain GEMM does not carry the registers of the others
 // (the shared epilogue code is in gemm_epilogue.inc).
 enum { EPI_PLAIN = 0, EPI_NORM = 1, EPI_STATS = 2 };

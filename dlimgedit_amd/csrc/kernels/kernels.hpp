@@ -177,6 +177,11 @@ void token_merge_linear(const float* scratch, const TokenLinear& out, const floa
 // tk / tv: fp32 [P][7][128], W: f16 [256][128].
 void image_update(const half_t* q, int ldq, const float* tk, const float* tv, const half_t* W, const float* bias,
                   const float* ln_w, const float* ln_b, float eps, float* keys, half_t* keys_h, int P, hipStream_t);
+// Up-scaling path + mask product in one launch (kernels/decoder_image.hip): logits [P,4,256,256] from the f16 keys, the two
+// transposed convolutions as GEMM weights (W1 [256][256], rows = sub-pixel * 64 + channel; W2 [128][64], rows = sub-pixel * 32
+// + channel), the LayerNorm2d between them and the hyper vectors [P,4,32].
+void upscale_logits(const half_t* keys_h, const half_t* W1, const float* b1, const float* ln_w, const float* ln_b, float eps,
+                    const half_t* W2, const float* b2, const float* hyper, float* logits, int P, hipStream_t);
 // keys = LayerNorm(keys) in place + f16(keys)
 void decoder_keys_norm(float* keys, const float* w, const float* b, float eps, half_t* keys_h, int P, hipStream_t);
 // hyper-network MLPs (4 x 256->256->256->32) and IoU head (256->256->256->4) on the output tokens: the launch finishes the

@@ -806,22 +806,6 @@ void SamModel::decode_chunk(float const* const* emb, float const* coords, float 
         img_gemm(W.final_kv_, W.final_pos_kv_);
         k::token_to_image_partials(sq_.get(), nullptr, kqv_h_.get(), 256, kqv_h_.get() + 128, 256, t2i_part_.get(), P, s);
 
-        // upscaling: ConvT(256->64) -> LN2d -> GELU -> ConvT(64->32) -> GELU, sub-pixels kept in quad order
-        k::GemmArgs g;
-        g.A = keys_h_.get(); g.lda = 256; g.W = W.up1_.w.get(); g.ldw = 256; g.bias = W.up1_.b.get();
-        g.out_f32 = up1_f32_.get(); g.ldc32 = 256; g.M = M; g.N = 256; g.K = 256;
-        g.shared_gpu = shared_gpu_;
-        g.unit_rows = kTokens;
-        k::gemm(g, s);
-        k::layernorm(up1_f32_.get(), W.up_ln_.w.get(), W.up_ln_.b.get(), kLnEps, M * 4, 64, k::ACT_GELU, nullptr,
-                     up1_h_.get(), s);
-        g = k::GemmArgs{};
-        g.A = up1_h_.get(); g.lda = 64; g.W = W.up2_.w.get(); g.ldw = 64; g.bias = W.up2_.b.get(); g.act = k::ACT_GELU;
-        g.out_f32 = up_.get(); g.ldc32 = 128; g.M = M * 4; g.N = 128; g.K = 64;
-        g.shared_gpu = shared_gpu_;
-        g.unit_rows = kTokens * 4;
-        k::gemm(g, s);
-
         k::HeadWeights hw;
         for (int m = 0; m < 5; ++m)
             for (int j = 0; j < 3; ++j) {
@@ -830,7 +814,9 @@ void SamModel::decode_chunk(float const* const* emb, float const* coords, float 
             }
         k::output_heads(t2i_part_.get(), lin({}, 128, W.final_o_, cur, nullptr, 0), W.final_o_t_.get(), normed(nullptr, W.ln_final_),
                         hw, hyper_.get(), iou_out, P, s);
-        k::mask_logits(up_.get(), hyper_.get(), logits_out, P, s);
+        // upscaling ConvT(256->64) -> LN2d -> GELU -> ConvT(64->32) -> GELU and the product with the hyper vectors
+        k::upscale_logits(keys_h_.get(), W.up1_.w.get(), W.up1_.b.get(), W.up_ln_.w.get(), W.up_ln_.b.get(), kLnEps,
+                          W.up2_.w.get(), W.up2_.b.get(), hyper_.get(), logits_out, P, s);
     };
     timed(ST_DECODER, 3.62e9 * P, body);
     HIP_CHECK(hipGetLastError());
