@@ -367,6 +367,7 @@ class ext:
                 "dlimg_amd_model_geometry": ([vp, C.POINTER(ci)], ci),
                 "dlimg_amd_get_embedding": ([vp, vp], ci),
                 "dlimg_amd_get_logits": ([vp, C.POINTER(ci), C.POINTER(ci), vp, vp], ci),
+                "dlimg_amd_decoder_state": ([vp, C.POINTER(ci), vp, ci, C.c_char_p, ci], ci),
                 "dlimg_amd_device_alloc": ([vp, C.c_size_t, C.POINTER(vp)], ci),
                 "dlimg_amd_device_free": ([vp, vp], ci),
                 "dlimg_amd_copy_to_device": ([vp, vp, vp, C.c_size_t], ci),
@@ -404,7 +405,7 @@ class ext:
         return lib
 
     EXPORTS = ("dlimg_amd_device_count", "dlimg_amd_model_geometry", "dlimg_amd_get_embedding", "dlimg_amd_get_logits",
-               "dlimg_amd_device_alloc", "dlimg_amd_device_free", "dlimg_amd_copy_to_device", "dlimg_amd_copy_to_host",
+               "dlimg_amd_decoder_state", "dlimg_amd_device_alloc", "dlimg_amd_device_free", "dlimg_amd_copy_to_device", "dlimg_amd_copy_to_host",
                "dlimg_amd_encode_and_mask", "dlimg_amd_encode_only", "dlimg_amd_synchronize", "dlimg_amd_lane_count",
                "dlimg_amd_replica_count", "dlimg_amd_segmentation_device", "dlimg_amd_get_segmentation_masks_device",
                "dlimg_amd_set_profiling",
@@ -442,6 +443,20 @@ class ext:
             if region is not None else None
         _check(cls._l().dlimg_amd_get_logits(seg._handle, p, r, logits.ctypes.data, iou.ctypes.data))
         return logits, iou
+
+    @classmethod
+    def decoder_state(cls, seg: Segmentation, point: Point):
+        """Diagnostic: {name: array} of the decoder's token-side workspaces after decoding `point`."""
+        buf = C.create_string_buffer(1024)
+        _check(cls._l().dlimg_amd_decoder_state(seg._handle, (C.c_int * 2)(point.x, point.y), None, 0, buf, 1024))
+        parts = [(n, int(c)) for n, c in (item.split(":") for item in buf.value.decode().strip(",").split(","))]
+        out = np.empty(sum(c for _, c in parts), dtype=np.float32)
+        _check(cls._l().dlimg_amd_decoder_state(seg._handle, (C.c_int * 2)(point.x, point.y), out.ctypes.data, out.size, None, 0))
+        res, off = {}, 0
+        for n, c in parts:
+            res[n] = out[off:off + c]
+            off += c
+        return res
 
     # -- benchmark path
     @classmethod

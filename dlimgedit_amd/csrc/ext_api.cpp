@@ -138,6 +138,35 @@ DLIMG_API int dlimg_amd_get_logits(dlimg_Segmentation seg, int const* point, int
     });
 }
 
+DLIMG_API int dlimg_amd_decoder_state(dlimg_Segmentation seg, int const* point, float* out, int capacity, char* out_layout,
+                                      int layout_capacity) {
+    return guarded([&] {
+        SegmentationImpl& s = impl(seg);
+        DLIMG_ASSERT(s.embedding() != nullptr && point != nullptr);
+        std::string layout;
+        size_t total = 0;
+        for (auto const& part : SamModel::decoder_state_layout()) {
+            layout += std::string(part.first) + ":" + std::to_string(part.second) + ",";
+            total += part.second;
+        }
+        if (out_layout && layout_capacity > 0) {
+            std::snprintf(out_layout, (size_t)layout_capacity, "%s", layout.c_str());
+        }
+        if (!out) return;
+        if ((size_t)capacity < total) throw Exception("decoder_state: the output buffer is too small");
+        Point p{point[0], point[1]};
+        float coords[4], labels[2];
+        pack_prompt(s.geometry(), &p, nullptr, coords, labels);
+        SamModel& m = s.environment().next_lane(s.replica());
+        std::lock_guard<std::mutex> lock(m.mutex());
+        HIP_CHECK(hipSetDevice(m.device()));
+        float const* emb = s.embedding();
+        m.decode(&emb, coords, labels, 1);
+        m.synchronize();
+        m.decoder_state(out);
+    });
+}
+
 DLIMG_API int dlimg_amd_device_alloc(dlimg_Environment env, size_t bytes, void** out_ptr) {
     return guarded([&] {
         HIP_CHECK(hipSetDevice(impl(env).first_device()));

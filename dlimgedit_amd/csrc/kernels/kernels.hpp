@@ -121,9 +121,6 @@ void attention_global(const half_t* qkv, const half_t* rel_h, const half_t* rel_
 // ---- mask decoder (token side is tiny: fp32 VALU kernels) ------------------------------------
 // floats of workspace for the per-key-group partial results of token_to_image_partials
 size_t token_to_image_scratch_floats(int P);
-// image attends to tokens: q [P,4096,ldq] f16, k,v [P,7,128] f32 -> out [P,4096,128] f16
-void image_to_token_attention(const half_t* q, int ldq, const float* k, const float* v, half_t* out, int P,
-                              hipStream_t);
 // A [rows][256] fp32 token matrix as a consumer sees it: optionally LayerNorm'ed (over the 256 columns) and with another
 // matrix added behind the LayerNorm (the query positional encoding), both applied while the rows are read.
 struct TokenRows {
@@ -182,16 +179,11 @@ void image_update(const half_t* q, int ldq, const float* tk, const float* tv, co
 // + channel), the LayerNorm2d between them and the hyper vectors [P,4,32].
 void upscale_logits(const half_t* keys_h, const half_t* W1, const float* b1, const float* ln_w, const float* ln_b, float eps,
                     const half_t* W2, const float* b2, const float* hyper, float* logits, int P, hipStream_t);
-// keys = LayerNorm(keys) in place + f16(keys)
-void decoder_keys_norm(float* keys, const float* w, const float* b, float eps, half_t* keys_h, int P, hipStream_t);
 // hyper-network MLPs (4 x 256->256->256->32) and IoU head (256->256->256->4) on the output tokens: the launch finishes the
 // final token-to-image attention (scratch, out, out_wt as above) for the five tokens it needs and applies `norm` to them
 struct HeadWeights { const float* w[5][3]; const float* b[5][3]; };
 void output_heads(const float* scratch, const TokenLinear& out, const float* out_wt, const TokenRows& norm /*ln_w, ln_b, eps*/,
                   const HeadWeights& hw, float* hyper /*[P,4,32]*/, float* iou /*[P,4]*/, int P, hipStream_t);
-// low-res logits [P,4,256,256] from the upscaled embedding in quad order and the hyper vectors.
-// up: [P*65536, 32] f32, row = ((y*64+x)*4 + dy1*2+dx1)*4 + dy2*2+dx2  (pixel Y = 4y+2dy1+dy2, X likewise)
-void mask_logits(const float* up, const float* hyper, float* logits, int P, hipStream_t);
 
 // ---- mask post-processing (K16) --------------------------------------------------------------
 // For each of `count` jobs: logits plane job.src (256x256 f32, device) -> two-stage bilinear

@@ -288,7 +288,6 @@ SamModel::SamModel(std::shared_ptr<SamWeights const> weights, int lane_index, in
         }
     }
     for (auto& st : stage_) HIP_CHECK(hipEventCreateWithFlags(&st.copied, hipEventDisableTiming));
-    for (auto& e : prompt_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 }
 
 SamModel::~SamModel() {
@@ -303,8 +302,6 @@ SamModel::~SamModel() {
         if (st.copied) (void)hipEventDestroy(st.copied);
     for (auto& m : mask_slots_)
         if (m->done) (void)hipEventDestroy(m->done);
-    for (auto e : prompt_done_)
-        if (e) (void)hipEventDestroy(e);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -679,29 +676,21 @@ void SamModel::reserve_decoder(int count) {
     keys_.reserve(M * 256);
     keys_h_.reserve(M * 256);
     kqv_h_.reserve(M * 384);
-    att_img_h_.reserve(M * 128);
-    up1_f32_.reserve(M * 256);
-    up1_h_.reserve(M * 256);
-    up_.reserve(M * 16 * 32);
     logits_.reserve(P * 4 * kLowRes * kLowRes);
     iou_.reserve(P * 4);
     hyper_.reserve(P * 4 * 32);
-    coords_.reserve(P * 8);              // coordinates [P][4], labels [P][2], embedding pointers [P] (8 bytes each)
     const size_t T = P * kDecTokens;
     tokens_.reserve(T * 256);
     queries_.reserve(T * 256);
-    tq_.reserve(T * 256);
     tk_.reserve(T * 256);
     tv_.reserve(T * 256);
     sq_.reserve(T * 256);
     sk_.reserve(T * 256);
     sv_.reserve(T * 256);
-    tatt_.reserve(T * 256);
     tsa_.reserve(T * 256);
     tt2i_.reserve(T * 256);
     t2i_part_.reserve(k::token_to_image_scratch_floats((int)P));
     tmlp_.reserve(T * 2048);
-    prompt_pinned_.reserve(kPromptRing * P * 8 * sizeof(float));
     dec_count_ = count;
 }
 
@@ -820,6 +809,23 @@ void SamModel::decode_chunk(float const* const* emb, float const* coords, float 
     };
     timed(ST_DECODER, 3.62e9 * P, body);
     HIP_CHECK(hipGetLastError());
+}
+
+std::vector<std::pair<const char*, size_t>> SamModel::decoder_state_layout() {
+    const size_t T = kDecTokens;
+    return {{"tokens", T * 256}, {"final_q", T * 128}, {"self_k", T * 256}, {"self_v", T * 256}, {"self_out", T * 256},
+            {"t2i_out", T * 256}, {"mlp_hidden", T * 2048}, {"queries", T * 256}, {"i2t_k", T * 128}, {"i2t_v", T * 128},
+            {"final_partials", k::token_to_image_scratch_floats(1)}, {"hyper", 4 * 32}, {"iou", 4}, {"keys_head", 4096}};
+}
+
+void SamModel::decoder_state(float* out) const {
+    float const* src[] = {tokens_.get(), sq_.get(), sk_.get(), sv_.get(), tsa_.get(), tt2i_.get(), tmlp_.get(), queries_.get(),
+                          tk_.get(), tv_.get(), t2i_part_.get(), hyper_.get(), iou_.get(), keys_.get()};
+    size_t off = 0, i = 0;
+    for (auto const& part : decoder_state_layout()) {
+        HIP_CHECK(hipMemcpy(out + off, src[i++], part.second * sizeof(float), hipMemcpyDeviceToHost));
+        off += part.second;
+    }
 }
 
 void SamModel::masks_on_device(k::PostJob const* jobs, int count) {

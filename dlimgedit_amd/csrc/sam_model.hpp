@@ -146,6 +146,10 @@ class SamModel {
     // labels [count][2] host arrays. Results stay on device: logits() [count][4][256][256], iou() [count][4].
     void decode(float const* const* emb, float const* coords, float const* labels, int count);
     float const* logits() const { return logits_.get(); }
+    // Diagnostic: the token-side workspaces as the last decode of ONE prompt left them (after synchronize()), one after
+    // the other; names/sizes in decoder_state_layout().  What a parity or race hunt compares stage by stage.
+    static std::vector<std::pair<const char*, size_t>> decoder_state_layout();
+    void decoder_state(float* out) const;
     float const* iou() const { return iou_.get(); }
 
     // Post-process to host masks in two steps so that the wait happens outside mutex():
@@ -229,15 +233,11 @@ class SamModel {
 
     // ---- decoder workspace (sized for dec_count_ prompts)
     int dec_count_ = 0;
-    DeviceBuffer<float> keys_, up1_f32_, up_, logits_, iou_, hyper_;
-    DeviceBuffer<half_t> keys_h_, kqv_h_, att_img_h_, up1_h_;
-    DeviceBuffer<float> coords_, tokens_, queries_, tq_, tk_, tv_, sq_, sk_, sv_, tatt_, tsa_, tt2i_, tmlp_, t2i_part_;
+    DeviceBuffer<float> keys_, logits_, iou_, hyper_;
+    DeviceBuffer<half_t> keys_h_, kqv_h_;
+    DeviceBuffer<float> tokens_, queries_, tk_, tv_, sq_, sk_, sv_, tsa_, tt2i_, tmlp_, t2i_part_;
     std::vector<std::unique_ptr<MaskSlot>> mask_slots_;     // all ever made (owned), guarded by done_mutex_
     std::vector<MaskSlot*> mask_free_;                      // those not handed out, guarded by done_mutex_
-    PinnedBuffer prompt_pinned_;
-    static constexpr int kPromptRing = 8;           // pinned prompt staging slots, re-used round robin
-    hipEvent_t prompt_done_[kPromptRing] = {};
-    unsigned prompt_seq_ = 0;
 
     // ---- profiling
     bool profiling_ = false;

@@ -35,6 +35,12 @@ DLIMG_API int dlimg_amd_get_embedding(dlimg_Segmentation seg, float* out);
 DLIMG_API int dlimg_amd_get_logits(dlimg_Segmentation seg, int const* point, int const* region, float* out_logits,
                                    float* out_iou);
 
+/* Diagnostic: decodes one point prompt and copies out the decoder's token-side workspaces as that decode left them
+ * (tokens, projections, attention outputs, MLP hidden layer, final partials, hyper vectors, IoU, the first 4096 keys
+ * values), one after the other; out_layout receives "name:floats,name:floats,...".  out == NULL: layout only. */
+DLIMG_API int dlimg_amd_decoder_state(dlimg_Segmentation seg, int const* point, float* out, int capacity, char* out_layout,
+                                      int layout_capacity);
+
 /* ---- benchmark path: everything device-resident, stream-ordered, no host synchronisation ----- */
 /* Device memory helpers (hipMalloc/hipFree/hipMemcpy on the environment's device). */
 DLIMG_API int dlimg_amd_device_alloc(dlimg_Environment env, size_t bytes, void** out_ptr);
