@@ -42,8 +42,8 @@ import time
 from pathlib import Path
 
 # Hardware queues of the HIP runtime: four by default, shared by every stream of the process; the library's execution
-# lanes each want their own.  Read once when the runtime initialises, so it is set before anything can touch the GPU.
-# DLIMGEDIT_PLAIN_STREAMS tells the library that this host did so (it cannot see the runtime's setting itself).
+# lanes each want their own.  Read once when the runtime initialises, so it is set before anything can touch the GPU
+# (torch may initialise HIP before the library is loaded; the library itself asks for eight queues at load otherwise).
 if "GPU_MAX_HW_QUEUES" not in os.environ:
     os.environ["GPU_MAX_HW_QUEUES"] = "8"
     os.environ.setdefault("DLIMGEDIT_PLAIN_STREAMS", "1")

@@ -5,6 +5,19 @@
 
 namespace dlimg {
 
+namespace {
+// The HIP runtime gives a process four hardware queues by default and multiplexes every stream onto them; the execution
+// lanes (four per GPU) want a queue each, beside the host's own streams.  The runtime reads GPU_MAX_HW_QUEUES when IT
+// initialises (its first API call), so the one place a library can still ask is its own load: if the host has not chosen,
+// ask for eight.  A host that initialised HIP before loading this library keeps what it had -- the lanes then share the
+// default queues through streams of three priority levels (sam_model.cpp), as before.  DLIMGEDIT_KEEP_HW_QUEUES=1: hands off.
+const bool g_asked_for_queues = [] {
+    const char* keep = std::getenv("DLIMGEDIT_KEEP_HW_QUEUES");
+    if (keep && std::atoi(keep) != 0) return false;
+    return setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0) == 0;
+}();
+}  // namespace
+
 void throw_error(const char* msg) { throw Exception(msg); }
 
 void assertion_failed(const char* file, int line, const char* expr) {

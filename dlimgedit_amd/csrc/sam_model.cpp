@@ -270,14 +270,20 @@ SamModel::SamModel(std::shared_ptr<SamWeights const> weights, int lane_index, in
     : device_(weights->device), shared_gpu_(lane_count > 1), weights_(std::move(weights)) {
     HIP_CHECK(hipSetDevice(device_));
     {
-        // The runtime multiplexes streams of one priority onto a few hardware queues (four by default), shared with
-        // the host's other streams: a fourth lane of the same priority ends up behind another lane's kernels and
-        // costs 15 %.  Each priority level has its own queues, so the lanes are spread over the three levels; no
-        // lane is favoured for long because requests are dealt round-robin.
-        // A host that starts the process with GPU_MAX_HW_QUEUES >= 8 (read by the HIP runtime when IT initialises,
-        // which may be long before this library is loaded -- the library cannot tell, so it does not guess from the
-        // variable) says so with DLIMGEDIT_PLAIN_STREAMS=1: plain streams then do slightly better (+1 %).
-        static const bool plain = [] { const char* e = std::getenv("DLIMGEDIT_PLAIN_STREAMS"); return e && std::atoi(e) != 0; }();
+        // The runtime multiplexes streams of one priority onto its hardware queues, shared with the host's other streams.
+        // With the default four queues a fourth lane of the same priority ends up behind another lane's kernels and costs
+        // 15 %; each priority level has its own queues, so the lanes are then spread over the three levels (no lane is
+        // favoured for long because requests are dealt round-robin).  With eight queues plain streams are better: the
+        // priority levels make four host threads wait on each other's lanes (ABI, config 2 from four threads: 479 against
+        // 569-596 images/s; one prompt per call from four threads: 4900 against 5500 masks/s).  The library asks for eight
+        // queues when it is loaded (environment.cpp), so plain streams are the default whenever GPU_MAX_HW_QUEUES says
+        // >= 8; a host that initialised HIP with fewer queues BEFORE loading the library says so with
+        // DLIMGEDIT_PLAIN_STREAMS=0 (the library cannot see what the runtime really read).
+        static const bool plain = [] {
+            if (const char* e = std::getenv("DLIMGEDIT_PLAIN_STREAMS")) return std::atoi(e) != 0;
+            const char* q = std::getenv("GPU_MAX_HW_QUEUES");
+            return q && std::atoi(q) >= 8;
+        }();
         if (plain) {
             HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
         } else {
