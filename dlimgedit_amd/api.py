@@ -24,6 +24,8 @@ LIB_PATH = Path(__file__).resolve().parent / "lib" / "libdlimgedit.so"
 # tools/ only: the -DDLIMG_TUNING build with ablated kernel variants and in-kernel stamps (python -m dlimgedit_amd.build --tuning)
 if os.environ.get("DLIMGEDIT_TUNING_LIB") == "1":
     LIB_PATH = LIB_PATH.with_name("libdlimgedit_tuning.so")
+elif os.environ.get("DLIMGEDIT_TUNING_LIB"):          # a copy of a tuning build kept under another name (A/B of several variants)
+    LIB_PATH = LIB_PATH.with_name(os.environ["DLIMGEDIT_TUNING_LIB"])
 
 
 class Error(RuntimeError):

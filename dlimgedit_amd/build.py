@@ -50,9 +50,6 @@ SOURCES = [
 # Kernels whose results must be bit-identical to the CPU oracle are compiled without mul+add contraction
 # (HIP's default is -ffp-contract=fast, which also fuses the __fmul_rn/__fadd_rn header wrappers).
 EXTRA_FLAGS = {
-    # the softmax arithmetic of the attention kernel stays on single values where it is written that way (v_pk_*_f32 is no
-    # faster per value and costs more beside the partner wave's MFMAs, MI355X_MICROARCH.md)
-    "kernels/attention_global.hip": ["-fno-slp-vectorize"],
     "kernels/postprocess.hip": ["-ffp-contract=off"],
     "kernels/resize.hip": ["-ffp-contract=off"],
     "kernels/objects.hip": ["-ffp-contract=off"],
@@ -68,8 +65,12 @@ def hipcc() -> str:
 
 
 def _flags() -> list:
+    # -fno-slp-vectorize (every source): packed fp32 arithmetic (v_pk_fma_f32 ...) only where the source asks for it with
+    # vector types.  Round 3: the SLP vectoriser paired the rows of the decoder's token linears into chains of
+    # v_pk_fma_f32 with op_sel, and that code -- no other -- gave one wrong element in about 10^4 decodes while several
+    # lanes kept the GPU busy; the same source is clean without the pass, and nothing got slower.
     return [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DDLIMGEDIT_EXPORTS",
-            "-Wall", "-Wno-unused-function", "-Wno-unused-result", f"-I{ROOT / 'include'}", f"-I{CSRC}"]
+            "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", "-Wno-unused-result", f"-I{ROOT / 'include'}", f"-I{CSRC}"]
 
 
 def _deps_mtime() -> float:
@@ -84,7 +85,7 @@ def _compile(src: str, force: bool, hdr_mtime: float, tuning: bool = False) -> P
     o = (OBJ_TUNING if tuning else OBJ) / (src.replace("/", "_") + ".o")
     if not force and o.exists() and o.stat().st_mtime > max(s.stat().st_mtime, hdr_mtime):
         return o
-    cmd = [hipcc(), *_flags(), *(["-DDLIMG_TUNING"] if tuning else []), *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c",
+    cmd = [hipcc(), *_flags(), *(["-DDLIMG_TUNING", *os.environ.get("DLIMG_TUNING_DEFS", "").split()] if tuning else []), *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c",
            str(s), "-o", str(o)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

@@ -161,15 +161,19 @@ DLIMG_DEVICE TokenColumn token_column_prefetch(const k::TokenLinear& op, int fir
     return c;
 }
 // NR = rows of the slice, 7 or 14 (whole prompts).
-// The accumulate loop keeps the round-2 shape on purpose -- a run-time row bound, one guarded step per row, chunks of 8.
-// With the row count as a compile-time constant and the loop body straight-line (the seven rows' loads in front of their
-// FMAs), ONE output element in about 10^4 decodes came out wrong (error 0.02-0.5, always in row 2, 4 or 6) as soon as
-// four host threads kept the execution lanes busy, and never from one thread: found by tools/decoder_stress.py (every
-// workspace of the token side compared bit for bit with the serial answer), bisected by swapping this loop alone (the
-// epilogue below, system-scope loads of the rows, a second barrier, lane-0 stores made no difference), 320 000 concurrent
-// decodes clean with this form.  The generated code of the straight-line form shows no missing wait; the cause is not
-// understood, so the form that is measured clean is the one that ships and tests/test_gpu_concurrency.py keeps the
-// stress in the suite.
+// The accumulate loop keeps the round-2 shape -- a run-time row bound, one guarded step per row, chunks of 8 -- and the whole
+// library is built with -fno-slp-vectorize (dlimgedit_amd/build.py).  With the row count a compile-time constant and the
+// seven rows' loads in straight-line code, the SLP vectoriser paired the rows (2,1), (4,3), (6,5) into chains of
+// v_pk_fma_f32 with op_sel between v_mov shuffles, and THAT code got ONE output element in about 10^4 decodes wrong (error
+// 0.02-0.5, always the low half of a pair: token row 2, 4 or 6) as soon as four host threads kept the execution lanes busy,
+// and never from one thread.  Found by tools/decoder_stress.py (every workspace of the token side compared bit for bit with
+// the serial answer); bisected in a second build by swapping single pieces: the epilogue, system-scope loads of the rows,
+// a second barrier, lane-0 stores and lower occupancy made no difference, the loop shape did (0 in 320 000 decodes), and so
+// did the compiler pass alone: the straight-line source built with -fno-slp-vectorize is clean too (0 in 240 000, the
+// vectorised build of the same source 7 in 60 000 on the same box).  Every wait the ISA manual asks for is in the failing
+// code; whether it is a gap in the compiler's hazard table for packed fp32 on gfx950 or an erratum is not known.  The
+// tuning build keeps the failing form (-DDLIMG_STRAIGHT_ROWS, build it WITHOUT -fno-slp-vectorize to see it fail);
+// tests/test_gpu_concurrency.py keeps the stress in the suite.
 template <int NR>
 DLIMG_DEVICE void token_linear_columns(const k::TokenLinear& op, int first_col, const float* lds_in, const float2_t* stat_in,
                                        const float2_t* stat_res, const TokenColumn& col, int row0) {
@@ -180,6 +184,33 @@ DLIMG_DEVICE void token_linear_columns(const k::TokenLinear& op, int first_col, 
     const int K4 = op.K >> 2;
     const float4_t* wr = reinterpret_cast<const float4_t*>(op.W + (size_t)n * op.K);
     float mine = 0.f;                       // the finished sum of row row0 + lane
+#if defined(DLIMG_TUNING) && defined(DLIMG_STRAIGHT_ROWS)
+    // the failing form, kept in the tuning build for the hunt (tools/decoder_stress.py with DLIMGEDIT_TUNING_LIB)
+#pragma unroll
+    for (int c0 = 0; c0 < NR; c0 += TOK) {
+        float acc[TOK];
+#pragma unroll
+        for (int r = 0; r < TOK; ++r) acc[r] = 0.f;
+        for (int k4 = lane; k4 < K4; k4 += 64) {
+            const float4_t w = k4 == lane ? col.w : wr[k4];
+            float4_t x[TOK];
+#pragma unroll
+            for (int r = 0; r < TOK; ++r) {
+                if (lds_in) x[r] = reinterpret_cast<const float4_t*>(lds_in + (size_t)(c0 + r) * op.K)[k4];
+                else if (op.K == DIM) x[r] = token_row_load4(op.in, stat_in, row0 + c0 + r, k4);
+                else x[r] = reinterpret_cast<const float4_t*>(op.in.x + (size_t)(row0 + c0 + r) * op.K)[k4];
+            }
+#pragma unroll
+            for (int r = 0; r < TOK; ++r)
+                acc[r] = fmaf(x[r][0], w[0], fmaf(x[r][1], w[1], fmaf(x[r][2], w[2], fmaf(x[r][3], w[3], acc[r]))));
+        }
+#pragma unroll
+        for (int r = 0; r < TOK; ++r) {
+            const float v = wave_sum(acc[r]);
+            if (lane == c0 + r) mine = v;
+        }
+    }
+#else
     const int rows = row0 + NR;
     for (int r0 = row0; r0 < rows; r0 += RCHUNK) {
         float acc[RCHUNK];
@@ -204,6 +235,7 @@ DLIMG_DEVICE void token_linear_columns(const k::TokenLinear& op, int first_col, 
             if (lane == r0 - row0 + r) mine = v;
         }
     }
+#endif
     if (lane < NR) {
         const int r = row0 + lane;
         float v = mine + col.bias;
@@ -221,6 +253,9 @@ DLIMG_DEVICE void token_linear_columns(const k::TokenLinear& op, int first_col, 
     if ((count) == TL_ROW_SLICE) { constexpr int NR = TL_ROW_SLICE; __VA_ARGS__ } \
     else { constexpr int NR = TOK; __VA_ARGS__ }
 
+#if defined(DLIMG_TUNING) && defined(DLIMG_LOW_OCCUPANCY)
+__attribute__((amdgpu_waves_per_eu(1, 4)))
+#endif
 __global__ __launch_bounds__(256) void token_linears_kernel(LinJob job) {
     __shared__ float2_t stat_in[TL_MAX_ROWS], stat_res[TL_MAX_ROWS];
     int o = 0, first = blockIdx.x * 4;

@@ -68,6 +68,18 @@ with tempfile.TemporaryDirectory() as d:
                     bad.append(info)
 
     want_state = [api.ext.decoder_state(seg, p) for p in prompts] if mode == "state" else None
+    images = [api.ImageView(synthetic_image(60 + i), api.Channels.rgba) for i in range(4)] if mode == "encode" else []
+    want_emb = [api.ext.get_embedding(api.Segmentation.process(v, env)) for v in images]
+
+    def encode_worker(t):
+        for rep in range(reps):
+            j = (rep + t) % len(images)
+            emb = api.ext.get_embedding(api.Segmentation.process(images[j], env))
+            d = emb != want_emb[j]
+            if d.any():
+                rows = np.nonzero(d.any(axis=1))[0]
+                with lock: bad.append(dict(thread=t, rep=rep, image=j, elements=int(d.sum()), rows=(int(rows.min()), int(rows.max())),
+                                           max_abs=float(np.abs(emb - want_emb[j]).max())))
 
     def state_worker(t):
         for rep in range(reps):
@@ -85,7 +97,7 @@ with tempfile.TemporaryDirectory() as d:
             if differing:
                 with lock: bad.append(dict(thread=t, rep=rep, prompt=j, differing=differing))
 
-    ts = [threading.Thread(target={'masks': mask_worker, 'state': state_worker}.get(mode, worker), args=(t,)) for t in range(threads)]
+    ts = [threading.Thread(target={'masks': mask_worker, 'state': state_worker, 'encode': encode_worker}.get(mode, worker), args=(t,)) for t in range(threads)]
     [t.start() for t in ts]
     [t.join() for t in ts]
     print(f"{threads} threads x {reps} decodes: {len(bad)} mismatches")

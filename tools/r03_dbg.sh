@@ -1,4 +1,3 @@
 #!/bin/bash
-# long concurrent decoder stress + decoder timings (tools/decoder_stress.py, tools/r03_dec.sh)
-timeout -k 10 500 python3 tools/decoder_stress.py 4 80000 state 2>&1 | tail -4 | cut -c1-300
-timeout -k 10 200 python3 tools/decoder_stress.py 4 120 masks 2>&1 | tail -3 | cut -c1-300
+# the wrong-element hunt: several copies of the tuning build (lib/libdlimgedit_var*.so), same box, same stress
+for v in "$@"; do echo "== $v"; DLIMGEDIT_TUNING_LIB=libdlimgedit_$v.so timeout -k 10 400 python3 tools/decoder_stress.py 4 60000 state 2>&1 | tail -7 | cut -c1-260; done
