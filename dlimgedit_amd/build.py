@@ -5,7 +5,8 @@ runs in the CPU-only build container.  Objects are cached by source mtime under 
 
 `--tuning` builds a SECOND library, lib/libdlimgedit_tuning.so, with -DDLIMG_TUNING: it additionally holds the ablated
 kernel variants and in-kernel cycle stamps the scripts under tools/ use (DLIMGEDIT_*_ABLATE, GemmArgs::stamps).  The
-product library never contains them; tools select the tuning library with DLIMGEDIT_TUNING_LIB=1.
+product library never contains them; tools select the tuning library with DLIMGEDIT_TUNING_LIB=1 (or the file name of a
+copy kept under lib/).  DLIMG_TUNING_DEFS in the environment adds compiler flags to the tuning build only (A/B of variants).
 """
 from __future__ import annotations
 
