@@ -7,6 +7,7 @@
 #include "kernels.hpp"
 
 #include <mutex>
+#include <type_traits>
 
 namespace dlimg {
 namespace {
@@ -566,12 +567,13 @@ DLIMG_DEVICE void lds_row_stats(const float* y, int rows, float eps, float2_t* s
 }
 
 // Token-to-image attention finished (merge + output projection + residual -> out.Y, written by the first column block) and
-// the NEXT linear (`next`, K = 256, whose input is the LayerNorm of those rows) applied to it: a workgroup = 16 columns
-// of `next` for the rows of one prompt.  [Kept small on purpose: code that runs once is fetched cold, and a 43 KB body --
+// the NEXT linear (`next`, K = 256, whose input is the LayerNorm of those rows) applied to it: a workgroup = COLS columns
+// of `next` for the rows of one prompt.  COLS = 16, 32 or 64: the smallest workgroups that still fit the chip in one round (16 for one or two prompts, 64
+// from five) (every workgroup pays the fold, the 128 KB of Wo and the projection before its columns: at five prompts 640
+// workgroups of 16 columns took 53 us, two and a half rounds on 256 CUs).  The arithmetic of a column does not depend on COLS.  [Kept small on purpose: code that runs once is fetched cold, and a 43 KB body --
 // 32 columns, two prompts, everything unrolled -- took 24 us where this one takes half.]
-constexpr int TML_COLS = 16;
 constexpr size_t TML_LDS = (size_t)(INNER * DIM + TL_ROW_SLICE * INNER + TL_ROW_SLICE * DIM) * 4 + 2 * TL_ROW_SLICE * 8;
-template <int NR>
+template <int NR, int COLS>
 DLIMG_DEVICE void token_merge_linear_body(const float* __restrict__ part, const k::TokenLinear& out,
                                           const float* __restrict__ out_wt, const k::TokenLinear& next, int p0, float* lds) {
     float* wt = lds;                                     // [128][256]: the whole transposed output projection (128 KB)
@@ -580,14 +582,12 @@ DLIMG_DEVICE void token_merge_linear_body(const float* __restrict__ part, const 
     float2_t* stat_res = reinterpret_cast<float2_t*>(y + TL_ROW_SLICE * DIM);
     float2_t* stat_in = stat_res + TL_ROW_SLICE;
     const int row0 = p0 * TOK, row1 = row0 + NR;
-    const int first = blockIdx.x * TML_COLS;
+    const int first = blockIdx.x * COLS;
     const int c = threadIdx.x, lane = lane_id(), wave = c >> 6;
     // everything this workgroup reads is requested here: Wo as DMA into LDS (no registers), the wave's columns of `next`,
     // the residual rows; the partials follow in merge_partials
     for (int k = wave; k < INNER; k += 4) glds16(out_wt + (size_t)k * DIM + lane * 4, wt + k * DIM);
-    TokenColumn wf[TML_COLS / 4];
-#pragma unroll
-    for (int i = 0; i < TML_COLS / 4; ++i) wf[i] = token_column_prefetch(next, first + 4 * i, row0, row1);
+    TokenColumn col = token_column_prefetch(next, first, row0, row1);      // the later columns are requested one step ahead
     float res[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) res[r] = out.resid.x ? out.resid.x[(size_t)(row0 + r) * DIM + c] : 0.f;
@@ -640,13 +640,18 @@ DLIMG_DEVICE void token_merge_linear_body(const float* __restrict__ part, const 
         }
         __syncthreads();
     }
-#pragma unroll
-    for (int i = 0; i < TML_COLS / 4; ++i) token_linear_columns<NR>(next, first + 4 * i, y, nullptr, nullptr, wf[i], row0);
+#pragma unroll 1
+    for (int i = 0; i < COLS / 4; ++i) {
+        const TokenColumn following = token_column_prefetch(next, first + 4 * min(i + 1, COLS / 4 - 1), row0, row1);
+        token_linear_columns<NR>(next, first + 4 * i, y, nullptr, nullptr, col, row0);
+        col = following;
+    }
 }
+template <int COLS>
 __global__ __launch_bounds__(256) void token_merge_linear_kernel(const float* __restrict__ part, k::TokenLinear out,
                                                                  const float* __restrict__ out_wt, k::TokenLinear next, int P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    token_merge_linear_body<TOK>(part, out, out_wt, next, blockIdx.y, lds);
+    token_merge_linear_body<TOK, COLS>(part, out, out_wt, next, blockIdx.y, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -873,13 +878,18 @@ void token_self_attention_out(const float* q, const float* kx, const float* v, c
 void token_merge_linear(const float* scratch, const TokenLinear& out, const float* out_wt, const TokenLinear& next, int P,
                         hipStream_t s) {
     if (P <= 0) return;
-    if (P * TOK > TL_MAX_ROWS || out.K != INNER || out.N != DIM || out.resid.add || next.K != DIM || next.N % TML_COLS ||
-        next.resid.x)
+    if (P * TOK > TL_MAX_ROWS || out.K != INNER || out.N != DIM || out.resid.add || next.K != DIM || next.N % 64 || next.resid.x)
         throw_error("token_merge_linear: unsupported shape");
-    static k::LdsOptIn opt_in;
-    opt_in.ensure((const void*)token_merge_linear_kernel, TML_LDS, "token_merge_linear: the device refuses the kernel's LDS size");
-    hipLaunchKernelGGL(token_merge_linear_kernel, dim3(next.N / TML_COLS, P), dim3(256),
-                       TML_LDS, s, scratch, out, out_wt, next, P);
+    auto launch = [&](auto cols_tag, k::LdsOptIn& opt_in) {
+        constexpr int COLS = decltype(cols_tag)::value;
+        opt_in.ensure((const void*)token_merge_linear_kernel<COLS>, TML_LDS, "token_merge_linear: the device refuses the kernel's LDS size");
+        hipLaunchKernelGGL(token_merge_linear_kernel<COLS>, dim3(next.N / COLS, P), dim3(256), TML_LDS, s, scratch, out, out_wt, next, P);
+    };
+    static k::LdsOptIn opt16, opt32, opt64;
+    // the smallest workgroups that still fit the chip in one round (256 CUs, one workgroup each: 150 KB of LDS)
+    if ((next.N / 16) * P <= 256) launch(std::integral_constant<int, 16>{}, opt16);
+    else if ((next.N / 32) * P <= 256) launch(std::integral_constant<int, 32>{}, opt32);
+    else launch(std::integral_constant<int, 64>{}, opt64);
 }
 
 void token_to_image_partials(const float* q, const TokenLinear* q_proj, const half_t* K, int ldk, const half_t* V, int ldv,

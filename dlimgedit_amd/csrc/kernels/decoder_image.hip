@@ -214,6 +214,7 @@ struct Upscale {
     const half_t* W2; const float* b2;         // [128][64], [128]
     const float* hyper;                        // [P][4][32]
     float* logits;                             // [P][4][256][256]
+    int rows_per_block;
 };
 
 __global__ __launch_bounds__(256) void upscale_logits_kernel(Upscale a) {
@@ -221,16 +222,11 @@ __global__ __launch_bounds__(256) void upscale_logits_kernel(Upscale a) {
     half_t* w1 = reinterpret_cast<half_t*>(smem);
     half_t* w2 = w1 + (size_t)DIM * UP_W1STRIDE;
     float* cst = reinterpret_cast<float*>(w2 + (size_t)128 * UP_W2STRIDE);
-    const float* c_b1 = cst;
-    const float* c_lw = cst + 256;
-    const float* c_lb = cst + 320;
-    const float* c_b2 = cst + 384;
-    const float* c_hy = cst + 512;
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const int m = lane & 15, g = lane >> 4;
-    const size_t row0 = (size_t)blockIdx.x * UP_ROWS;
+    const size_t row0 = (size_t)blockIdx.x * a.rows_per_block;         // rows_per_block: a multiple of 64 that divides 4096
     const int p = (int)(row0 / NTOK_IMG);
-    const size_t row = row0 + wave * 16 + m;
+    size_t row = row0 + wave * 16 + m;
 
     // the wave's own 16 rows of the keys, as A fragments: k = 32 kk + 8 g .. + 7
     half8_t a1[8];
@@ -272,12 +268,31 @@ __global__ __launch_bounds__(256) void upscale_logits_kernel(Upscale a) {
     }
     __syncthreads();
 
+    // with many prompts a workgroup takes several groups of 64 rows, so that the 150 KB of weights are staged once for all
+#pragma unroll 1
+    for (int rb = 0; rb < a.rows_per_block; rb += UP_ROWS) {
+    // the LDS reads below do not depend on rb: without this the compiler hoists all of them out of the loop into registers
+    // it does not have (474 spills)
+    int not_invariant = 0;
+    asm volatile("" : "+v"(not_invariant));
+    const half_t* w1i = w1 + not_invariant;
+    const half_t* w2i = w2 + not_invariant;
+    const float* c_b1 = cst + not_invariant;
+    const float* c_lw = c_b1 + 256;
+    const float* c_lb = c_b1 + 320;
+    const float* c_b2 = c_b1 + 384;
+    const float* c_hy = c_b1 + 512;
+    if (rb > 0) {
+        row = row0 + rb + wave * 16 + m;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) a1[kk] = *reinterpret_cast<const half8_t*>(a.keys_h + row * DIM + 32 * kk + 8 * g);
+    }
     // stage A: acc1[jt][r] = up1[row m][column jt * 16 + 4 g + r], column = s1 * 64 + co
     f32x4 acc1[16];
 #pragma unroll
     for (int jt = 0; jt < 16; ++jt) acc1[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
     {
-        const half_t* wl = w1 + (size_t)m * UP_W1STRIDE + 8 * g;
+        const half_t* wl = w1i + (size_t)m * UP_W1STRIDE + 8 * g;
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
@@ -289,7 +304,7 @@ __global__ __launch_bounds__(256) void upscale_logits_kernel(Upscale a) {
 
     const int tok = (int)(row % NTOK_IMG), ty = tok >> 6, tx = tok & 63;
     float* out = a.logits + ((size_t)p * 4 + g) * 65536;
-    const half_t* w2l = w2 + (size_t)m * UP_W2STRIDE + 4 * g;
+    const half_t* w2l = w2i + (size_t)m * UP_W2STRIDE + 4 * g;
 #pragma unroll
     for (int s1 = 0; s1 < 4; ++s1) {
         // stage B: LayerNorm2d over the 64 channels of sub-pixel s1, GELU, f16 -> A fragments of stage C
@@ -369,6 +384,7 @@ __global__ __launch_bounds__(256) void upscale_logits_kernel(Upscale a) {
             out[Y * 256 + X] = total;
         }
     }
+    }
 }
 
 }  // namespace
@@ -393,8 +409,10 @@ void upscale_logits(const half_t* keys_h, const half_t* W1, const float* b1, con
     if (((uintptr_t)keys_h | (uintptr_t)W1 | (uintptr_t)W2) & 15) throw_error("upscale_logits: operands must be 16-byte aligned");
     static k::LdsOptIn opt_in;
     opt_in.ensure((const void*)upscale_logits_kernel, UP_LDS, "upscale_logits: the device refuses the kernel's LDS size");
-    Upscale a{keys_h, W1, b1, ln_w, ln_b, eps, W2, b2, hyper, logits};
-    hipLaunchKernelGGL(upscale_logits_kernel, dim3(P * NTOK_IMG / UP_ROWS), dim3(256), UP_LDS, s, a);
+    // one workgroup per CU (156 KB of LDS): the smallest row groups that still fit the chip in one round
+    const int rows_per_block = P * (NTOK_IMG / 64) <= 256 ? 64 : (P * (NTOK_IMG / 128) <= 256 ? 128 : 256);
+    Upscale a{keys_h, W1, b1, ln_w, ln_b, eps, W2, b2, hyper, logits, rows_per_block};
+    hipLaunchKernelGGL(upscale_logits_kernel, dim3(P * NTOK_IMG / rows_per_block), dim3(256), UP_LDS, s, a);
 }
 
 }  // namespace k
