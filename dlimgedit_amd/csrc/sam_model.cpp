@@ -306,8 +306,10 @@ SamModel::~SamModel() {
     for (auto e : done_pool_) (void)hipEventDestroy(e);
     for (auto& st : stage_)
         if (st.copied) (void)hipEventDestroy(st.copied);
-    for (auto& m : mask_slots_)
+    for (auto& m : mask_slots_) {
         if (m->done) (void)hipEventDestroy(m->done);
+        for (auto e : m->piece_done) (void)hipEventDestroy(e);
+    }
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -887,7 +889,24 @@ void SamModel::enqueue_masks(MaskSlot& slot, k::PostJob const* jobs, int count, 
     if (iou_count > 0)
         HIP_CHECK(hipMemcpyAsync(slot.dev.get() + total, iou_.get(), (size_t)iou_count * sizeof(float),
                                  hipMemcpyDeviceToDevice, stream_));
-    HIP_CHECK(hipMemcpyAsync(slot.pin.get(), slot.dev.get(), with_iou, hipMemcpyDeviceToHost, stream_));
+    // device -> pinned host: one mask in one piece (every piece costs a copy command and an event, 20 us for four of them);
+    // two masks or more in up to six pieces of about 1 MiB, so that the host's copy-out of piece i runs beside the transfer
+    // of piece i + 1 (five masks per call: 0.81 -> 0.71 ms)
+    constexpr size_t kPiece = 1024 * 1024;
+    const size_t pieces = with_iou < 2 * kPiece ? 1 : std::min<size_t>(6, with_iou / kPiece);
+    const size_t piece = (with_iou / pieces + 255) / 256 * 256;
+    slot.piece_end.clear();
+    for (size_t a = 0, i = 0; a < with_iou; a += piece, ++i) {
+        const size_t b = std::min(with_iou, a + piece);
+        if (slot.piece_done.size() <= i) {
+            hipEvent_t e = nullptr;
+            HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            slot.piece_done.push_back(e);
+        }
+        HIP_CHECK(hipMemcpyAsync(static_cast<uint8_t*>(slot.pin.get()) + a, slot.dev.get() + a, b - a, hipMemcpyDeviceToHost, stream_));
+        HIP_CHECK(hipEventRecord(slot.piece_done[i], stream_));
+        slot.piece_end.push_back(b);
+    }
     HIP_CHECK(hipEventRecord(slot.done, stream_));
 }
 
@@ -895,19 +914,35 @@ void SamModel::finish_masks(MaskSlot& slot, k::PostJob const* jobs, int count, f
     if (count <= 0) return;
     static const bool trace = std::getenv("DLIMGEDIT_TIMING") != nullptr;     // diagnostic: host time of the two phases
     const auto t0 = std::chrono::steady_clock::now();
+    uint8_t const* pin = static_cast<uint8_t const*>(slot.pin.get());
+    // piece by piece: what has arrived is copied to the callers' buffers while the rest is still on its way
+    double waited_us = 0;
+    size_t off = 0, begin = 0;
+    int job = 0;
+    for (size_t i = 0; i < slot.piece_end.size(); ++i) {
+        const auto w0 = std::chrono::steady_clock::now();
+        HIP_CHECK(hipEventSynchronize(slot.piece_done[i]));
+        waited_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
+        const size_t end = slot.piece_end[i];
+        // jobs (staging range [off, off + w * h), padded to mask_bytes) that overlap [begin, end)
+        while (job < count) {
+            const size_t len = (size_t)jobs[job].out_w * jobs[job].out_h;
+            const size_t a = std::max(begin, off), b = std::min(end, off + len);
+            if (b > a) std::memcpy(jobs[job].dst + (a - off), pin + a, b - a);
+            if (off + mask_bytes(jobs[job]) > end) break;           // the rest of this job is in the next piece
+            off += mask_bytes(jobs[job]);
+            ++job;
+        }
+        begin = end;
+    }
     HIP_CHECK(hipEventSynchronize(slot.done));
     const auto t1 = std::chrono::steady_clock::now();
-    uint8_t const* pin = static_cast<uint8_t const*>(slot.pin.get());
-    size_t off = 0;
-    for (int i = 0; i < count; ++i) {
-        std::memcpy(jobs[i].dst, pin + off, (size_t)jobs[i].out_w * jobs[i].out_h);
-        off += mask_bytes(jobs[i]);
-    }
+    off = 0;
+    for (int i = 0; i < count; ++i) off += mask_bytes(jobs[i]);
     if (iou_out && iou_count > 0) std::memcpy(iou_out, pin + slot.iou_offset, (size_t)iou_count * sizeof(float));
     if (trace)
-        std::fprintf(stderr, "finish_masks: wait %.1f us, copy out %.1f us (%zu bytes)\n",
-                     std::chrono::duration<double, std::micro>(t1 - t0).count(),
-                     std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count(), off);
+        std::fprintf(stderr, "finish_masks: %.1f us in all, %.1f us of them waiting for the %zu pieces (%zu bytes)\n",
+                     std::chrono::duration<double, std::micro>(t1 - t0).count(), waited_us, slot.piece_end.size(), off);
 }
 
 namespace {

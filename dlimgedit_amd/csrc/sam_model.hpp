@@ -164,6 +164,10 @@ class SamModel {
         PinnedBuffer pin;
         hipEvent_t done = nullptr;
         size_t iou_offset = 0;
+        // the staging area travels to the host in a few pieces, each with its own event, so that the host copies piece i
+        // to the caller's buffers while piece i + 1 is still on the bus (enqueue_masks / finish_masks)
+        std::vector<hipEvent_t> piece_done;
+        std::vector<size_t> piece_end;
     };
     MaskSlot& acquire_mask_slot();
     void release_mask_slot(MaskSlot& s);
