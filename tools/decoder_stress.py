@@ -1,6 +1,6 @@
 """Hammer the decoder from several threads on ONE cached embedding and compare every result bit for bit with the serial
 answer; on a mismatch say where the logits differ (plane, rows, how many, how much).
-python tools/decoder_stress.py [threads] [reps per thread]"""
+python tools/decoder_stress.py [threads] [reps per thread] [logits|masks|state|encode] [variant]"""
 import sys, tempfile, threading
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent)); sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tests"))
@@ -12,7 +12,7 @@ from dlimgedit_amd.sam_config import get_config
 threads = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 mode = sys.argv[3] if len(sys.argv) > 3 else "logits"      # logits | masks (compute_mask / compute_masks mixed, as the test does)
-cfg = get_config("vit_test")
+cfg = get_config(sys.argv[4] if len(sys.argv) > 4 else "vit_test")      # the decoder is the same for every variant; "encode" wants vit_b
 with tempfile.TemporaryDirectory() as d:
     W.write_synthetic_model_dir(d, cfg, seed=0)
     env = api.Environment(api.Options(api.Backend.gpu, d))
