@@ -370,6 +370,7 @@ class ext:
                 "dlimg_amd_get_embedding": ([vp, vp], ci),
                 "dlimg_amd_get_logits": ([vp, C.POINTER(ci), C.POINTER(ci), vp, vp], ci),
                 "dlimg_amd_decoder_state": ([vp, C.POINTER(ci), vp, ci, C.c_char_p, ci], ci),
+                "dlimg_amd_test_plan_steps": ([ci, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), ci, ci, ci, ci, C.POINTER(ci), C.POINTER(ci), ci], ci),
                 "dlimg_amd_device_alloc": ([vp, C.c_size_t, C.POINTER(vp)], ci),
                 "dlimg_amd_device_free": ([vp, vp], ci),
                 "dlimg_amd_copy_to_device": ([vp, vp, vp, C.c_size_t], ci),
@@ -407,7 +408,7 @@ class ext:
         return lib
 
     EXPORTS = ("dlimg_amd_device_count", "dlimg_amd_model_geometry", "dlimg_amd_get_embedding", "dlimg_amd_get_logits",
-               "dlimg_amd_decoder_state", "dlimg_amd_device_alloc", "dlimg_amd_device_free", "dlimg_amd_copy_to_device", "dlimg_amd_copy_to_host",
+               "dlimg_amd_decoder_state", "dlimg_amd_test_plan_steps", "dlimg_amd_device_alloc", "dlimg_amd_device_free", "dlimg_amd_copy_to_device", "dlimg_amd_copy_to_host",
                "dlimg_amd_encode_and_mask", "dlimg_amd_encode_only", "dlimg_amd_synchronize", "dlimg_amd_lane_count",
                "dlimg_amd_replica_count", "dlimg_amd_segmentation_device", "dlimg_amd_get_segmentation_masks_device",
                "dlimg_amd_set_profiling",
@@ -459,6 +460,21 @@ class ext:
             res[n] = out[off:off + c]
             off += c
         return res
+
+    @classmethod
+    def plan_steps(cls, passes_in_flight, images_in_flight, cursor: int, pending: int, width: int, depth: int, all_: bool):
+        """Host logic of the device-step queue (no GPU needed): returns (passes [(lane, images)], new passes in flight, new
+        images in flight, new cursor)."""
+        lanes = len(passes_in_flight)
+        p = (C.c_int * lanes)(*passes_in_flight)
+        i = (C.c_int * lanes)(*images_in_flight)
+        cur = C.c_int(cursor)
+        cap = pending + lanes + 1
+        out_lane, out_images = (C.c_int * cap)(), (C.c_int * cap)()
+        n = cls._l().dlimg_amd_test_plan_steps(lanes, p, i, C.byref(cur), pending, width, depth, int(all_), out_lane, out_images, cap)
+        if n < 0:
+            _check(1)
+        return [(out_lane[k], out_images[k]) for k in range(n)], list(p), list(i), cur.value
 
     # -- benchmark path
     @classmethod

@@ -1,6 +1,7 @@
 // Extension entry points declared in include/dlimgedit/dlimgedit_amd.h: benchmark path with
 // device-resident data, stage clocks, and single-kernel hooks for the parity tests.
 #include "environment.hpp"
+#include "step_queue.hpp"
 #include "segmentation.hpp"
 #include "resize_tables.hpp"
 
@@ -247,64 +248,33 @@ int retire_device_steps(EnvironmentImpl& env) {
     return lanes;
 }
 
-// The lane with the fewest passes in flight; among equals the one after the lane used last, so that the lanes take turns
-// even where completion cannot be observed (under rocprofv3's kernel trace hipEventQuery reports every pass as finished).
-int least_busy_lane(EnvironmentImpl& env, int lanes) {
-    int best = -1;
-    for (int i = 0; i < lanes; ++i) {
-        const int l = (env.step_cursor + i) % lanes;
-        if (best < 0 || env.step_passes[l].size() < env.step_passes[best].size()) best = l;
+// The queue's state as the planner sees it (step_queue.hpp); `lanes` = the lanes requests are spread over
+void queue_state(EnvironmentImpl& env, int lanes, StepQueueState& st) {
+    st.cursor = env.step_cursor % lanes;
+    for (int l = 0; l < lanes; ++l) {
+        int images = 0;
+        for (auto const& pass : env.step_passes[l]) images += pass.images;
+        st.passes_in_flight.push_back((int)env.step_passes[l].size());
+        st.images_in_flight.push_back(images);
     }
-    env.step_cursor = (best + 1) % lanes;
-    return best;
 }
 
-// Launches what is waiting (environment.hpp, PendingStep).  Without `all`: one pass of `coalesce` images at a time on
-// the lane with the fewest passes in flight, as long as that lane has fewer than `step_depth`.  With `all`
-// (dlimg_amd_synchronize): every waiting request, dealt so that the images in flight per lane end up level, in passes of
-// at most `coalesce` images whose sizes differ by at most one on a lane.
+// Launches what is waiting (environment.hpp, PendingStep) as step_queue.hpp plans it.  pending_mutex held by the caller.
 // [Holding requests back until a whole wave of lanes x coalesce had arrived was measured and gained nothing on a burst of
-// 20 requests, while it delays the first launch.]  pending_mutex held by the caller.
+// 20 requests, while it delays the first launch.  Under rocprofv3's kernel trace hipEventQuery reports every pass as
+// finished: the planner's tie-break keeps the lanes taking turns there.]
 void flush_device_steps(EnvironmentImpl& env, bool all) {
     if (env.pending.empty()) return;
-    const size_t width = (size_t)std::max(1, env.coalesce);
     const int lanes = retire_device_steps(env);
+    StepQueueState st;
+    queue_state(env, lanes, st);
+    const std::vector<StepPlanPass> plan = plan_device_steps(st, (int)env.pending.size(), env.coalesce, env.step_depth, all);
+    env.step_cursor = st.cursor;
     size_t done = 0;
     try {
-        while (env.pending.size() - done >= width) {
-            const int best = least_busy_lane(env, lanes);
-            if ((int)env.step_passes[best].size() >= env.step_depth) break;
-            run_device_steps(env, best, env.pending.data() + done, (int)width);
-            done += width;
-        }
-        if (all && done < env.pending.size()) {
-            std::vector<size_t> load(lanes, 0), share(lanes, 0);
-            for (int l = 0; l < lanes; ++l)
-                for (auto const& pass : env.step_passes[l]) load[l] += (size_t)pass.images;
-            for (size_t i = done; i < env.pending.size(); ++i) {
-                int best = -1;
-                for (int k = 0; k < lanes; ++k) {
-                    const int l = (env.step_cursor + k) % lanes;
-                    if (best < 0 || load[l] < load[best]) best = l;
-                }
-                env.step_cursor = (best + 1) % lanes;
-                ++load[best];
-                ++share[best];
-            }
-            // round by round over the lanes, so that no lane's stream is filled long before the others'
-            std::vector<size_t> passes(lanes);
-            size_t rounds = 0;
-            for (int l = 0; l < lanes; ++l) {
-                passes[l] = (share[l] + width - 1) / width;
-                rounds = std::max(rounds, passes[l]);
-            }
-            for (size_t r = 0; r < rounds; ++r)
-                for (int l = 0; l < lanes; ++l) {
-                    if (r >= passes[l]) continue;
-                    const size_t n = share[l] / passes[l] + (r < share[l] % passes[l] ? 1 : 0);
-                    run_device_steps(env, l, env.pending.data() + done, (int)n);
-                    done += n;
-                }
+        for (StepPlanPass const& pass : plan) {
+            run_device_steps(env, pass.lane, env.pending.data() + done, pass.images);
+            done += (size_t)pass.images;
         }
     } catch (...) {
         env.pending.clear();         // a failed pass must not be retried by the next call
@@ -313,8 +283,41 @@ void flush_device_steps(EnvironmentImpl& env, bool all) {
     env.pending.erase(env.pending.begin(), env.pending.begin() + done);
 }
 
+// a call that is a batch already: the lane with the fewest passes in flight, whatever its depth
+int lane_for_batch(EnvironmentImpl& env) {
+    const int lanes = retire_device_steps(env);
+    StepQueueState st;
+    queue_state(env, lanes, st);
+    const std::vector<StepPlanPass> plan = plan_device_steps(st, 1, 1, 1 << 30, false);
+    env.step_cursor = st.cursor;
+    return plan.empty() ? 0 : plan[0].lane;
+}
+
 }  // namespace
 }  // namespace dlimg
+
+DLIMG_API int dlimg_amd_test_plan_steps(int lanes, int* passes_in_flight, int* images_in_flight, int* cursor, int pending, int width,
+                                        int depth, int all, int* out_lane, int* out_images, int capacity) {
+    int planned = -1;
+    const int rc = guarded([&] {
+        DLIMG_ASSERT(lanes > 0 && passes_in_flight && images_in_flight && cursor && capacity >= 0);
+        StepQueueState st;
+        st.passes_in_flight.assign(passes_in_flight, passes_in_flight + lanes);
+        st.images_in_flight.assign(images_in_flight, images_in_flight + lanes);
+        st.cursor = *cursor % lanes;
+        const std::vector<StepPlanPass> plan = plan_device_steps(st, pending, width, depth, all != 0);
+        if ((int)plan.size() > capacity) throw Exception("test_plan_steps: the output arrays are too small");
+        for (size_t i = 0; i < plan.size(); ++i) {
+            out_lane[i] = plan[i].lane;
+            out_images[i] = plan[i].images;
+        }
+        std::copy(st.passes_in_flight.begin(), st.passes_in_flight.end(), passes_in_flight);
+        std::copy(st.images_in_flight.begin(), st.images_in_flight.end(), images_in_flight);
+        *cursor = st.cursor;
+        planned = (int)plan.size();
+    });
+    return rc == 0 ? planned : -1;
+}
 
 DLIMG_API int dlimg_amd_encode_and_mask(dlimg_Environment env, dlimg_ImageView const* dev_images, int count,
                                         int const* points, uint8_t* const* dev_masks) {
@@ -334,7 +337,7 @@ DLIMG_API int dlimg_amd_encode_and_mask(dlimg_Environment env, dlimg_ImageView c
             std::vector<EnvironmentImpl::PendingStep> steps(count);
             for (int i = 0; i < count; ++i)
                 steps[i] = EnvironmentImpl::PendingStep{dev_images[i], points[i * 2], points[i * 2 + 1], dev_masks[i]};
-            run_device_steps(e, least_busy_lane(e, retire_device_steps(e)), steps.data(), count);
+            run_device_steps(e, lane_for_batch(e), steps.data(), count);
             return;
         }
         for (int i = 0; i < count; ++i)

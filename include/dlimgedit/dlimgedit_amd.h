@@ -41,6 +41,12 @@ DLIMG_API int dlimg_amd_get_logits(dlimg_Segmentation seg, int const* point, int
 DLIMG_API int dlimg_amd_decoder_state(dlimg_Segmentation seg, int const* point, float* out, int capacity, char* out_layout,
                                       int layout_capacity);
 
+/* Host logic of the device-step queue behind dlimg_amd_encode_and_mask, callable without a GPU (tests): plans the passes
+ * for `pending` waiting requests given the per-lane passes / images in flight and the lane cursor, updates those as if the
+ * passes had been launched, writes (lane, images) per pass in launch order and returns the number of passes (-1: error). */
+DLIMG_API int dlimg_amd_test_plan_steps(int lanes, int* passes_in_flight, int* images_in_flight, int* cursor, int pending, int width,
+                                        int depth, int all, int* out_lane, int* out_images, int capacity);
+
 /* ---- benchmark path: everything device-resident, stream-ordered, no host synchronisation ----- */
 /* Device memory helpers (hipMalloc/hipFree/hipMemcpy on the environment's device). */
 DLIMG_API int dlimg_amd_device_alloc(dlimg_Environment env, size_t bytes, void** out_ptr);
