@@ -370,6 +370,8 @@ class ext:
                 "dlimg_amd_get_embedding": ([vp, vp], ci),
                 "dlimg_amd_get_logits": ([vp, C.POINTER(ci), C.POINTER(ci), vp, vp], ci),
                 "dlimg_amd_decoder_state": ([vp, C.POINTER(ci), vp, ci, C.c_char_p, ci], ci),
+                "dlimg_amd_test_mask_pieces": ([ci, C.POINTER(C.c_longlong), C.c_longlong, C.POINTER(C.c_longlong), ci,
+                                               C.POINTER(C.c_longlong), ci, C.POINTER(ci)], ci),
                 "dlimg_amd_test_plan_steps": ([ci, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), ci, ci, ci, ci, C.POINTER(ci), C.POINTER(ci), ci], ci),
                 "dlimg_amd_device_alloc": ([vp, C.c_size_t, C.POINTER(vp)], ci),
                 "dlimg_amd_device_free": ([vp, vp], ci),
@@ -408,7 +410,7 @@ class ext:
         return lib
 
     EXPORTS = ("dlimg_amd_device_count", "dlimg_amd_model_geometry", "dlimg_amd_get_embedding", "dlimg_amd_get_logits",
-               "dlimg_amd_decoder_state", "dlimg_amd_test_plan_steps", "dlimg_amd_device_alloc", "dlimg_amd_device_free", "dlimg_amd_copy_to_device", "dlimg_amd_copy_to_host",
+               "dlimg_amd_decoder_state", "dlimg_amd_test_plan_steps", "dlimg_amd_test_mask_pieces", "dlimg_amd_device_alloc", "dlimg_amd_device_free", "dlimg_amd_copy_to_device", "dlimg_amd_copy_to_host",
                "dlimg_amd_encode_and_mask", "dlimg_amd_encode_only", "dlimg_amd_synchronize", "dlimg_amd_lane_count",
                "dlimg_amd_replica_count", "dlimg_amd_segmentation_device", "dlimg_amd_get_segmentation_masks_device",
                "dlimg_amd_set_profiling",
@@ -460,6 +462,21 @@ class ext:
             res[n] = out[off:off + c]
             off += c
         return res
+
+    @classmethod
+    def mask_pieces(cls, mask_bytes, extra_bytes: int = 0):
+        """Host logic of the mask transfer (no GPU needed): (piece end offsets, [(piece, mask, staging offset, offset in the
+        mask, bytes)])."""
+        n = len(mask_bytes)
+        sizes = (C.c_longlong * max(1, n))(*mask_bytes)
+        ends = (C.c_longlong * 8)()
+        cap = 8 * (n + 1)
+        copies = (C.c_longlong * (5 * cap))()
+        pieces = C.c_int(0)
+        got = cls._l().dlimg_amd_test_mask_pieces(n, sizes, extra_bytes, ends, 8, copies, cap, C.byref(pieces))
+        if got < 0:
+            _check(1)
+        return [ends[i] for i in range(pieces.value)], [tuple(copies[5 * k + j] for j in range(5)) for k in range(got)]
 
     @classmethod
     def plan_steps(cls, passes_in_flight, images_in_flight, cursor: int, pending: int, width: int, depth: int, all_: bool):

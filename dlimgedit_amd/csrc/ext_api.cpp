@@ -2,6 +2,7 @@
 // device-resident data, stage clocks, and single-kernel hooks for the parity tests.
 #include "environment.hpp"
 #include "step_queue.hpp"
+#include "mask_pieces.hpp"
 #include "segmentation.hpp"
 #include "resize_tables.hpp"
 
@@ -295,6 +296,42 @@ int lane_for_batch(EnvironmentImpl& env) {
 
 }  // namespace
 }  // namespace dlimg
+
+DLIMG_API int dlimg_amd_test_mask_pieces(int count, long long const* mask_bytes, long long extra_bytes, long long* out_piece_end,
+                                         int piece_capacity, long long* out_copies, int copy_capacity, int* out_pieces) {
+    int copies = -1;
+    const int rc = guarded([&] {
+        DLIMG_ASSERT(count >= 0 && mask_bytes && out_piece_end && out_copies && out_pieces);
+        std::vector<size_t> sizes(count);
+        size_t total = 0;
+        for (int i = 0; i < count; ++i) {
+            sizes[i] = (size_t)mask_bytes[i];
+            total += padded_mask_bytes(sizes[i]);
+        }
+        total += (size_t)extra_bytes;
+        const std::vector<size_t> ends = mask_piece_ends(total);
+        if ((int)ends.size() > piece_capacity) throw Exception("test_mask_pieces: the piece array is too small");
+        MaskCursor cursor;
+        size_t begin = 0;
+        int n = 0;
+        for (size_t i = 0; i < ends.size(); ++i) {
+            out_piece_end[i] = (long long)ends[i];
+            for (MaskCopy const& c : mask_copies_in_piece(sizes, begin, ends[i], cursor)) {
+                if (n >= copy_capacity) throw Exception("test_mask_pieces: the copy array is too small");
+                out_copies[n * 5 + 0] = (long long)i;
+                out_copies[n * 5 + 1] = c.mask;
+                out_copies[n * 5 + 2] = (long long)c.staging_offset;
+                out_copies[n * 5 + 3] = (long long)c.mask_offset;
+                out_copies[n * 5 + 4] = (long long)c.bytes;
+                ++n;
+            }
+            begin = ends[i];
+        }
+        *out_pieces = (int)ends.size();
+        copies = n;
+    });
+    return rc == 0 ? copies : -1;
+}
 
 DLIMG_API int dlimg_amd_test_plan_steps(int lanes, int* passes_in_flight, int* images_in_flight, int* cursor, int pending, int width,
                                         int depth, int all, int* out_lane, int* out_images, int capacity) {

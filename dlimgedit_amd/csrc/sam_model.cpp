@@ -1,4 +1,5 @@
 #include "sam_model.hpp"
+#include "mask_pieces.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -866,7 +867,7 @@ void SamModel::release_mask_slot(MaskSlot& s) {
     mask_free_.push_back(&s);
 }
 
-static size_t mask_bytes(k::PostJob const& j) { return ((size_t)j.out_w * j.out_h + 255) / 256 * 256; }
+static size_t mask_bytes(k::PostJob const& j) { return padded_mask_bytes((size_t)j.out_w * j.out_h); }
 
 void SamModel::enqueue_masks(MaskSlot& slot, k::PostJob const* jobs, int count, int iou_count) {
     if (count <= 0) return;
@@ -889,15 +890,11 @@ void SamModel::enqueue_masks(MaskSlot& slot, k::PostJob const* jobs, int count, 
     if (iou_count > 0)
         HIP_CHECK(hipMemcpyAsync(slot.dev.get() + total, iou_.get(), (size_t)iou_count * sizeof(float),
                                  hipMemcpyDeviceToDevice, stream_));
-    // device -> pinned host: one mask in one piece (every piece costs a copy command and an event, 20 us for four of them);
-    // two masks or more in up to six pieces of about 1 MiB, so that the host's copy-out of piece i runs beside the transfer
-    // of piece i + 1 (five masks per call: 0.81 -> 0.71 ms)
-    constexpr size_t kPiece = 1024 * 1024;
-    const size_t pieces = with_iou < 2 * kPiece ? 1 : std::min<size_t>(6, with_iou / kPiece);
-    const size_t piece = (with_iou / pieces + 255) / 256 * 256;
-    slot.piece_end.clear();
-    for (size_t a = 0, i = 0; a < with_iou; a += piece, ++i) {
-        const size_t b = std::min(with_iou, a + piece);
+    // device -> pinned host in pieces, each with its own event (mask_pieces.hpp)
+    slot.piece_end = mask_piece_ends(with_iou);
+    size_t a = 0;
+    for (size_t i = 0; i < slot.piece_end.size(); ++i) {
+        const size_t b = slot.piece_end[i];
         if (slot.piece_done.size() <= i) {
             hipEvent_t e = nullptr;
             HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -905,7 +902,7 @@ void SamModel::enqueue_masks(MaskSlot& slot, k::PostJob const* jobs, int count, 
         }
         HIP_CHECK(hipMemcpyAsync(static_cast<uint8_t*>(slot.pin.get()) + a, slot.dev.get() + a, b - a, hipMemcpyDeviceToHost, stream_));
         HIP_CHECK(hipEventRecord(slot.piece_done[i], stream_));
-        slot.piece_end.push_back(b);
+        a = b;
     }
     HIP_CHECK(hipEventRecord(slot.done, stream_));
 }
@@ -917,27 +914,21 @@ void SamModel::finish_masks(MaskSlot& slot, k::PostJob const* jobs, int count, f
     uint8_t const* pin = static_cast<uint8_t const*>(slot.pin.get());
     // piece by piece: what has arrived is copied to the callers' buffers while the rest is still on its way
     double waited_us = 0;
-    size_t off = 0, begin = 0;
-    int job = 0;
+    std::vector<size_t> sizes(count);
+    for (int i = 0; i < count; ++i) sizes[i] = (size_t)jobs[i].out_w * jobs[i].out_h;
+    MaskCursor cursor;
+    size_t begin = 0;
     for (size_t i = 0; i < slot.piece_end.size(); ++i) {
         const auto w0 = std::chrono::steady_clock::now();
         HIP_CHECK(hipEventSynchronize(slot.piece_done[i]));
         waited_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
-        const size_t end = slot.piece_end[i];
-        // jobs (staging range [off, off + w * h), padded to mask_bytes) that overlap [begin, end)
-        while (job < count) {
-            const size_t len = (size_t)jobs[job].out_w * jobs[job].out_h;
-            const size_t a = std::max(begin, off), b = std::min(end, off + len);
-            if (b > a) std::memcpy(jobs[job].dst + (a - off), pin + a, b - a);
-            if (off + mask_bytes(jobs[job]) > end) break;           // the rest of this job is in the next piece
-            off += mask_bytes(jobs[job]);
-            ++job;
-        }
-        begin = end;
+        for (MaskCopy const& c : mask_copies_in_piece(sizes, begin, slot.piece_end[i], cursor))
+            std::memcpy(jobs[c.mask].dst + c.mask_offset, pin + c.staging_offset, c.bytes);
+        begin = slot.piece_end[i];
     }
     HIP_CHECK(hipEventSynchronize(slot.done));
     const auto t1 = std::chrono::steady_clock::now();
-    off = 0;
+    size_t off = 0;
     for (int i = 0; i < count; ++i) off += mask_bytes(jobs[i]);
     if (iou_out && iou_count > 0) std::memcpy(iou_out, pin + slot.iou_offset, (size_t)iou_count * sizeof(float));
     if (trace)

@@ -41,6 +41,12 @@ DLIMG_API int dlimg_amd_get_logits(dlimg_Segmentation seg, int const* point, int
 DLIMG_API int dlimg_amd_decoder_state(dlimg_Segmentation seg, int const* point, float* out, int capacity, char* out_layout,
                                       int layout_capacity);
 
+/* Host logic of the mask transfer (csrc/mask_pieces.hpp), callable without a GPU (tests): for `count` masks of the given sizes
+ * (+ extra_bytes behind them) the end offsets of the pieces the staging area travels in, and per piece the copies the host
+ * makes once it has arrived, five numbers each: piece, mask, staging offset, offset inside the mask, bytes.  Returns the
+ * number of copies (-1: error). */
+DLIMG_API int dlimg_amd_test_mask_pieces(int count, long long const* mask_bytes, long long extra_bytes, long long* out_piece_end,
+                                         int piece_capacity, long long* out_copies, int copy_capacity, int* out_pieces);
 /* Host logic of the device-step queue behind dlimg_amd_encode_and_mask, callable without a GPU (tests): plans the passes
  * for `pending` waiting requests given the per-lane passes / images in flight and the lane cursor, updates those as if the
  * passes had been launched, writes (lane, images) per pass in launch order and returns the number of passes (-1: error). */
