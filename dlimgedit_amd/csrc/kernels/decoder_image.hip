@@ -192,7 +192,9 @@ __global__ __launch_bounds__(256) void image_update_kernel(ImageUpdate a) {
 // Both transposed convolutions (kernel 2, stride 2) are GEMMs over the image positions whose output columns are the four
 // sub-pixels times the output channels (SamWeights: rows of W1 = s1 * 64 + co, rows of W2 = s2 * 32 + c2).  A wave takes 16
 // image positions through all of it:
-//   stage A  [16][256] x W1^T -> 4 sub-pixels x 64 channels per position (v_mfma_f32_16x16x32_f16, W1 in LDS)
+//   stage A  [16][256] x W1^T -> sub-pixels x 64 channels per position (v_mfma_f32_16x16x32_f16, W1 in LDS); a workgroup
+//            does two of the four first-stage sub-pixels (half of W1), its twin the other two: twice the workgroups, each
+//            with half of the work and of the weights to stage (one prompt: 128 workgroups, 20 -> 13 us)
 //   stage B  + bias, LayerNorm over the 64 channels of a sub-pixel (16 values in the lane, the rest in the three other lane
 //            groups), GELU, f16: in the accumulator layout these ARE the A fragments of stage C, with the k-permutation
 //            k = (2 kk + i / 4) * 16 + 4 g + i % 4 that the W2 fragments are read with
@@ -205,7 +207,8 @@ constexpr int UP_ROWS = 64;
 constexpr int UP_W1STRIDE = DIM + 8;          // halves per row of W1 in LDS (528 B)
 constexpr int UP_W2STRIDE = 64 + 8;           // halves per row of W2 in LDS (144 B)
 constexpr int UP_CONST = 256 + 64 + 64 + 128 + 128;      // b1 | ln_w | ln_b | b2 | hyper
-constexpr size_t UP_LDS = (size_t)DIM * UP_W1STRIDE * 2 + (size_t)128 * UP_W2STRIDE * 2 + UP_CONST * 4;
+constexpr int UP_W1ROWS = 128;                // a workgroup takes two of the four first-stage sub-pixels: half of W1
+constexpr size_t UP_LDS = (size_t)UP_W1ROWS * UP_W1STRIDE * 2 + (size_t)128 * UP_W2STRIDE * 2 + UP_CONST * 4;
 
 struct Upscale {
     const half_t* keys_h;                      // [P*4096][256]
@@ -220,11 +223,12 @@ struct Upscale {
 __global__ __launch_bounds__(256) void upscale_logits_kernel(Upscale a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* w1 = reinterpret_cast<half_t*>(smem);
-    half_t* w2 = w1 + (size_t)DIM * UP_W1STRIDE;
+    half_t* w2 = w1 + (size_t)UP_W1ROWS * UP_W1STRIDE;
     float* cst = reinterpret_cast<float*>(w2 + (size_t)128 * UP_W2STRIDE);
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const int m = lane & 15, g = lane >> 4;
-    const size_t row0 = (size_t)blockIdx.x * a.rows_per_block;         // rows_per_block: a multiple of 64 that divides 4096
+    const int half = blockIdx.x & 1;                                    // first-stage sub-pixels 2 * half and 2 * half + 1
+    const size_t row0 = (size_t)(blockIdx.x >> 1) * a.rows_per_block;  // rows_per_block: a multiple of 64 that divides 4096
     const int p = (int)(row0 / NTOK_IMG);
     size_t row = row0 + wave * 16 + m;
 
@@ -232,16 +236,15 @@ __global__ __launch_bounds__(256) void upscale_logits_kernel(Upscale a) {
     half8_t a1[8];
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) a1[kk] = *reinterpret_cast<const half8_t*>(a.keys_h + row * DIM + 32 * kk + 8 * g);
-    // weights and constants -> LDS (W1: 8192 chunks of 16 bytes, 32 per thread in two rounds)
-#pragma unroll
-    for (int round = 0; round < 2; ++round) {
+    // weights and constants -> LDS (this half of W1: 128 rows = 4096 chunks of 16 bytes, 16 per thread)
+    {
         half8_t wr[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int ch = tid + 256 * (16 * round + i);
-            wr[i] = *reinterpret_cast<const half8_t*>(a.W1 + (size_t)(ch >> 5) * DIM + (ch & 31) * 8);
+            const int ch = tid + 256 * i;
+            wr[i] = *reinterpret_cast<const half8_t*>(a.W1 + (size_t)(half * UP_W1ROWS + (ch >> 5)) * DIM + (ch & 31) * 8);
         }
-        if (round == 0) {
+        {
             half8_t w2r[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(256) void upscale_logits_kernel(Upscale a) {
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int ch = tid + 256 * (16 * round + i);
+            const int ch = tid + 256 * i;
             *reinterpret_cast<half8_t*>(w1 + (size_t)(ch >> 5) * UP_W1STRIDE + (ch & 31) * 8) = wr[i];
         }
     }
@@ -287,16 +290,16 @@ __global__ __launch_bounds__(256) void upscale_logits_kernel(Upscale a) {
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) a1[kk] = *reinterpret_cast<const half8_t*>(a.keys_h + row * DIM + 32 * kk + 8 * g);
     }
-    // stage A: acc1[jt][r] = up1[row m][column jt * 16 + 4 g + r], column = s1 * 64 + co
-    f32x4 acc1[16];
+    // stage A: acc1[jt][r] = up1[row m][column half * 128 + jt * 16 + 4 g + r], column = s1 * 64 + co
+    f32x4 acc1[8];
 #pragma unroll
-    for (int jt = 0; jt < 16; ++jt) acc1[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int jt = 0; jt < 8; ++jt) acc1[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
     {
         const half_t* wl = w1i + (size_t)m * UP_W1STRIDE + 8 * g;
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
-            for (int jt = 0; jt < 16; ++jt) {
+            for (int jt = 0; jt < 8; ++jt) {
                 const half8_t b = *reinterpret_cast<const half8_t*>(wl + (size_t)jt * 16 * UP_W1STRIDE + 32 * kk);
                 acc1[jt] = mfma16(b, a1[kk], acc1[jt]);
             }
@@ -306,7 +309,8 @@ __global__ __launch_bounds__(256) void upscale_logits_kernel(Upscale a) {
     float* out = a.logits + ((size_t)p * 4 + g) * 65536;
     const half_t* w2l = w2i + (size_t)m * UP_W2STRIDE + 4 * g;
 #pragma unroll
-    for (int s1 = 0; s1 < 4; ++s1) {
+    for (int s1l = 0; s1l < 2; ++s1l) {
+        const int s1 = 2 * half + s1l;
         // stage B: LayerNorm2d over the 64 channels of sub-pixel s1, GELU, f16 -> A fragments of stage C
         f32x4 v[4];
         float sum = 0.f;
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(256) void upscale_logits_kernel(Upscale a) {
             const float4_t bv = reinterpret_cast<const float4_t*>(c_b1)[(4 * s1 + jl) * 4 + g];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                v[jl][r] = acc1[4 * s1 + jl][r] + bv[r];
+                v[jl][r] = acc1[4 * s1l + jl][r] + bv[r];
                 sum += v[jl][r];
             }
         }
@@ -409,10 +413,11 @@ void upscale_logits(const half_t* keys_h, const half_t* W1, const float* b1, con
     if (((uintptr_t)keys_h | (uintptr_t)W1 | (uintptr_t)W2) & 15) throw_error("upscale_logits: operands must be 16-byte aligned");
     static k::LdsOptIn opt_in;
     opt_in.ensure((const void*)upscale_logits_kernel, UP_LDS, "upscale_logits: the device refuses the kernel's LDS size");
-    // one workgroup per CU (156 KB of LDS): the smallest row groups that still fit the chip in one round
-    const int rows_per_block = P * (NTOK_IMG / 64) <= 256 ? 64 : (P * (NTOK_IMG / 128) <= 256 ? 128 : 256);
+    // two workgroups per group of rows (one per pair of first-stage sub-pixels), one workgroup per CU (89 KB of LDS): the
+    // smallest row groups that still fit the chip in one round
+    const int rows_per_block = 2 * P * (NTOK_IMG / 64) <= 256 ? 64 : (2 * P * (NTOK_IMG / 128) <= 256 ? 128 : 256);
     Upscale a{keys_h, W1, b1, ln_w, ln_b, eps, W2, b2, hyper, logits, rows_per_block};
-    hipLaunchKernelGGL(upscale_logits_kernel, dim3(P * NTOK_IMG / rows_per_block), dim3(256), UP_LDS, s, a);
+    hipLaunchKernelGGL(upscale_logits_kernel, dim3(2 * P * NTOK_IMG / rows_per_block), dim3(256), UP_LDS, s, a);
 }
 
 }  // namespace k
