@@ -55,6 +55,7 @@ sys.path.insert(0, str(ROOT))
 
 MFMA_F16_PEAK_TFLOPS = 2500.0      # MI355X dense f16/bf16 (MI355X_MICROARCH.md, spec)
 HBM_PEAK_GBS = 8000.0
+HBM_COPY_GBS = 6290.0               # what a float4 copy kernel reaches from HBM (MI355X_MICROARCH.md)
 
 
 def synthetic_image(seed: int, size: int = 1024) -> np.ndarray:
@@ -192,7 +193,9 @@ def main() -> None:
             "data": "synthetic",
             "config": {"workload": f"SAM {args.model} encoder + 1 point prompt, {B} image(s)/GPU/step, 1024x1024 RGBA, "
                                    "inputs and masks resident in HBM", "images_per_gpu_per_step": B, "lanes_per_gpu": ext.lane_count(env),
-                       "requests_coalesced_per_pass": int(os.environ.get("DLIMGEDIT_COALESCE", "2")),
+                       # what the library's step queue really uses (it clamps the variables and has its own defaults)
+                       "requests_coalesced_per_pass": ext.queue_config(env)["coalesce"],
+                       "passes_queued_per_lane": ext.queue_config(env)["step_depth"],
                        "weights": "seeded synthetic" if args.model_dir is None else "from --model-dir"},
             "repeats": len(repeat_s),
             "timed_total_s": float(sum(repeat_s)),
@@ -215,6 +218,14 @@ def main() -> None:
         torch.cuda.synchronize()
         t_gather = sharding.max_over_ranks(time.perf_counter() - t0, device=coll_dev)
         ok = bool(torch.equal(gathered[rank::world][:B], src))             # item i = b * world + rank
+        all_ok = sharding.max_over_ranks(0.0 if ok else 1.0, device=coll_dev) == 0.0
+        if ranks != world or not all_ok:
+            # a multi-GPU line is only printed when every rank took part in the collective and got its own masks back
+            if rank == 0:
+                print(json.dumps({"error": "multi-GPU check failed", "rccl_ranks": ranks, "expected_ranks": world,
+                                  "own_share_intact_on_every_rank": all_ok}), file=sys.stderr)
+            dist.destroy_process_group()
+            raise SystemExit(3)
         if rank == 0:
             result["rccl"] = {"rccl_ranks": ranks, "backend": "gloo (one-GPU REHEARSAL, not a result)" if args.rehearse_gloo else "nccl (RCCL)",
                               "gather": {"masks": int(gathered.shape[0]), "bytes": int(gathered.numel()), "ms": 1e3 * t_gather,
@@ -243,12 +254,33 @@ def main() -> None:
         st_lanes = profiled(2)
         st = profiled(1)
         g, gl = st["gemm"], st_lanes["gemm"]
-        achieved = gl["work"] / (gl["ms"] * 1e-3) / 1e12 if gl["ms"] > 0 else 0.0
-        achieved_alone = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        flavours = {"gemm_stats": "gemm_pp_kernel<ACT_NONE, EPI_STATS> / gemm_pp128_kernel<.., EPI_STATS>: patch, proj, fc2 "
+                                  "(bias + fp32 residual in, fp32 stream + f16 copy + row statistics out)",
+                    "gemm_norm": "gemm_pp_kernel<ACT_NONE, EPI_NORM>: qkv (LayerNorm folded in, f16 out)",
+                    "gemm_norm_gelu": "gemm_pp_kernel<ACT_GELU, EPI_NORM>: fc1 (LayerNorm folded in, GELU, f16 out)",
+                    "gemm_other": "gemm_f16_kernel: neck 1x1 / 3x3"}
+
+        def rate(s_):       # TFLOP/s of a stage record
+            return s_["work"] / (s_["ms"] * 1e-3) / 1e12 if s_["ms"] > 0 else 0.0
+
+        per_kernel = {}
+        for key, what in flavours.items():
+            a1, al = st[key], st_lanes[key]
+            if a1["launches"] == 0:
+                continue
+            per_kernel[key] = {"kernel": what, "launches_per_step": a1["launches"] / args.steps,
+                               "gflop_per_launch": a1["work"] / a1["launches"] / 1e9,
+                               "avg_launch_us": 1e3 * a1["ms"] / a1["launches"], "tflops": rate(a1),
+                               "frac": rate(a1) / MFMA_F16_PEAK_TFLOPS,
+                               "share_of_gemm_time": a1["ms"] / g["ms"] if g["ms"] > 0 else 0.0,
+                               "under_lanes_avg_launch_us": 1e3 * al["ms"] / max(1, al["launches"])}
+        dominant = max(per_kernel, key=lambda k_: per_kernel[k_]["share_of_gemm_time"]) if per_kernel else None
+        dom = per_kernel.get(dominant, {"tflops": 0.0, "frac": 0.0, "avg_launch_us": 0.0, "gflop_per_launch": 0.0, "kernel": "-"})
+        achieved_alone = rate(g)
         # HBM-side bytes per GEMM launch are NOT measured in this run: they come from separate rocprofv3 --pmc passes of
         # this command (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE), kept under profiles/
         traffic_static = None
-        for tfile in (ROOT / "profiles" / "r03_hbm_traffic_pmc.json", ROOT / "profiles" / "r02_hbm_traffic_pmc.json"):
+        for tfile in (ROOT / "profiles" / "r04_hbm_traffic_pmc.json", ROOT / "profiles" / "r03_hbm_traffic_pmc.json"):
             if tfile.exists() and args.model == "vit_b" and B == 1:
                 t = json.loads(tfile.read_text())["per_kernel"].get("gemm_pp")
                 if t:
@@ -257,27 +289,35 @@ def main() -> None:
                     break
         step_flops = B * (cfg.encoder_flops() + decoder_flops)
         chip_tflops = step_flops / (result["ms_per_step"] * 1e-3) / 1e12          # per GPU (every rank runs the same step)
+        lanes_wall_ms = result["ms_per_step"] * args.steps
         result["roofline"] = {
-            "kernel": "every MFMA GEMM launch of a step: gemm_pp_kernel / gemm_pp128_kernel (qkv, fc1, patch, proj, fc2) + "
-                      "gemm_f16_kernel (neck, decoder image side)",
-            "bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": None, "traffic_static": traffic_static,
-            "mode": "all lanes, as the timed region: a GEMM shares the chip with the other lanes' kernels while it is clocked",
-            "launches": gl["launches"], "avg_launch_us": 1e3 * gl["ms"] / max(1, gl["launches"]),
-            "concurrent_gemm_launches": gl["ms"] / (result["ms_per_step"] * args.steps),
-            "concurrency_note": "sum of the GEMM launches' durations / wall time of the profiled steps: how many GEMM kernels are "
-                                "in flight on average while one of them is being clocked (each holds a share of the CUs)",
-            "flops_per_launch": gl["work"] / max(1, gl["launches"]),
+            # the dominant kernel = the GEMM flavour with the largest share of GPU time, clocked ALONE on the chip (single
+            # lane): algorithmic FLOPs of its launches / their own dispatch-to-completion time.  This is the number a
+            # per-kernel rocprofv3 table reproduces (profiles/*_kernel_stats_single_lane_by_grid.txt).
+            "kernel": dom["kernel"], "kernel_key": dominant,
+            "bound": "mfma", "achieved": dom["tflops"], "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": dom["frac"], "traffic": None, "traffic_static": traffic_static,
+            "mode": "single lane: every request on lane 0, each kernel alone on the chip; two-image passes as in the timed region",
+            "avg_launch_us": dom["avg_launch_us"], "gflop_per_launch": dom["gflop_per_launch"],
+            "per_kernel": per_kernel,
+            "all_gemm_launches": {"achieved_single_lane": achieved_alone, "frac_single_lane": achieved_alone / MFMA_F16_PEAK_TFLOPS,
+                                  "avg_launch_us_single_lane": 1e3 * g["ms"] / max(1, g["launches"]), "launches": g["launches"]},
             "achieved_single_lane": achieved_alone, "frac_single_lane": achieved_alone / MFMA_F16_PEAK_TFLOPS,
-            "avg_launch_us_single_lane": 1e3 * g["ms"] / max(1, g["launches"]),
             "clock": "HIP events attached to each GEMM dispatch (hipExtLaunchKernelGGL) on the lane's own stream: the kernel's "
                      "own execution time",
+            # whole chip, regime of `value`: the figure the driver's clock supports
             "chip_achieved": chip_tflops, "chip_frac": chip_tflops / MFMA_F16_PEAK_TFLOPS,
             "chip_note": "per GPU: (encoder + decoder FLOPs of a step) / ms_per_step / peak -- all lanes, every kernel, gaps included",
+            # all lanes running: a launch is clocked while it SHARES the chip, so this is not a roofline fraction of anything;
+            # kept as a contention diagnostic only
+            "under_lanes": {"avg_gemm_launch_us": 1e3 * gl["ms"] / max(1, gl["launches"]),
+                            "gemm_kernels_in_flight": gl["ms"] / lanes_wall_ms if lanes_wall_ms > 0 else 0.0,
+                            "note": "sum of the GEMM launches' durations / wall time of the profiled steps = GEMM kernels in "
+                                    "flight on average; each holds a share of the CUs while it is clocked"},
         }
         stages = {}
         for name, s in st.items():
-            if s["launches"] == 0:
+            if s["launches"] == 0 or name in flavours:
                 continue
             per_step_ms = s["ms"] / args.steps
             e = {"ms_per_step": per_step_ms, "launches_per_step": s["launches"] / args.steps}
@@ -292,7 +332,8 @@ def main() -> None:
                                   "each kernel runs alone on the chip; GEMM launches are clocked by events attached to the "
                                   "dispatch, the other stages by hipEventRecord pairs around the launch (which adds a few "
                                   "microseconds per launch).  The stage times therefore do not add up to ms_per_step, "
-                                  "which overlaps the lanes.  `roofline.frac` is taken in a second repeat with all lanes.")
+                                  "which overlaps the lanes.  `roofline` is the dominant GEMM flavour of this same single-lane repeat; "
+                                  "`roofline.under_lanes` comes from a second repeat with all lanes.")
         enc_ms = sum(v["ms_per_step"] for k, v in stages.items() if k not in ("decoder", "post", "pre"))
         result["encoder"] = {"gflop_per_image": cfg.encoder_flops() / 1e9, "event_ms_per_step": enc_ms,
                              "tflops": B * cfg.encoder_flops() / (enc_ms * 1e-3) / 1e12 if enc_ms > 0 else 0.0,
@@ -312,17 +353,23 @@ def main() -> None:
                                   "note": "pre-processing + ViT encoder + neck, inputs resident in HBM, all lanes"}
 
     # ---- the two pixel kernels against the HBM rate (north_star: "HBM GB/s for the pre/post kernels"): one image per
-    # launch sits on the launch floor (`stages` above), so they are also clocked with 16 images / masks per launch
+    # launch sits on the launch floor (`stages` above), so they are also clocked with 16 images / masks per launch.
+    # Launches rotate over 768 MB of distinct inputs and outputs (3 x the 256 MB Infinity Cache): what moves is HBM traffic.
     if rank == 0 and world == 1:
         pre_b, post_b = 4 * 1024 * 1024 + 4096 * 768 * 2, 256 * 256 * 4 + 1024 * 1024      # algorithmic bytes per image / mask
-        hk = {"unit": "GB/s", "peak": HBM_PEAK_GBS, "clock": "HIP events around 50 back-to-back launches on one stream",
+        hk = {"unit": "GB/s", "peak": HBM_PEAK_GBS, "achievable": HBM_COPY_GBS,
+              "achievable_note": "float4 copy kernel, HBM to HBM (MI355X_MICROARCH.md)",
+              "working_set_mb": 768, "clock": "HIP events around 60 back-to-back launches on one stream, each on the next "
+              "set of a ring of distinct inputs and outputs (768 MB footprint, nothing Infinity-Cache resident)",
               "bytes_per_image": {"pre": pre_b, "post": post_b}}
         for n in (1, 16):
-            pre_ms, post_ms = ext.bench_prepost(n, 50)
-            hk[f"batch{n}"] = {"pre_us": 1e3 * pre_ms, "pre_gbs": n * pre_b / (pre_ms * 1e-3) / 1e9,
-                               "pre_frac": n * pre_b / (pre_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                               "post_us": 1e3 * post_ms, "post_gbs": n * post_b / (post_ms * 1e-3) / 1e9,
-                               "post_frac": n * post_b / (post_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            pre_ms, post_ms = ext.bench_prepost(n, 60, 768)
+            e = {"pre_us": 1e3 * pre_ms, "pre_gbs": n * pre_b / (pre_ms * 1e-3) / 1e9,
+                 "post_us": 1e3 * post_ms, "post_gbs": n * post_b / (post_ms * 1e-3) / 1e9}
+            for kname in ("pre", "post"):
+                e[f"{kname}_frac"] = e[f"{kname}_gbs"] / HBM_PEAK_GBS
+                e[f"{kname}_frac_of_achievable"] = e[f"{kname}_gbs"] / HBM_COPY_GBS
+            hk[f"batch{n}"] = e
         result["hbm_kernels"] = hk
 
     # ---- the drop-in ABI itself: host buffers in and out (PCIe inclusive), rank 0, N = 1 only

@@ -353,7 +353,8 @@ def segment_objects(img: ImageView, env: Environment) -> np.ndarray:
 # ---------------------------------------------------------------------------------------------
 # extension entry points (include/dlimgedit/dlimgedit_amd.h)
 
-STAGES = ("pre", "gemm", "layernorm", "attention_window", "attention_global", "encoder_other", "decoder", "post")
+STAGES = ("pre", "gemm", "layernorm", "attention_window", "attention_global", "encoder_other", "decoder", "post",
+          "gemm_stats", "gemm_norm", "gemm_norm_gelu", "gemm_other")
 
 
 class ext:
@@ -381,6 +382,7 @@ class ext:
                 "dlimg_amd_encode_only": ([vp, C.POINTER(_ImageView), ci], ci),
                 "dlimg_amd_synchronize": ([vp], ci),
                 "dlimg_amd_lane_count": ([vp], ci),
+                "dlimg_amd_queue_config": ([vp, C.POINTER(ci)], ci),
                 "dlimg_amd_replica_count": ([vp], ci),
                 "dlimg_amd_segmentation_device": ([vp, C.POINTER(ci), C.POINTER(ci)], ci),
                 "dlimg_amd_get_segmentation_masks_device": ([C.POINTER(vp), ci, C.POINTER(ci), C.POINTER(ci), ci, vp,
@@ -389,6 +391,7 @@ class ext:
                 "dlimg_amd_take_stage_stats": ([vp, vp, vp, vp], ci),
                 "dlimg_amd_test_preprocess": ([vp, ci, ci, ci, ci, vp], ci),
                 "dlimg_amd_test_postprocess": ([vp, ci, vp, ci, ci, vp], ci),
+                "dlimg_amd_test_force_gemm_tile": ([ci], ci),
                 "dlimg_amd_test_gemm": ([ci, ci, ci, vp, vp, vp, vp, ci, ci, vp, vp], ci),
                 "dlimg_amd_test_gemm_ln": ([ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, cf, ci, vp, vp, vp], ci),
                 "dlimg_amd_test_layernorm": ([vp, vp, vp, cf, ci, ci, ci, vp, vp], ci),
@@ -398,7 +401,7 @@ class ext:
                 "dlimg_amd_birefnet_process_mask": ([vp, ci, ci, vp], ci),
                 "dlimg_amd_resize_mask": ([vp, ci, ci, ci, ci, ci, vp], ci),
                 "dlimg_amd_bench_attention": ([ci, ci, ci, ci, ci, C.POINTER(C.c_double)], ci),
-                "dlimg_amd_bench_prepost": ([ci, ci, C.POINTER(C.c_double), C.POINTER(C.c_double)], ci),
+                "dlimg_amd_bench_prepost": ([ci, ci, ci, C.POINTER(C.c_double), C.POINTER(C.c_double)], ci),
                 "dlimg_amd_bench_gemm": ([ci, ci, ci, ci, ci, ci, C.POINTER(C.c_double)], ci),
                 "dlimg_amd_bench_gemm_streams": ([ci, ci, ci, ci, ci, ci, ci, ci, ci, C.POINTER(C.c_double)], ci),
                 "dlimg_amd_bench_gemm_stamps": ([ci, ci, ci, ci, ci, ci, ci, ci, ci, C.POINTER(C.c_double), vp, ci], ci),
@@ -412,10 +415,10 @@ class ext:
     EXPORTS = ("dlimg_amd_device_count", "dlimg_amd_model_geometry", "dlimg_amd_get_embedding", "dlimg_amd_get_logits",
                "dlimg_amd_decoder_state", "dlimg_amd_test_plan_steps", "dlimg_amd_test_mask_pieces", "dlimg_amd_device_alloc", "dlimg_amd_device_free", "dlimg_amd_copy_to_device", "dlimg_amd_copy_to_host",
                "dlimg_amd_encode_and_mask", "dlimg_amd_encode_only", "dlimg_amd_synchronize", "dlimg_amd_lane_count",
-               "dlimg_amd_replica_count", "dlimg_amd_segmentation_device", "dlimg_amd_get_segmentation_masks_device",
+               "dlimg_amd_queue_config", "dlimg_amd_replica_count", "dlimg_amd_segmentation_device", "dlimg_amd_get_segmentation_masks_device",
                "dlimg_amd_set_profiling",
                "dlimg_amd_take_stage_stats", "dlimg_amd_test_preprocess", "dlimg_amd_test_postprocess",
-               "dlimg_amd_test_gemm", "dlimg_amd_test_gemm_ln", "dlimg_amd_test_layernorm", "dlimg_amd_test_attention", "dlimg_amd_test_resize",
+               "dlimg_amd_test_force_gemm_tile", "dlimg_amd_test_gemm", "dlimg_amd_test_gemm_ln", "dlimg_amd_test_layernorm", "dlimg_amd_test_attention", "dlimg_amd_test_resize",
                "dlimg_amd_birefnet_prepare_image", "dlimg_amd_birefnet_process_mask", "dlimg_amd_resize_mask",
                "dlimg_amd_bench_attention", "dlimg_amd_bench_prepost", "dlimg_amd_bench_gemm", "dlimg_amd_bench_gemm_streams", "dlimg_amd_bench_gemm_stamps")
 
@@ -538,6 +541,13 @@ class ext:
         return cls._l().dlimg_amd_lane_count(env.handle())
 
     @classmethod
+    def queue_config(cls, env) -> dict:
+        """Effective settings of the step queue behind encode_and_mask, as the library clamped them."""
+        out = (C.c_int * 4)()
+        _check(cls._l().dlimg_amd_queue_config(env.handle(), out))
+        return {"coalesce": out[0], "step_depth": out[1], "lanes": out[2], "lanes_in_use": out[3]}
+
+    @classmethod
     def replica_count(cls, env) -> int:
         return cls._l().dlimg_amd_replica_count(env.handle())
 
@@ -594,6 +604,11 @@ class ext:
         _check(cls._l().dlimg_amd_test_postprocess(planes.ctypes.data, planes.shape[0], cls._ptr(iou), out_w, out_h,
                                                    out.ctypes.data))
         return out
+
+    @classmethod
+    def force_gemm_tile(cls, tile: int = -1) -> None:
+        """Tile configuration the GEMM test hooks use wherever it fits (-1: the product's own choice)."""
+        _check(cls._l().dlimg_amd_test_force_gemm_tile(int(tile)))
 
     @classmethod
     def test_gemm(cls, A: np.ndarray, W: np.ndarray, bias=None, resid=None, act: int = 0, want_f16: bool = False):
@@ -698,10 +713,11 @@ class ext:
         return out
 
     @classmethod
-    def bench_prepost(cls, batch: int = 16, iters: int = 50) -> Tuple[float, float]:
-        """(ms per launch of the pre-processing kernel, of the post-processing kernel) on `batch` images / masks."""
+    def bench_prepost(cls, batch: int = 16, iters: int = 50, working_set_mb: int = 768) -> Tuple[float, float]:
+        """(ms per launch of the pre-processing kernel, of the post-processing kernel) on `batch` images / masks; launches
+        rotate over `working_set_mb` MB of distinct inputs and outputs (nothing Infinity-Cache resident)."""
         pre, post = C.c_double(), C.c_double()
-        _check(cls._l().dlimg_amd_bench_prepost(batch, iters, C.byref(pre), C.byref(post)))
+        _check(cls._l().dlimg_amd_bench_prepost(batch, iters, working_set_mb, C.byref(pre), C.byref(post)))
         return pre.value, post.value
 
     @classmethod

@@ -26,6 +26,7 @@ LIB = PKG / "lib" / "libdlimgedit.so"
 LIB_TUNING = PKG / "lib" / "libdlimgedit_tuning.so"
 ARCH = "gfx950"
 SONAME = "libdlimgedit.so.1"
+EXPORTS_MAP = CSRC / "exports.map"
 
 SOURCES = [
     "kernels/gemm.hip",
@@ -96,6 +97,52 @@ def _compile(src: str, force: bool, hdr_mtime: float, tuning: bool = False) -> P
     return o
 
 
+LLVM_OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+# the toolchain the -fno-slp-vectorize workaround was validated with; another compiler may pair
+# fp32 operations by a different route, which is what check_token_kernel_isa() is there to catch
+VALIDATED_HIPCC = "HIP 7.2.26015 / AMD clang 22.0.0git roc-7.2.0 (7b800a19)"
+
+
+def disassemble_device_code(obj: Path) -> str:
+    """gfx950 ISA of the device code bundled in a host object (llvm-objdump --offloading extracts next to the input,
+    so it works on a copy in a scratch directory)."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        tmp = Path(d) / obj.name
+        shutil.copy(obj, tmp)
+        subprocess.run([LLVM_OBJDUMP, "--offloading", str(tmp)], capture_output=True, text=True, check=True)
+        code = [f for f in Path(d).iterdir() if f.name.startswith(obj.name + ".") and "amdgcn" in f.name]
+        if not code:
+            raise RuntimeError(f"no gfx950 code object found in {obj}")
+        return subprocess.run([LLVM_OBJDUMP, "-d", str(code[0])], capture_output=True, text=True, check=True).stdout
+
+
+def check_token_kernel_isa(obj: Path) -> dict:
+    """Build-time guard of the decoder's fp32 token kernels (kernels/decoder.hip).  Round 3 met a silent wrong element
+    (about 1 in 10^4 decodes, only under concurrent lanes) in code where the SLP vectoriser had paired the rows of the
+    token linears into chains of `v_pk_fma_f32` with op_sel / op_sel_hi modifiers fed by v_mov_b32 shuffles; the source
+    is now built with -fno-slp-vectorize and keeps a loop shape that offers nothing to pair.  A flag or compiler change
+    that brings the pattern back must fail the BUILD, not a stress test that catches it with some probability: no kernel
+    of decoder.hip may contain a v_pk_fma_f32 with a source-select modifier (packed fp32 from vector types in the source
+    -- aligned register pairs, no op_sel on the FMA -- is fine and expected).  Returns {kernel: packed FMA count}."""
+    import re
+    counts, bad, name = {}, [], None
+    for line in disassemble_device_code(obj).splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+        if m:
+            name = m.group(1)
+            continue
+        if name and "v_pk_fma_f32" in line:
+            counts[name] = counts.get(name, 0) + 1
+            if "op_sel" in line:
+                bad.append((name, line.strip().split("//")[0].strip()))
+    if bad:
+        listing = "\n".join(f"  {n}: {i}" for n, i in bad[:8])
+        raise RuntimeError("decoder.hip: v_pk_fma_f32 with op_sel modifiers in the token kernels (the pattern behind the wrong "
+                           f"element of DESIGN.md section 6; validated toolchain: {VALIDATED_HIPCC}):\n{listing}")
+    return counts
+
+
 def build(force: bool = False, verbose: bool = False, tuning: bool = False) -> Path:
     (OBJ_TUNING if tuning else OBJ).mkdir(parents=True, exist_ok=True)
     LIB.parent.mkdir(parents=True, exist_ok=True)
@@ -106,7 +153,7 @@ def build(force: bool = False, verbose: bool = False, tuning: bool = False) -> P
     if tuning:
         if force or not LIB_TUNING.exists() or LIB_TUNING.stat().st_mtime < max(o.stat().st_mtime for o in objs):
             cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB_TUNING), *map(str, objs),
-                   "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined", "-ldl", "-lz"]
+                   "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined", f"-Wl,--version-script={EXPORTS_MAP}", "-ldl", "-lz"]
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
@@ -114,8 +161,10 @@ def build(force: bool = False, verbose: bool = False, tuning: bool = False) -> P
             print(f"built {LIB_TUNING} ({LIB_TUNING.stat().st_size / 1e6:.1f} MB)")
         return LIB_TUNING
     if force or not LIB.exists() or LIB.stat().st_mtime < max(o.stat().st_mtime for o in objs):
+        check_token_kernel_isa(OBJ / "kernels_decoder.hip.o")      # before anything is linked: a refused build leaves no library
         cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs),
-               "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined", f"-Wl,-soname,{SONAME}", "-ldl", "-lz"]
+               "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined", f"-Wl,-soname,{SONAME}",
+               f"-Wl,--version-script={EXPORTS_MAP}", "-ldl", "-lz"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

@@ -30,6 +30,10 @@ class Exception : public std::exception {
 [[noreturn]] void assertion_failed(const char* file, int line, const char* expr);
 [[noreturn]] void hip_failed(const char* file, int line, const char* expr, hipError_t err);
 
+// Did the HIP runtime read a GPU_MAX_HW_QUEUES of at least 8 (environment.cpp: set by the host, or by this library's load-time
+// constructor while the runtime was demonstrably not yet initialised)?  Decides the lanes' stream layout (sam_model.cpp).
+bool hardware_queues_trusted();
+
 #define DLIMG_ASSERT(cond)                                           \
     do {                                                             \
         if (!(cond)) ::dlimg::assertion_failed(__FILE__, __LINE__, #cond); \

@@ -2,6 +2,8 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <filesystem>
+#include <system_error>
 
 namespace dlimg {
 
@@ -9,14 +11,47 @@ namespace {
 // The HIP runtime gives a process four hardware queues by default and multiplexes every stream onto them; the execution
 // lanes (four per GPU) want a queue each, beside the host's own streams.  The runtime reads GPU_MAX_HW_QUEUES when IT
 // initialises (its first API call), so the one place a library can still ask is its own load: if the host has not chosen,
-// ask for eight.  A host that initialised HIP before loading this library keeps what it had -- the lanes then share the
-// default queues through streams of three priority levels (sam_model.cpp), as before.  DLIMGEDIT_KEEP_HW_QUEUES=1: hands off.
-const bool g_asked_for_queues = [] {
+// ask for eight.  What the library must NOT do is believe its own request: if the host touched HIP before loading this
+// library (torch, any HIP host) the runtime has already read the default, and the variable now says 8 while the process has
+// 4 queues.  So the load-time constructor records WHO set the variable and whether the HIP runtime had demonstrably not
+// been initialised at that moment (it opens /dev/kfd when it initialises; no descriptor of this process pointing there =
+// not initialised).  sam_model.cpp picks its stream layout from hardware_queues_trusted().
+// Side effects on the host process: one setenv at load time -- inherited by child processes,
+// and, like every setenv, not safe against a concurrent getenv in another thread of a host that loads the library late.
+// DLIMGEDIT_KEEP_HW_QUEUES=1: hands off, nothing is written.
+bool kfd_is_open() {
+    std::error_code ec;
+    for (auto const& e : std::filesystem::directory_iterator("/proc/self/fd", ec)) {
+        std::error_code ec2;
+        const auto target = std::filesystem::read_symlink(e.path(), ec2);
+        if (!ec2 && target == "/dev/kfd") return true;
+    }
+    return false;
+}
+
+enum class QueueRequest { host_chose, library_asked_in_time, library_asked_too_late, hands_off };
+const QueueRequest g_queue_request = [] {
     const char* keep = std::getenv("DLIMGEDIT_KEEP_HW_QUEUES");
-    if (keep && std::atoi(keep) != 0) return false;
-    return setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0) == 0;
+    if (keep && std::atoi(keep) != 0) return QueueRequest::hands_off;
+    if (std::getenv("GPU_MAX_HW_QUEUES")) return QueueRequest::host_chose;
+    const bool hip_up = kfd_is_open();
+    if (setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0) != 0) return QueueRequest::hands_off;
+    return hip_up ? QueueRequest::library_asked_too_late : QueueRequest::library_asked_in_time;
 }();
 }  // namespace
+
+bool hardware_queues_trusted() {
+    switch (g_queue_request) {
+    case QueueRequest::library_asked_in_time: return true;      // the runtime will read the 8 this library wrote
+    case QueueRequest::library_asked_too_late: return false;    // the variable says 8, the runtime read its default
+    case QueueRequest::host_chose:
+    case QueueRequest::hands_off: {
+        const char* q = std::getenv("GPU_MAX_HW_QUEUES");       // the host's own number (it knows when it set it)
+        return q && std::atoi(q) >= 8;
+    }
+    }
+    return false;
+}
 
 void throw_error(const char* msg) { throw Exception(msg); }
 
@@ -115,6 +150,12 @@ EnvironmentImpl::EnvironmentImpl(dlimg_Options const& options) : backend(options
 }
 
 EnvironmentImpl::~EnvironmentImpl() {
+    // Requests accepted by dlimg_amd_encode_and_mask but never launched (a request still waiting for its coalescing
+    // partner): the caller destroyed the environment without dlimg_amd_synchronize.  Their masks will not be written;
+    // say so instead of dropping them silently (a destructor cannot return an error).
+    if (!pending.empty())
+        std::fprintf(stderr, "dlimgedit: environment destroyed with %zu queued request(s) that were never launched "
+                             "(call dlimg_amd_synchronize first)\n", pending.size());
     for (auto& lane : step_passes)
         for (auto& pass : lane) (void)hipEventDestroy(pass.done);
 }

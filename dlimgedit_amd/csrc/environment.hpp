@@ -98,6 +98,8 @@ class EnvironmentImpl {
     int coalesce = 2;
     int step_depth = 2;
     int step_cursor = 0;                               // lane after the one used last (pending_mutex)
+    std::string step_error;                            // first failure of a queued pass since the last synchronize (sticky)
+    int dropped_steps = 0;                             // requests that failure took with it (pending_mutex)
 
   private:
     struct SamLanes {

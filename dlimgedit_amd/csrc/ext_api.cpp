@@ -8,6 +8,7 @@
 
 #include <dlimgedit/dlimgedit_amd.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -55,12 +56,13 @@ template <typename T> void download(T* host, T const* dev, size_t n) {
     if (host && n) HIP_CHECK(hipMemcpy(host, dev, n * sizeof(T), hipMemcpyDeviceToHost));
 }
 
-// Tuning / test aid (never read by the product path): DLIMGEDIT_GEMM_TILE forces a tile configuration of kernels/gemm.hip
-// in the single-kernel hooks below wherever it fits the problem.
+// Test aid (never read by the product path): dlimg_amd_test_force_gemm_tile() forces a tile configuration of
+// kernels/gemm.hip in the single-kernel hooks below wherever it fits the problem.  An explicit call, not an environment
+// variable: nothing outside the test hooks can steer the product's tile choice.
+std::atomic<int> g_forced_test_tile{-1};
 void apply_forced_tile(k::GemmArgs& g) {
-    const char* e = std::getenv("DLIMGEDIT_GEMM_TILE");
-    if (!e || g.tile >= 0) return;
-    const int t = std::atoi(e);
+    const int t = g_forced_test_tile.load(std::memory_order_relaxed);
+    if (t < 0 || g.tile >= 0) return;
     if (k::gemm_tile_fits(g, t)) g.tile = t;
 }
 
@@ -271,14 +273,26 @@ void flush_device_steps(EnvironmentImpl& env, bool all) {
     queue_state(env, lanes, st);
     const std::vector<StepPlanPass> plan = plan_device_steps(st, (int)env.pending.size(), env.coalesce, env.step_depth, all);
     env.step_cursor = st.cursor;
+    // A pass that fails to enqueue takes only ITS OWN requests with it: the passes launched before it stay launched, the
+    // requests behind it stay queued for the next call, and the failure is kept as a sticky error that the next
+    // dlimg_amd_synchronize returns -- the callers whose requests were dropped got a success code when they queued them
+    // (possibly on other threads), synchronize is where they learn that a mask will not arrive.
     size_t done = 0;
     try {
         for (StepPlanPass const& pass : plan) {
             run_device_steps(env, pass.lane, env.pending.data() + done, pass.images);
             done += (size_t)pass.images;
         }
-    } catch (...) {
-        env.pending.clear();         // a failed pass must not be retried by the next call
+    } catch (std::exception const& ex) {
+        size_t lost = 0;
+        size_t at = 0;
+        for (StepPlanPass const& pass : plan) {          // the pass that threw is the first one not counted in `done`
+            if (at == done) { lost = (size_t)pass.images; break; }
+            at += (size_t)pass.images;
+        }
+        env.pending.erase(env.pending.begin(), env.pending.begin() + std::min(env.pending.size(), done + lost));
+        env.dropped_steps += (int)lost;
+        if (env.step_error.empty()) env.step_error = ex.what();
         throw;
     }
     env.pending.erase(env.pending.begin(), env.pending.begin() + done);
@@ -400,13 +414,38 @@ DLIMG_API int dlimg_amd_get_segmentation_masks_device(dlimg_Segmentation const* 
 DLIMG_API int dlimg_amd_synchronize(dlimg_Environment env) {
     return guarded([&] {
         EnvironmentImpl& e = impl(env);
+        std::string flush_error;
         {
             std::lock_guard<std::mutex> lock(e.pending_mutex);
-            flush_device_steps(e, true);
+            // keep dealing out what is queued even if one pass fails: every request either runs or is counted as dropped
+            for (int guard = 0; !e.pending.empty() && guard < 1024; ++guard) {
+                try {
+                    flush_device_steps(e, true);
+                } catch (std::exception const&) {
+                }                                   // recorded in e.step_error by flush_device_steps
+            }
         }
         for_each_lane(e, [](SamModel& m) { m.synchronize(); });
         std::lock_guard<std::mutex> lock(e.pending_mutex);
         retire_device_steps(e);
+        if (!e.step_error.empty()) {
+            const std::string msg = "dlimg_amd_encode_and_mask: " + std::to_string(e.dropped_steps) +
+                                    " queued request(s) were dropped because their pass failed: " + e.step_error;
+            e.step_error.clear();
+            e.dropped_steps = 0;
+            throw Exception(msg);
+        }
+    });
+}
+
+DLIMG_API int dlimg_amd_queue_config(dlimg_Environment env, int* out) {
+    return guarded([&] {
+        DLIMG_ASSERT(out != nullptr);
+        EnvironmentImpl& e = impl(env);
+        out[0] = e.coalesce;
+        out[1] = e.step_depth;
+        out[2] = e.lane_count(0);
+        out[3] = std::max(1, e.effective_lane_count(0));
     });
 }
 
@@ -496,6 +535,11 @@ DLIMG_API int dlimg_amd_test_postprocess(float const* planes, int n_planes, floa
         HIP_CHECK(hipDeviceSynchronize());
         download(out_mask, dst.get(), (size_t)out_w * out_h);
     });
+}
+
+DLIMG_API int dlimg_amd_test_force_gemm_tile(int tile) {
+    g_forced_test_tile.store(tile < 0 ? -1 : tile, std::memory_order_relaxed);
+    return 0;
 }
 
 DLIMG_API int dlimg_amd_test_gemm(int M, int N, int K, uint16_t const* A, uint16_t const* W, float const* bias,
@@ -687,50 +731,68 @@ DLIMG_API int dlimg_amd_resize_mask(uint8_t const* mask, int width, int height, 
     });
 }
 
-DLIMG_API int dlimg_amd_bench_prepost(int batch, int iters, double* out_pre_ms, double* out_post_ms) {
+DLIMG_API int dlimg_amd_bench_prepost(int batch, int iters, int working_set_mb, double* out_pre_ms, double* out_post_ms) {
     return guarded([&] {
         require_gpu();
-        DLIMG_ASSERT(batch > 0 && batch <= 16 && iters > 0 && out_pre_ms && out_post_ms);
-        const size_t img_bytes = (size_t)kImageSize * kImageSize * 4;
+        DLIMG_ASSERT(batch > 0 && batch <= 16 && iters > 0 && working_set_mb >= 0 && working_set_mb <= 8192 && out_pre_ms && out_post_ms);
+        // Successive launches rotate over a ring of DISTINCT input and output sets whose footprint is `working_set_mb`
+        // (default 768 MB, three times the 256 MB Infinity Cache): by the time a set comes round again nothing of it is
+        // cache-resident, so bytes / time is an HBM rate.  [Re-running one 160 MiB set back to back, as this hook did
+        // before, measures the Infinity Cache: 6.35 TB/s "HBM" where a float4 copy from HBM reaches 6.29.]
+        const size_t want = (size_t)(working_set_mb > 0 ? working_set_mb : 768) << 20;
+        const size_t img_bytes = (size_t)kImageSize * kImageSize * 4, patch_elems = (size_t)kTokens * kPatchK;
+        const size_t mask_bytes = (size_t)kImageSize * kImageSize, logit_elems = (size_t)4 * kLowRes * kLowRes;
+        const size_t pre_set = batch * (img_bytes + patch_elems * 2), post_set = batch * (logit_elems * 4 + mask_bytes);
+        const int pre_sets = (int)std::max<size_t>(1, (want + pre_set - 1) / pre_set);
+        const int post_sets = (int)std::max<size_t>(1, (want + post_set - 1) / post_set);
         std::vector<uint8_t> himg(img_bytes);
         uint32_t seed = 99u;
         for (auto& v : himg) { seed = seed * 1664525u + 1013904223u; v = (uint8_t)(seed >> 24); }
-        std::vector<float> hlog((size_t)4 * kLowRes * kLowRes);
+        std::vector<float> hlog(logit_elems);
         for (auto& v : hlog) { seed = seed * 1664525u + 1013904223u; v = ((seed >> 8) & 0xffff) / 32768.0f - 1.0f; }
         std::vector<float> hiou = {0.1f, 0.7f, 0.5f, 0.3f};
-        DeviceBuffer<uint8_t> imgs(batch * img_bytes), masks((size_t)batch * kImageSize * kImageSize);
-        DeviceBuffer<half_t> patches((size_t)batch * kTokens * kPatchK);
-        DeviceBuffer<float> logits((size_t)batch * 4 * kLowRes * kLowRes), iou((size_t)batch * 4);
-        for (int i = 0; i < batch; ++i) {
-            HIP_CHECK(hipMemcpy(imgs.get() + i * img_bytes, himg.data(), img_bytes, hipMemcpyHostToDevice));
-            HIP_CHECK(hipMemcpy(logits.get() + (size_t)i * hlog.size(), hlog.data(), hlog.size() * 4, hipMemcpyHostToDevice));
-            HIP_CHECK(hipMemcpy(iou.get() + (size_t)i * 4, hiou.data(), 16, hipMemcpyHostToDevice));
+        DeviceBuffer<uint8_t> imgs((size_t)pre_sets * batch * img_bytes), masks((size_t)post_sets * batch * mask_bytes);
+        DeviceBuffer<half_t> patches((size_t)pre_sets * batch * patch_elems);
+        DeviceBuffer<float> logits((size_t)post_sets * batch * logit_elems), iou((size_t)post_sets * batch * 4);
+        HIP_CHECK(hipMemcpy(imgs.get(), himg.data(), img_bytes, hipMemcpyHostToDevice));
+        for (size_t i = 1; i < (size_t)pre_sets * batch; ++i)
+            HIP_CHECK(hipMemcpy(imgs.get() + i * img_bytes, imgs.get(), img_bytes, hipMemcpyDeviceToDevice));
+        HIP_CHECK(hipMemcpy(logits.get(), hlog.data(), logit_elems * 4, hipMemcpyHostToDevice));
+        for (size_t i = 0; i < (size_t)post_sets * batch; ++i) {
+            if (i) HIP_CHECK(hipMemcpy(logits.get() + i * logit_elems, logits.get(), logit_elems * 4, hipMemcpyDeviceToDevice));
+            HIP_CHECK(hipMemcpy(iou.get() + i * 4, hiou.data(), 16, hipMemcpyHostToDevice));
         }
-        std::vector<k::PreImage> pre(batch);
-        std::vector<k::PostJob> post(batch);
-        for (int i = 0; i < batch; ++i) {
-            pre[i] = k::PreImage{imgs.get() + i * img_bytes, kImageSize, kImageSize, kImageSize * 4, 4,
-                                 patches.get() + (size_t)i * kTokens * kPatchK};
-            post[i] = k::PostJob{logits.get() + (size_t)i * 4 * kLowRes * kLowRes, iou.get() + (size_t)i * 4,
-                                 masks.get() + (size_t)i * kImageSize * kImageSize, kImageSize, kImageSize, kImageSize, kImageSize};
-        }
+        std::vector<std::vector<k::PreImage>> pre(pre_sets, std::vector<k::PreImage>(batch));
+        std::vector<std::vector<k::PostJob>> post(post_sets, std::vector<k::PostJob>(batch));
+        for (int sidx = 0; sidx < pre_sets; ++sidx)
+            for (int i = 0; i < batch; ++i) {
+                const size_t n = (size_t)sidx * batch + i;
+                pre[sidx][i] = k::PreImage{imgs.get() + n * img_bytes, kImageSize, kImageSize, kImageSize * 4, 4, patches.get() + n * patch_elems};
+            }
+        for (int sidx = 0; sidx < post_sets; ++sidx)
+            for (int i = 0; i < batch; ++i) {
+                const size_t n = (size_t)sidx * batch + i;
+                post[sidx][i] = k::PostJob{logits.get() + n * logit_elems, iou.get() + n * 4, masks.get() + n * mask_bytes,
+                                           kImageSize, kImageSize, kImageSize, kImageSize};
+            }
         hipStream_t st;
         HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         hipEvent_t e0, e1;
         HIP_CHECK(hipEventCreate(&e0));
         HIP_CHECK(hipEventCreate(&e1));
-        auto time = [&](auto&& launch) {
-            for (int i = 0; i < 3; ++i) launch();
+        auto time = [&](auto&& launch, int sets) {
+            int at = 0;
+            for (int i = 0; i < std::max(3, sets); ++i) launch(at++ % sets);      // one whole turn of the ring: everything touched once
             HIP_CHECK(hipEventRecord(e0, st));
-            for (int i = 0; i < iters; ++i) launch();
+            for (int i = 0; i < iters; ++i) launch(at++ % sets);
             HIP_CHECK(hipEventRecord(e1, st));
             HIP_CHECK(hipStreamSynchronize(st));
             float ms = 0.f;
             HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
             return (double)ms / iters;
         };
-        *out_pre_ms = time([&] { k::preprocess_batch(pre.data(), batch, st); });
-        *out_post_ms = time([&] { k::postprocess_masks(post.data(), batch, st); });
+        *out_pre_ms = time([&](int sidx) { k::preprocess_batch(pre[sidx].data(), batch, st); }, pre_sets);
+        *out_post_ms = time([&](int sidx) { k::postprocess_masks(post[sidx].data(), batch, st); }, post_sets);
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
         (void)hipStreamDestroy(st);

@@ -756,7 +756,11 @@ void launch_global(const half_t* qkv, const half_t* rel_h, const half_t* rel_w, 
     const size_t scratch = 4 * 32 * GW_STRIDE * 4;
     const size_t lds = 4 * 64 * RELH_STRIDE * 4 + (tiles > scratch ? tiles : scratch);
     const size_t pp_lds = 8 * 64 * RELH_STRIDE * 4 + tiles;
+#ifndef DLIMG_TUNING
+    constexpr bool pingpong = true;
+#else
     static const bool pingpong = [] { const char* e = std::getenv("DLIMGEDIT_ATTN_PP"); return !e || std::atoi(e) != 0; }();
+#endif
 #ifdef DLIMG_TUNING     // tuning build only (python -m dlimgedit_amd.build --tuning): ablated variants with WRONG results
     static const int ablate = [] { const char* e = std::getenv("DLIMGEDIT_ATTN_ABLATE"); return e ? std::atoi(e) : 0; }();
     static const int pp_abl = [] { const char* e = std::getenv("DLIMGEDIT_ATTN_PP_ABLATE"); return e ? std::atoi(e) : 0; }();

@@ -869,8 +869,7 @@ void token_self_attention_out(const float* q, const float* kx, const float* v, c
     if (P <= 0) return;
     if (P * TOK > TL_MAX_ROWS || out.K != DIM || out.N % 4) throw_error("token_self_attention_out: unsupported shape");
     const size_t lds = (size_t)TL_PROMPT_SLICE * TOK * (DIM * 4 + 8);
-    static k::LdsOptIn opt_in;
-    opt_in.ensure((const void*)token_self_attn_out_kernel, 160 * 1024, "token_self_attention_out: the device refuses the kernel's LDS size");
+    static_assert((size_t)TL_PROMPT_SLICE * TOK * (DIM * 4 + 8) <= 64 * 1024, "below the default dynamic-LDS limit: no opt-in needed");
     hipLaunchKernelGGL(token_self_attn_out_kernel, dim3(out.N / 4, (P + TL_PROMPT_SLICE - 1) / TL_PROMPT_SLICE), dim3(256), lds, s, q, kx,
                        v, out, P);
 }

@@ -1171,10 +1171,14 @@ int gemm_pick_tile(const GemmArgs& a) {
     // batch-equals-single tests assert it.
     // (only where a single unit would run tile 10: the other tiles use a different MFMA shape, i.e. another summation order)
     // too few 256 x 256 tiles (ViT-B proj / fc2: 48): the 128 x 256 ping-pong kernel doubles them
+#ifdef DLIMG_TUNING     // A/B switches of the tuning build only; the product's choice is not steerable from outside
     static const bool use_pp128 = [] { const char* e = std::getenv("DLIMGEDIT_GEMM_PP128"); return !e || std::atoi(e) != 0; }();
+    static const bool batch_pp = [] { const char* e = std::getenv("DLIMGEDIT_GEMM_BATCH_PP"); return !e || std::atoi(e) != 0; }();
+#else
+    constexpr bool use_pp128 = true, batch_pp = true;
+#endif
     if (use_pp128 && shared && forced < 0 && unit % 128 == 0 && a.N % 256 == 0 && (unit / 128) * (a.N / 256) >= 64 &&
         !wraps_inside(128)) {
-        static const bool batch_pp = [] { const char* e = std::getenv("DLIMGEDIT_GEMM_BATCH_PP"); return !e || std::atoi(e) != 0; }();
         if (batch_pp && a.M % 256 == 0 && (a.M / 256) * (a.N / 256) >= 96 && !wraps_inside(256)) return 9;
         return 10;
     }

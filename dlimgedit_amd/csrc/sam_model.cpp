@@ -277,13 +277,13 @@ SamModel::SamModel(std::shared_ptr<SamWeights const> weights, int lane_index, in
         // favoured for long because requests are dealt round-robin).  With eight queues plain streams are better: the
         // priority levels make four host threads wait on each other's lanes (ABI, config 2 from four threads: 479 against
         // 569-596 images/s; one prompt per call from four threads: 4900 against 5500 masks/s).  The library asks for eight
-        // queues when it is loaded (environment.cpp), so plain streams are the default whenever GPU_MAX_HW_QUEUES says
-        // >= 8; a host that initialised HIP with fewer queues BEFORE loading the library says so with
-        // DLIMGEDIT_PLAIN_STREAMS=0 (the library cannot see what the runtime really read).
+        // queues when it is loaded (environment.cpp) and remembers whether the runtime can have seen that request: plain
+        // streams are the default only when it can (hardware_queues_trusted(): the host set >= 8 itself, or the library set
+        // it before the runtime initialised); a host that initialised HIP first keeps the three-priority layout.
+        // DLIMGEDIT_PLAIN_STREAMS=0/1 overrides the detection.
         static const bool plain = [] {
             if (const char* e = std::getenv("DLIMGEDIT_PLAIN_STREAMS")) return std::atoi(e) != 0;
-            const char* q = std::getenv("GPU_MAX_HW_QUEUES");
-            return q && std::atoi(q) >= 8;
+            return hardware_queues_trusted();
         }();
         if (plain) {
             HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
@@ -331,6 +331,11 @@ void SamModel::flush_events() {
         stats_.ms[p.st] += ms;
         stats_.work[p.st] += p.work;
         stats_.launches[p.st] += 1;
+        if (p.also != ST_COUNT) {
+            stats_.ms[p.also] += ms;
+            stats_.work[p.also] += p.work;
+            stats_.launches[p.also] += 1;
+        }
         event_pool_.push_back(p.a);
         event_pool_.push_back(p.b);
     }
@@ -377,7 +382,8 @@ void SamModel::gemm(k::GemmArgs const& args) {
         return;
     }
     // the clock of a GEMM launch is the kernel's own dispatch-to-completion time (events attached to the dispatch)
-    Pending p{take_event(), take_event(), ST_GEMM, 2.0 * a.M * a.N * a.K};
+    const Stage flavour = a.stats_out ? ST_GEMM_STATS : a.ln_stats ? (a.act == k::ACT_GELU ? ST_GEMM_NORM_GELU : ST_GEMM_NORM) : ST_GEMM_OTHER;
+    Pending p{take_event(), take_event(), ST_GEMM, 2.0 * a.M * a.N * a.K, flavour};
     k::gemm(a, stream_, p.a, p.b);
     pending_.push_back(p);
     if (pending_.size() > 8192) flush_events();

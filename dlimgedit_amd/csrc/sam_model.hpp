@@ -97,7 +97,11 @@ struct SamWeights {
 };
 
 // Stage clock for roofline accounting (HIP events on the executor's own stream).
-enum Stage { ST_PRE = 0, ST_GEMM, ST_LAYERNORM, ST_ATTN_WINDOW, ST_ATTN_GLOBAL, ST_ENC_OTHER, ST_DECODER, ST_POST, ST_COUNT };
+// ST_GEMM is the sum over all GEMM launches of the encoder; ST_GEMM_* split the same launches by kernel flavour (what
+// the by-grid table of a kernel trace tells apart): residual-stream writers with row statistics (patch / proj / fc2),
+// LayerNorm-folded consumers without / with GELU (qkv / fc1), everything else (neck).
+enum Stage { ST_PRE = 0, ST_GEMM, ST_LAYERNORM, ST_ATTN_WINDOW, ST_ATTN_GLOBAL, ST_ENC_OTHER, ST_DECODER, ST_POST,
+             ST_GEMM_STATS, ST_GEMM_NORM, ST_GEMM_NORM_GELU, ST_GEMM_OTHER, ST_COUNT };
 
 struct StageStats {
     double ms[ST_COUNT] = {0};
@@ -245,7 +249,7 @@ class SamModel {
 
     // ---- profiling
     bool profiling_ = false;
-    struct Pending { hipEvent_t a, b; Stage st; double work; };
+    struct Pending { hipEvent_t a, b; Stage st; double work; Stage also = ST_COUNT; };
     std::vector<Pending> pending_;
     std::vector<hipEvent_t> event_pool_;
     StageStats stats_;

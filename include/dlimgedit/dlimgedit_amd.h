@@ -76,6 +76,11 @@ DLIMG_API int dlimg_amd_synchronize(dlimg_Environment env);
  * Successive requests are spread over the lanes round-robin so independent images overlap on the GPU. */
 DLIMG_API int dlimg_amd_lane_count(dlimg_Environment env);
 
+/* What the step queue behind dlimg_amd_encode_and_mask really uses (the library clamps DLIMGEDIT_COALESCE / _STEP_DEPTH /
+ * _LANES and has its own defaults): out[0] = requests coalesced per pass, out[1] = passes that may wait on a lane,
+ * out[2] = execution lanes of replica 0, out[3] = lanes requests are currently spread over (1 while per-kernel clocks run). */
+DLIMG_API int dlimg_amd_queue_config(dlimg_Environment env, int* out);
+
 /* Multi-GPU: number of replicas of the environment (entries of DLIMGEDIT_DEVICES; 1 by default) and, for a
  * segmentation handle, the replica / HIP device index that holds its embedding (either pointer may be null). */
 DLIMG_API int dlimg_amd_replica_count(dlimg_Environment env);
@@ -94,9 +99,11 @@ DLIMG_API int dlimg_amd_get_segmentation_masks_device(dlimg_Segmentation const* 
                                                       size_t* out_offsets);
 
 /* ---- stage clocks (HIP events on the executor's stream) -------------------------------------- */
-#define DLIMG_AMD_STAGE_COUNT 8
+#define DLIMG_AMD_STAGE_COUNT 12
 /* stage ids: 0 pre, 1 gemm (all MFMA GEMMs of the encoder), 2 layernorm, 3 attention_window,
- * 4 attention_global, 5 encoder_other, 6 decoder (whole prompt+mask decoder), 7 post */
+ * 4 attention_global, 5 encoder_other, 6 decoder (whole prompt+mask decoder), 7 post;
+ * 8-11 split the launches of stage 1 by kernel flavour: 8 residual-stream writers with row statistics (patch, proj, fc2),
+ * 9 LayerNorm-folded consumer (qkv), 10 LayerNorm-folded consumer + GELU (fc1), 11 other (neck) */
 /* enabled = 1: all requests run on lane 0, so every kernel is clocked alone on the chip; enabled = 2: the lanes run as
  * usual and every lane clocks its own launches (the regime the throughput figure is measured in); 0 = off.
  * dlimg_amd_take_stage_stats sums over the lanes. */
@@ -113,6 +120,9 @@ DLIMG_API int dlimg_amd_test_preprocess(uint8_t const* pixels, int width, int he
  * decoder does, otherwise plane 0 is used.  out_mask: out_w*out_h bytes. */
 DLIMG_API int dlimg_amd_test_postprocess(float const* planes, int n_planes, float const* iou, int out_w, int out_h,
                                          uint8_t* out_mask);
+/* Forces tile configuration `tile` (index into kernels/gemm.hip's table; < 0: off) in the GEMM test hooks below wherever it
+ * fits the problem.  Affects only dlimg_amd_test_gemm / dlimg_amd_test_gemm_ln / the bench hooks, never the product path. */
+DLIMG_API int dlimg_amd_test_force_gemm_tile(int tile);
 /* C = epilogue(A[M,K] . W[N,K]^T): bias[N], resid[resid_rows][N] (row m % resid_rows), act 0/1(GELU). */
 DLIMG_API int dlimg_amd_test_gemm(int M, int N, int K, uint16_t const* A, uint16_t const* W, float const* bias,
                                   float const* resid, int resid_rows, int act, float* out_f32, uint16_t* out_f16);
@@ -150,9 +160,11 @@ DLIMG_API int dlimg_amd_resize_mask(uint8_t const* mask, int width, int height, 
                                     uint8_t* out_mask);
 /* Times the two pixel kernels of the path alone on `batch` (1..16) device-resident 1024x1024 RGBA images / mask requests in
  * ONE launch each: K1 pre-processing (4 MiB u8 in, 6 MiB f16 patch matrix out per image) and K16 post-processing (256 KiB
- * of fp32 logits in, 1 MiB u8 mask out per mask); average ms per launch.  At one image these kernels sit on the launch
- * floor; at 16 they move 168 MB / 21 MB and can be read against the HBM rate. */
-DLIMG_API int dlimg_amd_bench_prepost(int batch, int iters, double* out_pre_ms, double* out_post_ms);
+ * of fp32 logits in, 1 MiB u8 mask out per mask); average ms per launch.  Successive launches rotate over distinct input and
+ * output sets with a footprint of `working_set_mb` MB (0: 768, three times the 256 MB Infinity Cache), so that the bytes a
+ * launch moves come from and go to HBM.  At one image the kernels sit on the launch floor; at 16 they move 168 MB / 21 MB
+ * per launch and can be read against the HBM rate. */
+DLIMG_API int dlimg_amd_bench_prepost(int batch, int iters, int working_set_mb, double* out_pre_ms, double* out_post_ms);
 /* Times `iters` back-to-back launches of an encoder attention kernel (global != 0: the 4096-token kernel, else the 14x14
  * windowed one) on device-resident random data of `batch` images; returns the average ms per launch. */
 DLIMG_API int dlimg_amd_bench_attention(int global, int batch, int heads, int hd, int iters, double* out_ms);

@@ -34,11 +34,15 @@ def test_library_exports_every_declared_symbol(api):
         assert getattr(lib, name) is not None
 
 
-def test_only_dlimg_symbols_are_exported():
+def test_only_dlimg_symbols_are_exported(api):
+    """The reference hides everything but dlimg_init (/root/reference/src/CMakeLists.txt:11, dlimgedit.h:70).  Here:
+    dlimg_init + the dlimg_amd_* extension entry points and NOTHING else of any symbol type -- weak libstdc++ template
+    instantiations (std::filesystem::path::..., std::vector<...>::~vector) included (csrc/exports.map)."""
     out = subprocess.run(["nm", "-D", "--defined-only", str(ROOT / "dlimgedit_amd" / "lib" / "libdlimgedit.so")],
                          capture_output=True, text=True, check=True).stdout
-    names = [l.split()[-1] for l in out.splitlines() if " T " in l]
-    assert names and all(n.startswith("dlimg_") for n in names), names
+    names = [l.split()[-1] for l in out.splitlines() if l.strip()]
+    assert "dlimg_init" in names
+    assert sorted(names) == sorted({"dlimg_init", *api.ext.EXPORTS}), sorted(set(names) ^ {"dlimg_init", *api.ext.EXPORTS})
 
 
 def test_pod_layouts_match_reference(api):
@@ -149,3 +153,18 @@ def test_reference_wrapper_consumer_runs_against_this_library():
     assert r.returncode == 0, r.stderr
     assert "cpu=0" in r.stdout and "image size=192" in r.stdout
     assert "error=Model path /definitely/not/here does not exist" in r.stdout
+
+
+def test_token_kernel_isa_guard_passes_on_the_product_and_fires_on_the_known_bad_form(api, tmp_path):
+    """dlimgedit_amd/build.py::check_token_kernel_isa: the decoder's token kernels must not contain v_pk_fma_f32 with
+    op_sel modifiers (the SLP-paired form that gave one wrong element in ~1e4 decodes).  The product
+    object passes; the known-bad form (-DDLIMG_STRAIGHT_ROWS with the SLP vectoriser left on) is refused."""
+    from dlimgedit_amd import build as B
+    counts = B.check_token_kernel_isa(B.OBJ / "kernels_decoder.hip.o")
+    assert all("op_sel" not in k for k in counts)          # returns {kernel: packed FMA count}; raising is the failure mode
+    bad = tmp_path / "kernels_decoder.hip.o"
+    flags = [f for f in B._flags() if f != "-fno-slp-vectorize"]
+    subprocess.run([B.hipcc(), *flags, "-DDLIMG_TUNING", "-DDLIMG_STRAIGHT_ROWS", "-x", "hip", "-c",
+                    str(B.CSRC / "kernels" / "decoder.hip"), "-o", str(bad)], check=True, capture_output=True)
+    with pytest.raises(RuntimeError, match="v_pk_fma_f32 with op_sel"):
+        B.check_token_kernel_isa(bad)

@@ -160,7 +160,9 @@ def test_decoder_workspaces_are_bit_stable_under_concurrent_lanes(setup):
     vectors, IoU) after decoding a prompt equals the serial answer bit for bit while four host threads keep the execution
     lanes busy with other prompts.  [Round 3: a straight-line form of the token linears' accumulate loop got one element in
     about 10^4 decodes wrong under exactly this load and never from one thread; masks only showed it as a few flipped
-    pixels.  tools/decoder_stress.py is the long form of this test.]"""
+    pixels.  tools/decoder_stress.py is the long form of this test.]  4 x 15 000 = 60 000 decodes: an event of that rate
+    (1e-4 per decode) escapes a run with probability exp(-6) = 0.25 %; the 20 000 of round 3 let it through once in seven."""
+    DECODES_PER_THREAD = 15000
     api, env = setup
     seg = api.Segmentation.process(api.ImageView(synthetic_image(41), api.Channels.rgba), env)
     prompts = [api.Point(150 + 90 * i, 900 - 85 * i) for i in range(8)]
@@ -172,7 +174,7 @@ def test_decoder_workspaces_are_bit_stable_under_concurrent_lanes(setup):
 
     def worker(t):
         try:
-            for rep in range(5000):
+            for rep in range(DECODES_PER_THREAD):
                 j = (rep + 2 * t) % 8
                 got = api.ext.decoder_state(seg, prompts[j])
                 wrong = [(n, int((got[n] != want[j][n]).sum())) for n in got if not np.array_equal(got[n], want[j][n])]
@@ -186,3 +188,40 @@ def test_decoder_workspaces_are_bit_stable_under_concurrent_lanes(setup):
     [t.join() for t in ts]
     assert not errors, errors
     assert not bad, bad[:3]
+
+
+def test_encoder_is_bit_stable_under_concurrent_lanes(model_dirs):
+    """2 000 full-size ViT-B encodes from four host threads over the execution lanes (the regime bench.py measures in):
+    every embedding equals the serial answer of its image bit for bit.  The GEMM epilogues run ~1e8 hand-written packed
+    fp32 operations per image and the attention kernels carry hand-padded hazards: this is their
+    standing stress, the encoder counterpart of the decoder test above (tools/decoder_stress.py ... encode is its long form)."""
+    from dlimgedit_amd import api
+    mdir, _, _ = model_dirs("vit_b")
+    env = api.Environment(api.Options(api.Backend.gpu, mdir))
+    views = [api.ImageView(synthetic_image(60 + i), api.Channels.rgba) for i in range(4)]
+    want = []
+    for v in views:
+        seg = api.Segmentation.process(v, env)
+        want.append(api.ext.get_embedding(seg))
+        seg.close()
+    bad, errors = [], []
+
+    def worker(t):
+        try:
+            for rep in range(500):
+                j = (rep + t) % len(views)
+                seg = api.Segmentation.process(views[j], env)
+                emb = api.ext.get_embedding(seg)
+                seg.close()
+                if not np.array_equal(emb, want[j]):
+                    d = emb != want[j]
+                    bad.append((t, rep, j, int(d.sum()), float(np.abs(emb - want[j]).max())))
+        except Exception as e:       # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    env.close()
+    assert not errors, errors
+    assert not bad, bad[:5]

@@ -271,3 +271,47 @@ def test_device_output_gather_matches_host_masks(api, model_dirs, monkeypatch):
     for s in segs:
         s.close()
     env.close()
+
+
+def test_device_output_gather_config5_eighty_prompts(api, model_dirs, monkeypatch):
+    """BASELINE config 5 in the shape one rank of the 8-GPU job sees it (16 mixed-resolution images, five Halton prompts per
+    cached embedding) through the device-output gather: ONE call with 80 prompts, two replicas (GPU 0 listed twice) and
+    the peer-copy branch forced, so every mask takes the hipMemcpyPeerAsync route into the root's buffer.  Bit-equal to
+    slot 14's host masks; offsets tightly packed in prompt order."""
+    mdir, _, _ = model_dirs("vit_test")
+    monkeypatch.setenv("DLIMGEDIT_DEVICES", "0,0")
+    monkeypatch.setenv("DLIMGEDIT_FORCE_PEER_COPY", "1")
+    env = api.Environment(api.Options(api.Backend.gpu, mdir))
+    monkeypatch.delenv("DLIMGEDIT_DEVICES")
+    base = [(1800, 1200), (1024, 768), (512, 512), (640, 960), (1024, 1024)]
+    sizes = [base[i % 5] for i in range(16)]
+    views = [api.ImageView(synthetic_image(70 + i, width=w, height=h), api.Channels.rgba) for i, (w, h) in enumerate(sizes)]
+    segs = api.Segmentation.process_batch(views, env)
+    placement = [api.ext.segmentation_device(s)[0] for s in segs]
+    assert placement.count(0) == 8 and placement.count(1) == 8
+    many, pts, extents = [], [], []
+    for i, (w, h) in enumerate(sizes):
+        for x, y in halton_points(5, w, h, start=1 + i):
+            many.append(segs[i])
+            pts.append(api.Point(x, y))
+            extents.append((w, h))
+    assert len(many) == 80
+    want = api.Segmentation.compute_mask_batch(many, points=pts)
+    total = sum(w * h for w, h in extents)
+    dev = api.ext.device_alloc(env, total)
+    try:
+        api.ext.copy_to_device(env, dev, np.full(total, 7, np.uint8))
+        offsets = api.ext.compute_mask_batch_device(many, dev, points=pts, root_device=0)
+        got = np.empty(total, np.uint8)
+        api.ext.copy_to_host(env, got, dev)
+        assert offsets[0] == 0
+        assert all(offsets[k + 1] - offsets[k] == extents[k][0] * extents[k][1] for k in range(79))
+        for k, (w, h) in enumerate(extents):
+            m = got[offsets[k]:offsets[k] + w * h].reshape(h, w)
+            assert np.array_equal(m, want[k]), k
+            assert set(np.unique(m)) <= {0, 255}
+    finally:
+        api.ext.device_free(env, dev)
+    for s in segs:
+        s.close()
+    env.close()

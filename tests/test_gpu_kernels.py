@@ -17,6 +17,13 @@ def ext():
     return api.ext
 
 
+@pytest.fixture(autouse=True)
+def _product_tile_choice_after_each_test(ext):
+    """Tests that force a GEMM tile (ext.force_gemm_tile) must not leak the choice into the next test."""
+    yield
+    ext.force_gemm_tile(-1)
+
+
 def _oracle():
     from oracle import sam_oracle as O
     return O
@@ -164,7 +171,7 @@ def test_gemm_parity(ext, M, N, K, act, with_bias, resid_rows):
 def test_gemm_every_tile_configuration(ext, monkeypatch, tile, M, N, K):
     """Each tile configuration (waves layout, K-tile, pipeline depth) against the fp32 product, incl. K tails
     shorter than the pipeline depth."""
-    monkeypatch.setenv("DLIMGEDIT_GEMM_TILE", str(tile))
+    ext.force_gemm_tile(tile)
     rng = np.random.default_rng(tile * 1000 + K)
     A = rng.standard_normal((M, K)).astype(np.float16)
     W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float16)
@@ -205,7 +212,7 @@ def test_gemm_folded_layernorm(ext, monkeypatch, M, D, K1, N, act, tile):
     multiplies it by W*gamma, takes the row moments from its own operand fragments and normalises in its epilogue.
     Checked against the oracle's LayerNorm + fp64 product and against the un-fused kernels' own error."""
     if tile is not None:
-        monkeypatch.setenv("DLIMGEDIT_GEMM_TILE", str(tile))
+        ext.force_gemm_tile(tile)
     O = _oracle()
     rng = np.random.default_rng(M + D + N)
     A1 = rng.standard_normal((M, K1)).astype(np.float16)

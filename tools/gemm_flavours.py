@@ -6,6 +6,8 @@ ROOT = Path(__file__).resolve().parent.parent
 code = r'''
 import sys; sys.path.insert(0, %r)
 from dlimgedit_amd import api
+import os
+if os.environ.get('TOOL_GEMM_TILE'): api.ext.force_gemm_tile(int(os.environ['TOOL_GEMM_TILE']))
 for rep in range(2):
     print("  plain, no bias: qkv {:.1f} us  fc1 {:.1f} us".format(api.ext.bench_gemm(4096,2304,768,0,iters=50)*1e3, api.ext.bench_gemm(4096,3072,768,0,iters=50)*1e3))
     for M,N,K,name,fl in [(4096,2304,768,"qkv",(4,1)),(4096,3072,768,"fc1",(4,1)),(4096,768,768,"proj",(2,3)),(4096,768,3072,"fc2",(2,3))]:
@@ -15,6 +17,6 @@ for rep in range(2):
 for tile in sys.argv[1:] or ["", "7", "4"]:
     env = dict(os.environ)
     if tile:
-        env["DLIMGEDIT_GEMM_TILE"] = tile
+        env["TOOL_GEMM_TILE"] = tile
     print(f"tile={tile or 'auto'}", flush=True)
     subprocess.run([sys.executable, "-c", code], env=env)
