@@ -99,7 +99,7 @@ def _compile(src: str, force: bool, hdr_mtime: float, tuning: bool = False) -> P
 
 LLVM_OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 # the toolchain the -fno-slp-vectorize workaround was validated with; another compiler may pair
-# fp32 operations by a different route, which is what check_token_kernel_isa() is there to catch
+# fp32 operations by a different route, which is what check_packed_select_erratum() is there to catch
 VALIDATED_HIPCC = "HIP 7.2.26015 / AMD clang 22.0.0git roc-7.2.0 (7b800a19)"
 
 
@@ -117,14 +117,17 @@ def disassemble_device_code(obj: Path) -> str:
         return subprocess.run([LLVM_OBJDUMP, "-d", str(code[0])], capture_output=True, text=True, check=True).stdout
 
 
-def check_token_kernel_isa(obj: Path) -> dict:
-    """Build-time guard of the decoder's fp32 token kernels (kernels/decoder.hip).  Round 3 met a silent wrong element
-    (about 1 in 10^4 decodes, only under concurrent lanes) in code where the SLP vectoriser had paired the rows of the
-    token linears into chains of `v_pk_fma_f32` with op_sel / op_sel_hi modifiers fed by v_mov_b32 shuffles; the source
-    is now built with -fno-slp-vectorize and keeps a loop shape that offers nothing to pair.  A flag or compiler change
-    that brings the pattern back must fail the BUILD, not a stress test that catches it with some probability: no kernel
-    of decoder.hip may contain a v_pk_fma_f32 with a source-select modifier (packed fp32 from vector types in the source
-    -- aligned register pairs, no op_sel on the FMA -- is fine and expected).  Returns {kernel: packed FMA count}."""
+def check_packed_select_erratum(obj: Path) -> dict:
+    """Build-time guard against the gfx950 packed-fp32 operand-select erratum (tools/pkfma_hazard.cpp).
+
+    Measured on MI355X (round 4): a v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 whose LOW lane takes src1 from the HIGH
+    register of the pair (op_sel:[_,1,...]) reads 0.0 for that operand about once in 1e6 executions while ANOTHER wave
+    on the same SIMD has an MFMA in flight -- on settled registers, with any number of wait states around it, so it is
+    not a dependency hazard and no padding cures it.  Selects on src0 or src2, op_sel_hi selects, and packed operations
+    without selects never failed (0 in 5e11 each).  hipcc 7.2 emits the bad form when the SLP vectoriser pairs scalar
+    FMAs of two rows (round 3: one wrong element in ~1e4 decodes); every source is therefore built with
+    -fno-slp-vectorize, and this check refuses any kernel object that contains a packed instruction with a src1
+    low-lane select, whoever emitted it.  Returns {kernel: number of packed fp32 instructions} for the log."""
     import re
     counts, bad, name = {}, [], None
     for line in disassemble_device_code(obj).splitlines():
@@ -132,14 +135,18 @@ def check_token_kernel_isa(obj: Path) -> dict:
         if m:
             name = m.group(1)
             continue
-        if name and "v_pk_fma_f32" in line:
+        m = re.search(r"\b(v_pk_\w+)\s", line)
+        if not (name and m):
+            continue
+        if m.group(1).endswith("_f32"):
             counts[name] = counts.get(name, 0) + 1
-            if "op_sel" in line:
-                bad.append((name, line.strip().split("//")[0].strip()))
+        sel = re.search(r"op_sel:\[([01]),([01])", line)
+        if sel and sel.group(2) == "1":
+            bad.append((name, line.strip().split("//")[0].strip()))
     if bad:
         listing = "\n".join(f"  {n}: {i}" for n, i in bad[:8])
-        raise RuntimeError("decoder.hip: v_pk_fma_f32 with op_sel modifiers in the token kernels (the pattern behind the wrong "
-                           f"element of DESIGN.md section 6; validated toolchain: {VALIDATED_HIPCC}):\n{listing}")
+        raise RuntimeError(f"{obj.name}: packed instruction with a src1 low-lane select (op_sel:[_,1,..]) -- reads 0.0 beside another "
+                           f"wave's MFMA on gfx950 (DESIGN.md section 6; validated toolchain: {VALIDATED_HIPCC}):\n{listing}")
     return counts
 
 
@@ -161,7 +168,9 @@ def build(force: bool = False, verbose: bool = False, tuning: bool = False) -> P
             print(f"built {LIB_TUNING} ({LIB_TUNING.stat().st_size / 1e6:.1f} MB)")
         return LIB_TUNING
     if force or not LIB.exists() or LIB.stat().st_mtime < max(o.stat().st_mtime for o in objs):
-        check_token_kernel_isa(OBJ / "kernels_decoder.hip.o")      # before anything is linked: a refused build leaves no library
+        for o in objs:                                          # before anything is linked: a refused build leaves no library
+            if o.name.startswith("kernels_"):
+                check_packed_select_erratum(o)
         cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs),
                "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined", f"-Wl,-soname,{SONAME}",
                f"-Wl,--version-script={EXPORTS_MAP}", "-ldl", "-lz"]

@@ -155,16 +155,20 @@ def test_reference_wrapper_consumer_runs_against_this_library():
     assert "error=Model path /definitely/not/here does not exist" in r.stdout
 
 
-def test_token_kernel_isa_guard_passes_on_the_product_and_fires_on_the_known_bad_form(api, tmp_path):
-    """dlimgedit_amd/build.py::check_token_kernel_isa: the decoder's token kernels must not contain v_pk_fma_f32 with
-    op_sel modifiers (the SLP-paired form that gave one wrong element in ~1e4 decodes).  The product
-    object passes; the known-bad form (-DDLIMG_STRAIGHT_ROWS with the SLP vectoriser left on) is refused."""
+def test_packed_select_guard_passes_on_the_product_and_fires_on_the_known_bad_form(api, tmp_path):
+    """dlimgedit_amd/build.py::check_packed_select_erratum: no kernel may contain a packed instruction whose low lane takes
+    src1 from the high register (op_sel:[_,1,..]) -- on gfx950 that operand reads 0.0 about once in 1e6 executions beside
+    another wave's MFMA (tools/pkfma_hazard.cpp).  Every product kernel object passes; the known-bad
+    form of the token linears (-DDLIMG_STRAIGHT_ROWS with the SLP vectoriser left on, what round 3 shipped for a day) is
+    refused."""
     from dlimgedit_amd import build as B
-    counts = B.check_token_kernel_isa(B.OBJ / "kernels_decoder.hip.o")
-    assert all("op_sel" not in k for k in counts)          # returns {kernel: packed FMA count}; raising is the failure mode
+    objs = sorted(B.OBJ.glob("kernels_*.o"))
+    assert len(objs) >= 9
+    for o in objs:
+        B.check_packed_select_erratum(o)                   # raising is the failure mode
     bad = tmp_path / "kernels_decoder.hip.o"
     flags = [f for f in B._flags() if f != "-fno-slp-vectorize"]
     subprocess.run([B.hipcc(), *flags, "-DDLIMG_TUNING", "-DDLIMG_STRAIGHT_ROWS", "-x", "hip", "-c",
                     str(B.CSRC / "kernels" / "decoder.hip"), "-o", str(bad)], check=True, capture_output=True)
-    with pytest.raises(RuntimeError, match="v_pk_fma_f32 with op_sel"):
-        B.check_token_kernel_isa(bad)
+    with pytest.raises(RuntimeError, match="src1 low-lane select"):
+        B.check_packed_select_erratum(bad)
