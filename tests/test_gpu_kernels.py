@@ -387,3 +387,49 @@ def test_resize_reference_kat_on_device(ext):
     out = ext.test_resize(img, api.Channels.rgba, 4, 4)
     for i in range(16):
         assert tuple(int(v) for v in out[i // 4, i % 4]) == (255, 2 + 8 * (i // 4), 2 + 8 * (i % 4), 255)
+
+
+@pytest.mark.parametrize("N,K,act", [(2304, 128, 0), (3072, 256, 1), (1536, 1152, 0)])
+def test_gemm_persistent_tile_chain_is_bit_equal_to_single_tiles(ext, N, K, act):
+    """The ping-pong kernel chains several tiles per workgroup once a launch has more tiles than CUs (batched passes: two
+    images give qkv 288 and fc1 384 tiles of 256 x 256; kernels/gemm.hip, "PERSISTENT form").  Which workgroup computes a
+    tile must not enter the arithmetic: M = 16384 rows in one launch (576 / 768 / 384 tiles on 192 / 256 / 192 workgroups) against
+    the same rows as four launches of 4096 (one tile per workgroup), bit for bit, for the plain, the GELU and the
+    residual-stream flavours; and against the fp32 product."""
+    ext.force_gemm_tile(9)
+    rng = np.random.default_rng(N + K)
+    M = 16384
+    A = rng.standard_normal((M, K)).astype(np.float16)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float16)
+    bias = rng.standard_normal(N).astype(np.float32)
+    resid = rng.standard_normal((M, N)).astype(np.float32) if N == 1536 else None
+    whole32, whole16 = ext.test_gemm(A, W, bias, resid, act, want_f16=True)
+    ref = _gemm_ref(A[:512], W, bias, None if resid is None else resid[:512], act)
+    assert np.abs(whole32[:512] - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max())
+    for q in range(4):
+        rows = slice(q * 4096, (q + 1) * 4096)
+        part32, part16 = ext.test_gemm(A[rows], W, bias, None if resid is None else resid[rows], act, want_f16=True)
+        assert np.array_equal(part32, whole32[rows]) and np.array_equal(part16, whole16[rows]), q
+
+
+def test_gemm_persistent_tile_chain_with_folded_layernorm(ext):
+    """The same for the LayerNorm-folded consumer (row statistics and column vectors of the NEXT tile are requested in the
+    middle of the current tile's epilogue and merged into the other parity of the auxiliary LDS area): 8192 rows, producer
+    96 tiles, consumer 288 tiles on 144 workgroups, against the two halves run on their own."""
+    ext.force_gemm_tile(9)
+    rng = np.random.default_rng(99)
+    M, D, K1, N = 8192, 768, 256, 2304
+    A1 = rng.standard_normal((M, K1)).astype(np.float16)
+    W1 = (rng.standard_normal((D, K1)) / np.sqrt(K1)).astype(np.float16)
+    b1 = rng.standard_normal(D).astype(np.float32)
+    resid = (rng.standard_normal((M, D)) * 3 + 1).astype(np.float32)
+    gamma = (1 + 0.2 * rng.standard_normal(D)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(D)).astype(np.float32)
+    W2 = (rng.standard_normal((N, D)) / np.sqrt(D)).astype(np.float32)
+    b2 = rng.standard_normal(N).astype(np.float32)
+    for act in (0, 1):
+        x, xh, y = ext.test_gemm_ln(A1, W1, b1, resid, W2, gamma, beta, b2, 1e-6, act)
+        for h in range(2):
+            rows = slice(h * 4096, (h + 1) * 4096)
+            xp, xhp, yp = ext.test_gemm_ln(A1[rows], W1, b1, resid[rows], W2, gamma, beta, b2, 1e-6, act)
+            assert np.array_equal(xp, x[rows]) and np.array_equal(xhp, xh[rows]) and np.array_equal(yp, y[rows]), (act, h)
