@@ -100,15 +100,11 @@ struct RowStats {
         if (EPI != EPI_NORM) return;
         const int r = threadIdx.x / TPR, sub = threadIdx.x % TPR;
         // [group][row]: the lanes of one load instruction read runs of consecutive rows
-        const float2_t* p = reinterpret_cast<const float2_t*>(a.ln_stats) + (m0 + r);
-        // branch-free (the persistent ping-pong kernel issues these in the middle of its epilogue: a divergent branch per
-        // load there costs the register allocator dearly): a lane whose group does not exist re-reads the last group and
-        // discards it
+        const float2_t* p = reinterpret_cast<const float2_t*>(a.ln_stats) + (size_t)sub * a.M + (m0 + r);
 #pragma unroll
         for (int u = 0; u < kStatRegs; ++u) {
-            const int g = sub + u * TPR;
-            const float2_t v = p[(size_t)min(g, a.ln_groups - 1) * a.M];
-            q[u] = g < a.ln_groups ? v : float2_t{0.f, -1.f};      // M2 < 0 marks "no such group"
+            q[u] = float2_t{0.f, -1.f};          // M2 < 0 marks "no such group"
+            if (sub + u * TPR < a.ln_groups) q[u] = p[(size_t)u * TPR * a.M];
         }
     }
     DLIMG_DEVICE void finish(const k::GemmArgs& a, float* rowstat) {
@@ -542,8 +538,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm16_f16_kernel(k::Gem
 // slot 4t+4.
 constexpr int kPPHalfBytes = 128 * 128;
 constexpr int kPPBufBytes = 4 * kPPHalfBytes;
-constexpr int kPPAuxParity = 256 * 8 + 2 * 256 * 4;                    // rowstat [256] x (mean, rstd), colvec [2][256]: per tile parity
-constexpr int kPPAuxBytes = 2 * kPPAuxParity + 256 * 4 * 8;            // both parities (persistent kernel), rowpart [256][4]
+constexpr int kPPAuxBytes = 256 * 8 + 2 * 256 * 4 + 256 * 4 * 8;      // rowstat, colvec[2], rowpart [256][4]
 constexpr int kPPLds = 2 * kPPBufBytes + kPPAuxBytes;
 
 // L segment's end: fragment reads of this wave have returned, then the workgroup barrier.  One statement with a memory
@@ -563,24 +558,10 @@ DLIMG_DEVICE void pp_barrier() {
 // PRE: the residual of the whole wave tile was requested before the main loop (pre[band][kk]; only where the
 // registers allow it) -- the epilogue is bound by the CU's memory pipe (~30 B/clk: 320 KB per 128 x 256 tile of a
 // stream writer), so every byte moved earlier comes off it.
-struct NoHook { DLIMG_DEVICE void operator()(int) const {} };
-// band of the epilogue after whose stores the hook runs (the persistent kernel requests its next tile's row statistics
-// and column vectors there): late, because every band finished frees 16 accumulator registers -- after band NI - 2 the
-// 32 requested values fit without spilling (r04: hook after band NI / 2 - 1: 160-170 spilled registers in the
-// LayerNorm-folded flavours, after NI - 2: 100, after the last band: 90-100; 43 without a tile loop at all)
-#ifndef DLIMG_PP_HOOK_BAND
-#define DLIMG_PP_HOOK_BAND(NI) ((NI) - 2)
-#endif
-
-// slab / slab_alt: the wave's LDS staging slab(s) -- two of 4 KB used alternately (slab_alt = 4096) or one (slab_alt = 0: the
-// persistent kernel, whose next tile's operands already occupy most of the buffers; LDS operations of a wave execute in
-// order, so re-using one slab needs no extra wait).  mid(stores): called once, after the stores of band DLIMG_PP_HOOK_BAND, with the
-// number of global stores this wave has issued so far -- by then half of the accumulators are dead, i.e. registers are free
-// for whatever the caller wants to request for its next tile.
-template <int NI, int ACT, int EPI, bool PRE = false, typename Mid = NoHook>
-DLIMG_DEVICE void pp_epilogue(const k::GemmArgs& a, float4v (&acc)[NI][4], char* slab, int slab_alt, const float* rowstat, const float* colvec,
+template <int NI, int ACT, int EPI, bool PRE = false>
+DLIMG_DEVICE void pp_epilogue(const k::GemmArgs& a, float4v (&acc)[NI][4], char* smem, const float* rowstat, const float* colvec,
                               float2_t* rowpart, int m0, int n0, int row_base, int wc, int wave, int lane,
-                              float4_t (*pre)[4] = nullptr, Mid mid = Mid{}) {
+                              float4_t (*pre)[4] = nullptr) {
     // ---- epilogue.  A lane owns 4 consecutive columns of one row per accumulator tile (row = l15, columns 4 * quad ..):
     // storing that directly touches 16 cache lines per wave-instruction with 32 or 64 bytes each, and the store path
     // pays per line touched (measured: 16-22 k cycles for the tile).  So the wave's 16 x 64 band goes through a private
@@ -597,13 +578,14 @@ DLIMG_DEVICE void pp_epilogue(const k::GemmArgs& a, float4v (&acc)[NI][4], char*
         bias4[j] = *reinterpret_cast<const float4_t*>(colvec + col_base + j * 16);
         if (EPI == EPI_NORM) csum4[j] = *reinterpret_cast<const float4_t*>(colvec + BN + col_base + j * 16);
     }
+    char* slab = smem + wave * 8192;             // two slabs of 4 KB per wave, used alternately
     const int resid_row0 = a.resid ? m0 % a.resid_mod : 0;
     if (a.out_f32 == nullptr) {
         // ---- f16 rows: slot = 8-byte piece (j*4 + quad) of a 128-byte row, XORed with (row & 7) << 1 (pairs stay adjacent)
         const int rd_row = lane >> 3, rd_chunk = lane & 7;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            char* sl = slab + (i & 1) * slab_alt;
+            char* sl = slab + (i & 1) * 4096;
             float2_t st = float2_t{0.f, 1.f};
             if (EPI == EPI_NORM) st = reinterpret_cast<const float2_t*>(rowstat)[row_base + i * 16 + l15];
 #pragma unroll
@@ -625,7 +607,6 @@ DLIMG_DEVICE void pp_epilogue(const k::GemmArgs& a, float4v (&acc)[NI][4], char*
                 const size_t m = (size_t)(m0 + row_base + i * 16 + r);
                 *reinterpret_cast<float4_t*>(a.out_h + m * a.ldc16 + n0 + wc * 64 + rd_chunk * 8) = piece16;
             }
-            if (i == DLIMG_PP_HOOK_BAND(NI)) mid((DLIMG_PP_HOOK_BAND(NI) + 1) * 2);
         }
     } else {
         // The residual / f16-copy options are compile-time inside the band loop: a run-time test per load makes the
@@ -652,7 +633,7 @@ DLIMG_DEVICE void pp_epilogue(const k::GemmArgs& a, float4v (&acc)[NI][4], char*
             if (!PRE) request_residual(0, rv[0]);
     #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                char* sl = slab + (i & 1) * slab_alt;
+                char* sl = slab + (i & 1) * 4096;
                 float2_t st = float2_t{0.f, 1.f};
                 if (EPI == EPI_NORM) st = reinterpret_cast<const float2_t*>(rowstat)[row_base + i * 16 + l15];
     #pragma unroll
@@ -693,7 +674,6 @@ DLIMG_DEVICE void pp_epilogue(const k::GemmArgs& a, float4v (&acc)[NI][4], char*
                         if (rd_slot == 0) rowpart[(row_base + i * 16 + r) * 4 + wc] = float2_t{s1, m2};
                     }
                 }
-                if (i == DLIMG_PP_HOOK_BAND(NI)) mid((DLIMG_PP_HOOK_BAND(NI) + 1) * (HAS_H ? 8 : 4));
             }
     
         };
@@ -723,44 +703,19 @@ DLIMG_DEVICE void pp_epilogue(const k::GemmArgs& a, float4v (&acc)[NI][4], char*
     }
 }
 
-// PERSISTENT form (round 4).  The grid may be smaller than the number of tiles: workgroup w takes tiles w, w + grid, ...
-// (logical ids through the XCD remap, so a workgroup's tiles stay on its XCD's share of the tile range), one after the
-// other, and the turn-around between two tiles is overlapped instead of paid: as soon as both wave groups have left the
-// main loop, the wave requests the next tile's first operands (K tile 0 into buffer 0, W of K tile 1 into buffer 1: 96 KB
-// of DMA) and only then runs its epilogue, whose staging slabs live in the one region the next tile does not need yet
-// (buffer 1's A halves, 4 KB per wave).  Half way through the epilogue -- half of the accumulators are dead by then, so
-// registers are free -- the next tile's bias / LayerNorm column sums and row statistics are requested; they are merged into
-// the OTHER parity of the auxiliary area behind the epilogue.  One barrier later the next main loop starts on operands that
-// landed microseconds ago.  What this removes per tile after a workgroup's first: the workgroup launch, the kernel-argument
-// and statistics fetches and the first operand fetch (3.0-5.6 us of a 22-36 us tile by in-kernel stamps, r04) -- during
-// which a one-tile workgroup keeps its CU's matrix pipe idle.  Which workgroup computes a tile does not enter the
-// arithmetic: results are bit-identical to the one-tile-per-workgroup launch (asserted by the batch == single tests).
-// vmcnt bookkeeping: the counter is in order across loads, DMA copies and stores.  The next tile's DMA requests are OLDER
-// than every store of the epilogue, so "at most as many outstanding as stores issued since" (the hook's wait) proves they
-// have landed without waiting for a single store; the main loop's counted waits (everything but the newest four requests)
-// then also cover what is left of the epilogue's stores, half a K tile into the loop.
-// Kernel arguments in the tile loop.  Passed by value they are fetched once and then stay in ~45 scalar registers for the
-// whole kernel; with a back edge around main loop + epilogue that costs 60 spilled SGPRs and, through them, ~100 spilled
-// VGPRs whose scratch traffic sits in the epilogue (measured r04: qkv's epilogue 5.4 k -> 18 k cycles).  So each phase of a
-// tile re-reads the fields it uses from the kernarg segment (GemmArgs is the kernel's first parameter: offset 0) through a
-// pointer made opaque at that point -- scalar loads that hit the scalar cache -- into a local copy whose fields are plain
-// values for the phase: 2-22 spilled VGPRs, fewer than the one-tile kernel had (43).
-typedef const __attribute__((address_space(4))) k::GemmArgs* KernArgPtr;
-DLIMG_DEVICE k::GemmArgs fetch_args(KernArgPtr& p) {
-    asm volatile("" : "+s"(p));
-    k::GemmArgs copy;
-    __builtin_memcpy(&copy, p, sizeof(copy));
-    return copy;
-}
-
+// One tile per workgroup.  [r04, measured and NOT kept (commit e1871cc holds the code and its parity tests): a PERSISTENT
+// form -- grid = ceil(tiles / rounds), each workgroup walking its tiles, the next tile's first operands (96 KB of DMA)
+// requested before the epilogue, slabs in the one LDS region those leave free, the next tile's vectors / statistics into
+// the other parity of the auxiliary area, kernel arguments re-read per phase so that the tile loop does not pin 45 SGPRs.
+// Bit-equal to this kernel; but on the two-image shapes qkv 46.2 us against 42.2 here (4 concurrent streams: 31.9 / 29.2),
+// fc1 59.0 / 56.0 (54.2 / 51.2), eight images qkv 145 / 134, and the bench 784-787 against 808 images/s on the same box.
+// Why the turn-around it removes (3.0-5.6 us of launch + first fetch by the stamps) does not come back: vmcnt counts
+// stores and DMA copies in order, so the chained tile's first counted wait stands behind the WHOLE drain of the previous
+// epilogue's stores -- which a fresh workgroup overlaps with its own launch for free; the tile loop costs the epilogue
+// 15-70 spilled registers whatever is done about it; and with the grid cut to tiles / rounds the short last round of the
+// one-tile launch (32 of 288 tiles on an empty chip, at a higher clock) is gone.]
 template <int ACT, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(k::GemmArgs a_by_value, int ntiles) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    KernArgPtr kernarg = (KernArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    k::GemmArgs a = fetch_args(kernarg);         // prologue's view; every later phase fetches its own
-#else
-    const k::GemmArgs& a = a_by_value;           // (host pass of the compiler only)
-#endif
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(k::GemmArgs a) {
     constexpr int BM = 256, BN = 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = lane_id();
@@ -769,49 +724,47 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(k::GemmArgs a_by_value,
     const int l15 = lane & 15, quad = lane >> 4;
 
     const int ntn = a.N / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / ntn) * BM;
+    const int n0 = (tile % ntn) * BN;
     const int nk = a.K / 64;
-    int logical = blockIdx.x;                    // this workgroup's tiles: logical ids blockIdx.x, + gridDim.x, ...
-    int tile = xcd_remap(logical, ntiles);
-    int m0 = (tile / ntn) * BM;
-    int n0 = (tile % ntn) * BN;
 
-    char* aux = smem + 2 * kPPBufBytes;          // [parity]{rowstat [BM][2], colvec [2][BN]}, then rowpart
-    float2_t* rowpart = reinterpret_cast<float2_t*>(aux + 2 * kPPAuxParity);
+    float* rowstat = reinterpret_cast<float*>(smem + 2 * kPPBufBytes);
+    float* colvec = rowstat + 2 * BM;
+    float2_t* rowpart = reinterpret_cast<float2_t*>(colvec + 2 * BN);
 
     float4v acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
 
     // ---- DMA sources: piece p = 2*wave + q of a half-tile = rows 8p .. 8p+7, lane -> (row, swizzled chunk)
     const half_t* src_a[2];
     const half_t* src_w[2];
-    auto set_sources = [&](int tm0, int tn0, int ln) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int row = (wave * 2 + q) * 8 + (ln >> 3);
-            const int chunk = (ln & 7) ^ ((row >> 1) & 7);
-            src_a[q] = a.A + (size_t)(tm0 + row) * a.lda + chunk * 8;
-            src_w[q] = a.W + (size_t)(tn0 + row) * a.ldw + chunk * 8;
-        }
-    };
-    set_sources(m0, n0, lane);
+    for (int q = 0; q < 2; ++q) {
+        const int row = (wave * 2 + q) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        src_a[q] = a.A + (size_t)(m0 + row) * a.lda + chunk * 8;
+        src_w[q] = a.W + (size_t)(n0 + row) * a.ldw + chunk * 8;
+    }
+    const size_t a_half = (size_t)128 * a.lda, w_half = (size_t)128 * a.ldw;
     // H: 0 = A rows 0-127, 1 = A rows 128-255, 2 = W rows 0-127, 3 = W rows 128-255
     auto stage = [&](int t, int H) {
         char* dst = smem + (t & 1) * kPPBufBytes + H * kPPHalfBytes + wave * 2048;
-        const size_t a_half = (size_t)128 * a.lda, w_half = (size_t)128 * a.ldw;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const half_t* g = (H < 2 ? src_a[q] + (H & 1) * a_half : src_w[q] + (H & 1) * w_half) + (size_t)t * 64;
             glds16(g, dst + q * 1024);
         }
     };
-    auto stage_first = [&] {                     // what a main loop expects to be on its way: K tile 0, and W of K tile 1
-        stage(0, 0); stage(0, 1); stage(0, 2); stage(0, 3);
-        if (nk > 1) { stage(1, 2); stage(1, 3); }
-    };
 
     // ---- fragment addresses: row l15 of a 16-row tile, chunk 4*ks + quad, swizzle (l15 >> 1) & 7 (tile bases are
     // multiples of 16 rows and do not touch the swizzle bits)
-    int off0 = 0, off1 = 0;                      // set per tile (below) from an opaque lane id: nothing lane-dependent is kept
-                                                 // in registers across the epilogue
+    const int sw = (l15 >> 1) & 7;
+    const int off0 = l15 * 128 + ((quad ^ sw) << 4);
+    const int off1 = l15 * 128 + (((quad ^ sw) ^ 4) << 4);
     const char* a_base = smem + wr * kPPHalfBytes;                                     // + buffer + (mh*64 + i*16) * 128
     const char* w_base = smem + (2 + (wc >> 1)) * kPPHalfBytes + (wc & 1) * 64 * 128;  // + buffer + (nh*32 + j*16) * 128
     auto frag = [&](const char* p) { return *reinterpret_cast<const half8_t*>(p); };
@@ -822,11 +775,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(k::GemmArgs a_by_value,
     RowStats<BM, 512, EPI> row_stats;
     column_vectors.issue(a, n0);                 // ordinary loads first: they are the oldest entries of the vm counter
     row_stats.issue(a, m0);
-    stage_first();
-    column_vectors.store(reinterpret_cast<float*>(aux) + 2 * BM);
-    row_stats.finish(a, reinterpret_cast<float*>(aux));
+    stage(0, 0); stage(0, 1); stage(0, 2); stage(0, 3);
+    if (nk > 1) { stage(1, 2); stage(1, 3); }
+    column_vectors.store(colvec);
+    row_stats.finish(a, rowstat);
     if (nk > 1) wait_dma<4>(); else wait_dma<0>();
     pp_barrier();                                // tile 0 is visible to every wave
+    if (wr == 1) pp_barrier();                   // group 1 runs one slot behind group 0
 
     half8_t fa[4][2], fw[2][2][2];               // A: [i][ks]; W: [nh][j][ks]
     auto mfma_quadrant = [&](int mh, int nh) {
@@ -887,96 +842,29 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(k::GemmArgs a_by_value,
     };
     using Even = std::integral_constant<int, 0>;
     using Odd = std::integral_constant<int, 1>;
+    const unsigned long long t_loop = DLIMG_STAMPS(a) ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long r_loop = DLIMG_STAMPS(a) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    int t = 0;
+    for (; t + 3 < nk; t += 2) {
+        step(t, Even{}, std::true_type{});
+        step(t + 1, Odd{}, std::true_type{});
+    }
+    for (; t < nk; t += 2) {
+        step(t, Even{}, std::false_type{});
+        if (t + 1 < nk) step(t + 1, Odd{}, std::false_type{});
+    }
+    if (wr == 0) pp_barrier();                   // group 0 waits for group 1's last M segment: barrier counts match
+    const unsigned long long t_loop_end = DLIMG_STAMPS(a) ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long r_loop_end = DLIMG_STAMPS(a) ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
-    for (int parity = 0;; parity ^= 1) {         // one tile per turn
-        {
-            int lane_t = lane;
-            asm volatile("" : "+v"(lane_t));
-            const int tl15 = lane_t & 15, tquad = lane_t >> 4, sw = (tl15 >> 1) & 7;
-            off0 = tl15 * 128 + ((tquad ^ sw) << 4);
-            off1 = tl15 * 128 + (((tquad ^ sw) ^ 4) << 4);
-#if defined(__HIP_DEVICE_COMPILE__)
-            a = fetch_args(kernarg);             // the main loop's view: A, W, lda, ldw
-#endif
-            set_sources(m0, n0, lane_t);         // (again for the first tile; after that the registers were free in between)
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
-        if (wr == 1) pp_barrier();               // group 1 runs one slot behind group 0
-        const unsigned long long t_loop = DLIMG_STAMPS(a) ? __builtin_amdgcn_s_memtime() : 0ull;
-        const unsigned long long r_loop = DLIMG_STAMPS(a) ? __builtin_amdgcn_s_memrealtime() : 0ull;
-        int t = 0;
-        for (; t + 3 < nk; t += 2) {
-            step(t, Even{}, std::true_type{});
-            step(t + 1, Odd{}, std::true_type{});
-        }
-        for (; t < nk; t += 2) {
-            step(t, Even{}, std::false_type{});
-            if (t + 1 < nk) step(t + 1, Odd{}, std::false_type{});
-        }
-        if (wr == 0) pp_barrier();               // group 0 waits for group 1's last M segment: barrier counts match
-        const unsigned long long t_loop_end = DLIMG_STAMPS(a) ? __builtin_amdgcn_s_memtime() : 0ull;
-        const unsigned long long r_loop_end = DLIMG_STAMPS(a) ? __builtin_amdgcn_s_memrealtime() : 0ull;
-
-        // every wave is past its last LDS read: the operand buffers are free.  Next tile (if any): first operands now.
-        const int next = logical + (int)gridDim.x;
-        const bool more = next < ntiles && (nk & 1) == 0;        // (an odd K tile count would leave the last tile in buffer 0)
-        const float* rowstat = reinterpret_cast<const float*>(aux + parity * kPPAuxParity);
-        const float* colvec = rowstat + 2 * BM;
-#if defined(__HIP_DEVICE_COMPILE__)
-        a = fetch_args(kernarg);                 // the epilogue's view: outputs, residual, vectors, statistics
-#endif
-        int nm0 = m0, nn0 = n0;
-        if (more) {
-            const int ntile = xcd_remap(next, ntiles);
-            nm0 = (ntile / ntn) * BM;
-            nn0 = (ntile % ntn) * BN;
-            int lane_n = lane;
-            asm volatile("" : "+v"(lane_n));
-            set_sources(nm0, nn0, lane_n);
-            stage_first();
-        }
-        // slabs: buffer 1's A halves (32 KB), the one region stage_first() leaves alone: one slab of 4 KB per wave (a slab
-        // address that depends on `more` costs the epilogue ~20 registers -- r04 -- so the last tile uses the same place).
-        // The lane id the epilogue derives its addresses from is made opaque per tile: otherwise every lane-dependent piece
-        // of its address arithmetic is hoisted out of the tile loop and kept in registers through the main loop (r04:
-        // 492 spilled registers, 574 scratch accesses beside the epilogue's 208 stores)
-        int lane_e = lane;
-        asm volatile("" : "+v"(lane_e));
-        pp_epilogue<8, ACT, EPI>(a, acc, smem + kPPBufBytes + wave * 4096, 0, rowstat, colvec,
-                                 rowpart, m0, n0, wr * 128, wc, wave, lane_e, nullptr, [&](int stores) {
-                                     // the DMA requests above are older than these stores: they have landed
-                                     if (stores >= 56) wait_dma<56>();
-                                     else if (stores >= 32) wait_dma<32>();
-                                     else if (stores >= 16) wait_dma<16>();
-                                     else wait_dma<8>();
-                                 });
-        // The next tile's bias / column sums and row statistics are requested behind the epilogue, not inside it: 32 more
-        // live registers there are 40-110 more spilled ones (r04, every placement tried), and their scratch traffic costs
-        // more than the ~1 us these (L2-resident) loads take now.
-        if (more) {
-            column_vectors.issue(a, nn0);
-            row_stats.issue(a, nm0);
-        }
-        if (more) {
-            float* nrowstat = reinterpret_cast<float*>(aux + (parity ^ 1) * kPPAuxParity);
-            column_vectors.store(nrowstat + 2 * BM);
-            row_stats.finish(a, nrowstat);
-            logical = next; m0 = nm0; n0 = nn0;
-            pp_barrier();                        // slabs are dead, the other parity's vectors are complete, K tile 0 is visible
-            continue;
-        }
-        if (DLIMG_STAMPS(a) && threadIdx.x == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the wave's own stores have left
-            unsigned long long* d = DLIMG_STAMPS(a) + (size_t)blockIdx.x * 4;
-            d[0] = t_loop_end - t_loop;
-            d[1] = r_loop_end - r_loop;
-            d[2] = ((t_loop - t_start) << 32) | ((__builtin_amdgcn_s_memtime() - t_loop_end) & 0xffffffffull);   // prologue | epilogue cycles (last tile)
-            d[3] = __builtin_amdgcn_s_memrealtime() - r_start;
-        }
-        break;
+    pp_epilogue<8, ACT, EPI>(a, acc, smem, rowstat, colvec, rowpart, m0, n0, wr * 128, wc, wave, lane);
+    if (DLIMG_STAMPS(a) && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the wave's own stores have left
+        unsigned long long* d = DLIMG_STAMPS(a) + (size_t)blockIdx.x * 4;
+        d[0] = t_loop_end - t_loop;
+        d[1] = r_loop_end - r_loop;
+        d[2] = ((t_loop - t_start) << 32) | ((__builtin_amdgcn_s_memtime() - t_loop_end) & 0xffffffffull);   // prologue | epilogue cycles
+        d[3] = __builtin_amdgcn_s_memrealtime() - r_start;
     }
 }
 
@@ -1136,7 +1024,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(k::GemmArgs a) {
     const unsigned long long t_loop_end = DLIMG_STAMPS(a) ? __builtin_amdgcn_s_memtime() : 0ull;
     const unsigned long long r_loop_end = DLIMG_STAMPS(a) ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
-    pp_epilogue<4, ACT, EPI, PRE>(a, acc, smem + wave * 8192, 4096, rowstat, colvec, rowpart, m0, n0, wr * 64, wc, wave, lane, PRE ? rpre : nullptr);
+    pp_epilogue<4, ACT, EPI, PRE>(a, acc, smem, rowstat, colvec, rowpart, m0, n0, wr * 64, wc, wave, lane, PRE ? rpre : nullptr);
     if (DLIMG_STAMPS(a) && threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned long long* d = DLIMG_STAMPS(a) + (size_t)blockIdx.x * 4;
@@ -1199,35 +1087,13 @@ void launch(const k::GemmArgs& a, hipStream_t s, Timing t) {
     launch_flavour(kernels, attr_once, a, (a.M / BM) * (a.N / BN), 64 * WGM * WGN, lds, s, t);
 }
 
-// Grid of the persistent ping-pong kernel.  Up to one workgroup per CU the launch is one tile per workgroup, as before.
-// Beyond that (batched passes: two images give qkv 288 and fc1 384 tiles) the tiles are dealt evenly over the smallest
-// number of rounds: grid = ceil(tiles / ceil(tiles / 256)) -- 288 -> 144 workgroups with two tiles each, 384 -> 192,
-// 1152 -> 231 (five or four each).  The CUs a smaller grid leaves free are what the other lanes' kernels run on.
-int pp_grid(int tiles, int nk) {
-    if (tiles <= 256 || (nk & 1)) return tiles;          // (odd K tile count: the kernel does not chain tiles)
-#ifdef DLIMG_TUNING
-    static const bool chain = [] { const char* e = std::getenv("DLIMGEDIT_GEMM_PERSIST"); return !e || std::atoi(e) != 0; }();
-    if (!chain) return tiles;
-#endif
-    const int rounds = (tiles + 255) / 256;
-    return (tiles + rounds - 1) / rounds;
-}
-
 void launch_pp(const k::GemmArgs& a, hipStream_t s, Timing t) {
-    typedef void (*PPKernel)(k::GemmArgs, int);
-    static const PPKernel kernels[5] = {
+    static const GemmKernel kernels[5] = {
         gemm_pp_kernel<k::ACT_NONE, EPI_PLAIN>, gemm_pp_kernel<k::ACT_GELU, EPI_PLAIN>, gemm_pp_kernel<k::ACT_NONE, EPI_NORM>,
         gemm_pp_kernel<k::ACT_GELU, EPI_NORM>,  gemm_pp_kernel<k::ACT_NONE, EPI_STATS>,
     };
     static k::LdsOptIn attr_once[5];
-    const int index = a.stats_out ? 4 : (a.ln_stats ? 2 : 0) + (a.act == k::ACT_GELU ? 1 : 0);
-    attr_once[index].ensure((const void*)kernels[index], kPPLds, "gemm: the device refuses the LDS size of this tile configuration");
-    const int tiles = (a.M / 256) * (a.N / 256);
-    const int grid = pp_grid(tiles, a.K / 64);
-    if (t.start && t.stop)
-        hipExtLaunchKernelGGL(kernels[index], dim3(grid), dim3(512), kPPLds, s, t.start, t.stop, 0, a, tiles);
-    else
-        hipLaunchKernelGGL(kernels[index], dim3(grid), dim3(512), kPPLds, s, a, tiles);
+    launch_flavour(kernels, attr_once, a, (a.M / 256) * (a.N / 256), 512, kPPLds, s, t);
 }
 
 void launch_pp128(const k::GemmArgs& a, hipStream_t s, Timing t) {

@@ -390,12 +390,12 @@ def test_resize_reference_kat_on_device(ext):
 
 
 @pytest.mark.parametrize("N,K,act", [(2304, 128, 0), (3072, 256, 1), (1536, 1152, 0)])
-def test_gemm_persistent_tile_chain_is_bit_equal_to_single_tiles(ext, N, K, act):
-    """The ping-pong kernel chains several tiles per workgroup once a launch has more tiles than CUs (batched passes: two
-    images give qkv 288 and fc1 384 tiles of 256 x 256; kernels/gemm.hip, "PERSISTENT form").  Which workgroup computes a
-    tile must not enter the arithmetic: M = 16384 rows in one launch (576 / 768 / 384 tiles on 192 / 256 / 192 workgroups) against
-    the same rows as four launches of 4096 (one tile per workgroup), bit for bit, for the plain, the GELU and the
-    residual-stream flavours; and against the fp32 product."""
+def test_gemm_many_rounds_of_tiles_bit_equal_to_single_rounds(ext, N, K, act):
+    """Launches with more tiles than CUs (batched passes: two images give qkv 288 and fc1 384 tiles of 256 x 256, eight images
+    1152 / 1536) against the same rows in launches of one round: which workgroup (or, in the persistent form of r04 that
+    these tests were written for, which turn of a workgroup's tile loop) computes a tile must not enter the arithmetic.
+    M = 16384 rows in one launch (576 / 768 / 384 tiles) against four launches of 4096 rows, bit for bit, for the plain,
+    the GELU and the residual-stream flavours; and against the fp32 product."""
     ext.force_gemm_tile(9)
     rng = np.random.default_rng(N + K)
     M = 16384
@@ -412,10 +412,9 @@ def test_gemm_persistent_tile_chain_is_bit_equal_to_single_tiles(ext, N, K, act)
         assert np.array_equal(part32, whole32[rows]) and np.array_equal(part16, whole16[rows]), q
 
 
-def test_gemm_persistent_tile_chain_with_folded_layernorm(ext):
-    """The same for the LayerNorm-folded consumer (row statistics and column vectors of the NEXT tile are requested in the
-    middle of the current tile's epilogue and merged into the other parity of the auxiliary LDS area): 8192 rows, producer
-    96 tiles, consumer 288 tiles on 144 workgroups, against the two halves run on their own."""
+def test_gemm_many_rounds_of_tiles_with_folded_layernorm(ext):
+    """The same for the LayerNorm-folded consumer: 8192 rows (producer 96 tiles, consumer 288) against the two halves run on
+    their own -- row statistics are merged per tile from the producer's partials, so a half must see exactly its rows'."""
     ext.force_gemm_tile(9)
     rng = np.random.default_rng(99)
     M, D, K1, N = 8192, 768, 256, 2304
