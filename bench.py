@@ -312,6 +312,16 @@ def main() -> None:
             # kept as a contention diagnostic only
             "under_lanes": {"avg_gemm_launch_us": 1e3 * gl["ms"] / max(1, gl["launches"]),
                             "gemm_kernels_in_flight": gl["ms"] / lanes_wall_ms if lanes_wall_ms > 0 else 0.0,
+                            # every stage's own clocks with all lanes running (HIP events on the lanes' streams, no profiler:
+                            # rocprofv3's kernel trace runs the lanes' passes one after another on this pool, r04)
+                            "per_stage": {name: {"launches_per_step": v["launches"] / args.steps,
+                                                 "avg_launch_us": 1e3 * v["ms"] / v["launches"],
+                                                 "ms_per_step": v["ms"] / args.steps,
+                                                 "slowdown_vs_single_lane": (v["ms"] / v["launches"]) / (st[name]["ms"] / st[name]["launches"])
+                                                 if st[name]["launches"] and st[name]["ms"] > 0 else None}
+                                          for name, v in st_lanes.items() if v["launches"] and name not in flavours},
+                            "kernels_in_flight": sum(v["ms"] for name, v in st_lanes.items() if name not in flavours) / lanes_wall_ms
+                            if lanes_wall_ms > 0 else 0.0,
                             "note": "sum of the GEMM launches' durations / wall time of the profiled steps = GEMM kernels in "
                                     "flight on average; each holds a share of the CUs while it is clocked"},
         }

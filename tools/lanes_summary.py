@@ -15,8 +15,9 @@ import statistics
 import sys
 
 db = sqlite3.connect(sys.argv[1])
-images_per_block = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-flop_per_image = float(sys.argv[3]) if len(sys.argv) > 3 else (941.7e9 + 3.62e9)
+args = [x for x in sys.argv[2:] if not x.startswith('--')]
+images_per_block = int(args[0]) if len(args) > 0 else 8
+flop_per_image = float(args[1]) if len(args) > 1 else (941.7e9 + 3.62e9)
 tabs = [r[0] for r in db.execute("select name from sqlite_master where type in ('table','view')")]
 kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
 ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
@@ -25,7 +26,8 @@ gx, gy, wx, wy = (("grid_size_x", "grid_size_y", "workgroup_size_x", "workgroup_
                   else ("grid_x", "grid_y", "workgroup_x", "workgroup_y"))
 lds_col = next((c for c in ("lds_block_size", "group_segment_size", "lds_size") if c in cols), None)
 sel_lds = f", d.{lds_col}" if lds_col else ", 0"
-rows = db.execute(f"select d.start, d.end, (d.{gx} / d.{wx}) * (d.{gy} / d.{wy}), s.kernel_name{sel_lds} from {kd} d "
+lane_col = "stream_id" if "stream_id" in cols else "queue_id"
+rows = db.execute(f"select d.start, d.end, (d.{gx} / d.{wx}) * (d.{gy} / d.{wy}), s.kernel_name{sel_lds}, d.{lane_col} from {kd} d "
                   f"join {ks} s on d.kernel_id = s.id order by d.start").fetchall()
 blocks, cur = [], [rows[0]]
 for r in rows[1:]:
@@ -34,13 +36,28 @@ for r in rows[1:]:
         cur = []
     cur.append(r)
 blocks.append(cur)
-sizes = [len(b) for b in blocks]
-typical = statistics.median([n for n in sizes if n > 300]) if any(n > 300 for n in sizes) else max(sizes)
-timed = [b for b in blocks if abs(len(b) - typical) <= 0.1 * typical]
-timed = timed[len(timed) // 4: max(len(timed) // 4 + 1, 3 * len(timed) // 4)]          # the middle half: no warm-up, no profiled repeats
-print(f"{len(blocks)} blocks of kernels in the trace; {len(timed)} middle blocks of ~{int(typical)} kernels used "
-      f"({images_per_block} images per block)")
 
+
+def describe(b):
+    pre = sum(1 for r in b if "preprocess" in r[3])
+    lanes = len({r[5] for r in b})
+    return len(b), (max(r[1] for r in b) - b[0][0]) / 1e3, pre, lanes
+
+
+# the timed repeats of bench.py: blocks of `images_per_block` images (two per pass: images / 2 pre-processing launches) that
+# ran on several lanes; the single-lane profiled repeat has one lane, warm-up and the per-stage rates have other sizes
+want_pre = (images_per_block // 2, images_per_block)
+cand = [b for b in blocks if describe(b)[2] in want_pre and describe(b)[3] >= 3]
+if "--blocks" in sys.argv:
+    for i, b in enumerate(blocks):
+        n, w, pre, lanes = describe(b)
+        print(f"block {i:3d}: {n:5d} kernels {w:9.1f} us, {pre} pre-processing launches, {lanes} lanes")
+med = statistics.median([describe(b)[1] for b in cand]) if cand else 0.0
+timed = [b for b in cand if describe(b)[1] <= 1.3 * med]
+print(f"{len(blocks)} blocks of kernels in the trace; {len(cand)} look like timed repeats ({images_per_block} images on >= 3 lanes), "
+      f"{len(timed)} of them within 1.3 x the median wall time are used")
+if not timed:
+    raise SystemExit("no timed block found: run with --blocks to see what the trace holds")
 
 def short(name):
     name = name.replace("_ZN5dlimg12_GLOBAL__N_1", "").replace(".kd", "")
@@ -53,7 +70,7 @@ def short(name):
 wall = [(max(r[1] for r in b) - b[0][0]) / 1e3 for b in timed]          # us
 groups = {}
 for b in timed:
-    for a, e, wgs, name, lds in b:
+    for a, e, wgs, name, lds, _lane in b:
         per_cu = 1 if (lds and lds > 64 * 1024) else 2
         slots = min(float(wgs), 256.0 * per_cu) / per_cu
         g = groups.setdefault((short(name), int(wgs)), [0, 0.0, 0.0])
@@ -77,7 +94,7 @@ blk = timed[len(timed) // 2]
 t0, t1 = blk[0][0], max(r[1] for r in blk)
 bin_ns = 0.25e6
 occ = [0.0] * (int((t1 - t0) / bin_ns) + 1)
-for a, e, wgs, name, lds in blk:
+for a, e, wgs, name, lds, _lane in blk:
     per_cu = 1 if (lds and lds > 64 * 1024) else 2
     w = min(float(wgs), 256.0 * per_cu) / per_cu
     i = int((a - t0) / bin_ns)
