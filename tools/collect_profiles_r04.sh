@@ -17,7 +17,15 @@ timeout -k 10 250 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_
 timeout -k 10 250 rocprofv3 --kernel-trace --stats -d $O/st -o st --output-format csv -- $B > $O/st.log 2>&1 && echo stats ok
 S=$R/gpurun_out/r04_summary_$MODEL; rm -rf "$S"; mkdir -p "$S"
 FLOP=$(python3 -c "import sys; sys.path.insert(0, '$R'); from dlimgedit_amd.sam_config import get_config; print(get_config('$MODEL').encoder_flops() + 3.62e9)")
-python3 $R/tools/lanes_summary.py $O/kt/kt_results.db 8 $FLOP > $S/lanes_summary.txt 2>&1
+# the same trace of the timed region alone (bursts of 20 requests + synchronize): block structure is unambiguous there
+DLIMGEDIT_SAM_MODEL=$MODEL timeout -k 10 250 rocprofv3 --kernel-trace -d $O/ktb -o ktb -- python3 $R/tools/burst_trace.py 20 8 > $O/burst.log 2>&1 && echo burst ok
+{ echo "# rocprofv3 --kernel-trace of tools/burst_trace.py 20 8 ($MODEL): the timed region of bench.py (20 requests + synchronize)."
+  echo "# NOTE: under rocprofv3 on this pool the execution lanes' passes run ONE AFTER ANOTHER (see the per-lane pass starts"
+  echo "# below; the r03 library behaves the same): this is the profiler's regime, not the overlapped one 'value' is measured in."
+  echo "# The overlapped regime's own clocks are in the bench line: roofline.under_lanes (HIP events on the lanes' streams)."
+  grep "images/s" $O/burst.log
+  python3 $R/tools/trace_lanes.py $O/ktb/ktb_results.db 2>&1 | tail -5
+  python3 $R/tools/lanes_summary.py $O/ktb/ktb_results.db 20 $FLOP; } > $S/lanes_summary.txt 2>&1
 python3 $R/tools/kernel_stats.py $O/kt1/kt1_results.db 40 > $S/kernel_stats_single_lane.txt
 python3 $R/tools/kernel_stats.py $O/kt1/kt1_results.db 60 --by-grid > $S/kernel_stats_single_lane_by_grid.txt 2>&1
 python3 $R/tools/pmc_traffic.py $O/pmc_fetch/fetch_results.db $O/pmc_write/write_results.db $S/hbm_traffic_pmc.json "$B" > $S/traffic.log 2>&1
