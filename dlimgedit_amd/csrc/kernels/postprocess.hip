@@ -78,43 +78,81 @@ __global__ __launch_bounds__(256) void postprocess_identity_kernel(JobPack pack)
     }
     const int W = job.out_w, H = job.out_h;
     const int bw = (W + 3) >> 2, bh = (H + 3) >> 2;
-    const long total = (long)bw * bh;
+    // a thread takes FOUR vertically adjacent 4 x 4 blocks (16 rows x 4 columns of the mask): a quarter of the waves, and the
+    // 18 logits of its 6 x 3 neighbourhood are requested together instead of 9 per wave (r04: 16 masks per launch, inputs
+    // and outputs rotating through 768 MB so that they come from HBM: 21.5 us -> see DESIGN section 6)
+    const int bh4 = (bh + 3) >> 2;
+    const long total = (long)bw * bh4;
     const float wa[4] = {0.375f, 0.125f, 0.875f, 0.625f};      // weight of the first tap for p = 0..3
     const float wb[4] = {0.625f, 0.875f, 0.125f, 0.375f};      // weight of the second tap
     for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long)gridDim.x * 256) {
-        const int by = (int)(g / bw), bx = (int)(g % bw);
-        const int oy0 = by * 4, ox0 = bx * 4;
-        uint8_t* dst = job.dst + (size_t)oy0 * W + ox0;
-        const bool interior = by >= 1 && by <= LOW - 2 && bx >= 1 && bx <= LOW - 2 && oy0 + 4 <= H && ox0 + 4 <= W &&
-                              (((uintptr_t)dst | (uintptr_t)W) & 3) == 0;
-        if (interior) {
-            float v[3][3];
+        const int by4 = (int)(g / bw), bx = (int)(g % bw);
+        const int ox0 = bx * 4;
+        const bool cols_inside = bx >= 1 && bx <= LOW - 2 && ox0 + 4 <= W && (W & 3) == 0 && (((uintptr_t)job.dst) & 3) == 0;
+        const bool all_interior = cols_inside && by4 >= 1 && by4 * 4 + 3 <= LOW - 2 && by4 * 16 + 16 <= H;
+        if (all_interior) {
+            // logit rows by0 - 1 .. by0 + 4 (six), columns bx - 1 .. bx + 1: horizontal interpolation once per row
+            const int by0 = by4 * 4;
+            float hz[6][4];
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
+            for (int r = 0; r < 6; ++r) {
+                const float* row = low + (by0 - 1 + r) * LOW + (bx - 1);
+                const float v0 = row[0], v1 = row[1], v2 = row[2];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) v[r][c] = low[(by - 1 + r) * LOW + (bx - 1 + c)];
-            float hz[3][4];                      // horizontal interpolation of the three rows at the four x positions
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int c0 = p < 2 ? 0 : 1;
-                    hz[r][p] = __fadd_rn(__fmul_rn(v[r][c0], wa[p]), __fmul_rn(v[r][c0 + 1], wb[p]));
-                }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r0 = q < 2 ? 0 : 1;
-                uint32_t packed = 0;
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const float val = __fadd_rn(__fmul_rn(wa[q], hz[r0][p]), __fmul_rn(wb[q], hz[r0 + 1][p]));
-                    if (val > 0.f) packed |= 0xffu << (8 * p);
-                }
-                *reinterpret_cast<uint32_t*>(dst + (size_t)q * W) = packed;
+                for (int p = 0; p < 4; ++p) hz[r][p] = __fadd_rn(__fmul_rn(p < 2 ? v0 : v1, wa[p]), __fmul_rn(p < 2 ? v1 : v2, wb[p]));
             }
-        } else {
-            for (int q = 0; q < 4 && oy0 + q < H; ++q)
-                for (int p = 0; p < 4 && ox0 + p < W; ++p) dst[(size_t)q * W + p] = stage1(low, oy0 + q, ox0 + p) > 0.f ? 255 : 0;
+            uint8_t* dst = job.dst + (size_t)(by0 * 4) * W + ox0;
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r0 = sub + (q < 2 ? 0 : 1);
+                    uint32_t packed = 0;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const float val = __fadd_rn(__fmul_rn(wa[q], hz[r0][p]), __fmul_rn(wb[q], hz[r0 + 1][p]));
+                        if (val > 0.f) packed |= 0xffu << (8 * p);
+                    }
+                    *reinterpret_cast<uint32_t*>(dst + (size_t)(sub * 4 + q) * W) = packed;
+                }
+            continue;
+        }
+        for (int sub = 0; sub < 4; ++sub) {
+            const int by = by4 * 4 + sub;
+            if (by >= bh) break;
+            const int oy0 = by * 4;
+            uint8_t* dst = job.dst + (size_t)oy0 * W + ox0;
+            const bool interior = by >= 1 && by <= LOW - 2 && bx >= 1 && bx <= LOW - 2 && oy0 + 4 <= H && ox0 + 4 <= W &&
+                                  (((uintptr_t)dst | (uintptr_t)W) & 3) == 0;
+            if (interior) {
+                float v[3][3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) v[r][c] = low[(by - 1 + r) * LOW + (bx - 1 + c)];
+                float hz[3][4];                  // horizontal interpolation of the three rows at the four x positions
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const int c0 = p < 2 ? 0 : 1;
+                        hz[r][p] = __fadd_rn(__fmul_rn(v[r][c0], wa[p]), __fmul_rn(v[r][c0 + 1], wb[p]));
+                    }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r0 = q < 2 ? 0 : 1;
+                    uint32_t packed = 0;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const float val = __fadd_rn(__fmul_rn(wa[q], hz[r0][p]), __fmul_rn(wb[q], hz[r0 + 1][p]));
+                        if (val > 0.f) packed |= 0xffu << (8 * p);
+                    }
+                    *reinterpret_cast<uint32_t*>(dst + (size_t)q * W) = packed;
+                }
+            } else {
+                for (int q = 0; q < 4 && oy0 + q < H; ++q)
+                    for (int p = 0; p < 4 && ox0 + p < W; ++p) dst[(size_t)q * W + p] = stage1(low, oy0 + q, ox0 + p) > 0.f ? 255 : 0;
+            }
         }
     }
 }
@@ -183,7 +221,7 @@ void postprocess_masks(const PostJob* jobs, int count, hipStream_t s) {
             pack.j[i] = j;
             long g = (long)j.out_h * ((j.out_w + 3) / 4);
             if (g > max_groups) max_groups = g;
-            long b16 = (long)((j.out_h + 3) / 4) * ((j.out_w + 3) / 4);
+            long b16 = (long)((((j.out_h + 3) / 4) + 3) / 4) * ((j.out_w + 3) / 4);      // 16 x 4 pixels per thread
             if (b16 > max_blocks16) max_blocks16 = b16;
             all_identity = all_identity && j.pre_w == j.out_w && j.pre_h == j.out_h;
         }

@@ -315,3 +315,22 @@ def test_device_output_gather_config5_eighty_prompts(api, model_dirs, monkeypatc
     for s in segs:
         s.close()
     env.close()
+
+
+def test_batched_identity_postprocessing_on_ragged_extents(api, model_dirs):
+    """Launches of four or more masks whose second resize stage is the identity (longest side 1024) take the 16 x 4-pixels-per-thread
+    form of the post-processing kernel (kernels/postprocess.hip); one mask at a time takes the general per-pixel kernel.
+    Heights / widths that are not multiples of 16 or of 4 exercise its ragged bottom and right edges: bit-equal either way."""
+    mdir, _, _ = model_dirs("vit_test")
+    env = api.Environment(api.Options(api.Backend.gpu, mdir))
+    sizes = [(1024, 700), (600, 1024), (1024, 1022), (1024, 1024), (1022, 1024), (1024, 52)]
+    views = [api.ImageView(synthetic_image(90 + i, width=w, height=h), api.Channels.rgba) for i, (w, h) in enumerate(sizes)]
+    segs = api.Segmentation.process_batch(views, env)
+    pts = [api.Point(w // 2, h // 2) for (w, h) in sizes]
+    batch = api.Segmentation.compute_mask_batch(segs, points=pts)
+    for seg, p, got, (w, h) in zip(segs, pts, batch, sizes):
+        assert got.shape == (h, w)
+        assert np.array_equal(seg.compute_mask(p), got), (w, h)
+    for s in segs:
+        s.close()
+    env.close()
