@@ -338,3 +338,49 @@ def test_trained_like_activation_statistics(api, tmp_path_factory, monkeypatch, 
         env.close()
     # folding the LayerNorm in must not cost more than a small multiple of the separate kernels' own f16 error
     assert errs["1"] <= 3.0 * errs["0"] + 5e-3, errs
+
+
+def _hard_edged_image(seed: int, width: int = 1024, height: int = 1024) -> np.ndarray:
+    """A second family of synthetic inputs (every other test uses low-frequency sinusoids + noise): flat-coloured rectangles
+    and discs with hard edges on a gradient, saturated regions (0 and 255), a one-pixel checkerboard patch -- step
+    edges, clipping and the highest spatial frequency a patch embedding can see."""
+    rng = np.random.default_rng(5000 + seed)
+    yy, xx = np.mgrid[0:height, 0:width]
+    img = np.zeros((height, width, 4), np.uint8)
+    for c in range(3):
+        img[:, :, c] = (xx * (c + 1) * 255 // (3 * max(1, width - 1)) + yy * 40 // max(1, height - 1)).astype(np.uint8)
+    for _ in range(14):
+        x0, y0 = rng.integers(0, width - 40), rng.integers(0, height - 40)
+        w, h = rng.integers(30, 400), rng.integers(30, 400)
+        img[y0:y0 + h, x0:x0 + w, :3] = rng.integers(0, 256, 3)
+    for _ in range(8):
+        cx, cy, r = rng.integers(0, width), rng.integers(0, height), rng.integers(20, 180)
+        img[(xx - cx) ** 2 + (yy - cy) ** 2 < r * r, :3] = rng.integers(0, 256, 3)
+    img[100:260, 700:900, :3] = 255
+    img[800:960, 80:300, :3] = 0
+    img[400:528, 400:528, :3] = (((xx[400:528, 400:528] + yy[400:528, 400:528]) & 1) * 255)[:, :, None]
+    img[:, :, 3] = 255
+    return img
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_hard_edged_images_against_the_oracle(api, session, seed):
+    """Embedding, logits and masks on images with step edges, saturated areas and a one-pixel checkerboard (all other parity
+    tests use smooth images): same tolerances."""
+    from oracle import sam_oracle as O
+    env, params, cfg, *_ = session
+    img = _hard_edged_image(seed)
+    seg = api.Segmentation.process(api.ImageView(img, api.Channels.rgba), env)
+    ora = O.OracleSegmentation(params, cfg).process(img, O.CH_RGBA)
+    within(f"e2e.hard_edges.{seed}.embedding", np.abs(api.ext.get_embedding(seg) - ora.embedding).max(), EMB_TOL)
+    for name, gp, op in (("point", api.Point(450, 450), dict(point=(450, 450))), ("point2", api.Point(800, 180), dict(point=(800, 180))),
+                         ("box", api.Region(api.Point(60, 700), api.Point(420, 1000)), dict(region=(60, 700, 420, 1000)))):
+        got, got_iou = api.ext.get_logits(seg, **({"point": gp} if isinstance(gp, api.Point) else {"region": gp}))
+        want, want_iou = ora.logits(**op)
+        within(f"e2e.hard_edges.{seed}.{name}.logits", np.abs(got - want).max(), LOGIT_TOL)
+        within(f"e2e.hard_edges.{seed}.{name}.iou_pred", np.abs(got_iou - want_iou).max(), IOU_PRED_TOL)
+        got_mask, want_mask = seg.compute_mask(gp), ora.compute_mask(**op)
+        within(f"e2e.hard_edges.{seed}.{name}.differing_pixels", (got_mask != want_mask).mean(), 0.002)
+        if (want_mask > 0).mean() >= 0.02:          # IoU of a sliver says nothing
+            at_least(f"e2e.hard_edges.{seed}.{name}.mask_iou", iou(got_mask, want_mask), IOU_BAR)
+    seg.close()
