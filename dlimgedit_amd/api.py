@@ -392,6 +392,7 @@ class ext:
                 "dlimg_amd_test_preprocess": ([vp, ci, ci, ci, ci, vp], ci),
                 "dlimg_amd_test_postprocess": ([vp, ci, vp, ci, ci, vp], ci),
                 "dlimg_amd_test_force_gemm_tile": ([ci], ci),
+                "dlimg_amd_test_force_gemm_consumer_tile": ([ci], ci),
                 "dlimg_amd_test_gemm": ([ci, ci, ci, vp, vp, vp, vp, ci, ci, vp, vp], ci),
                 "dlimg_amd_test_gemm_ln": ([ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, cf, ci, vp, vp, vp], ci),
                 "dlimg_amd_test_layernorm": ([vp, vp, vp, cf, ci, ci, ci, vp, vp], ci),
@@ -421,7 +422,7 @@ class ext:
                "dlimg_amd_queue_config", "dlimg_amd_replica_count", "dlimg_amd_segmentation_device", "dlimg_amd_get_segmentation_masks_device",
                "dlimg_amd_set_profiling",
                "dlimg_amd_take_stage_stats", "dlimg_amd_test_preprocess", "dlimg_amd_test_postprocess",
-               "dlimg_amd_test_force_gemm_tile", "dlimg_amd_test_gemm", "dlimg_amd_test_gemm_ln", "dlimg_amd_test_layernorm", "dlimg_amd_test_attention", "dlimg_amd_test_resize",
+               "dlimg_amd_test_force_gemm_tile", "dlimg_amd_test_force_gemm_consumer_tile", "dlimg_amd_test_gemm", "dlimg_amd_test_gemm_ln", "dlimg_amd_test_layernorm", "dlimg_amd_test_attention", "dlimg_amd_test_resize",
                "dlimg_amd_birefnet_prepare_image", "dlimg_amd_birefnet_process_mask", "dlimg_amd_resize_mask",
                "dlimg_amd_bench_attention", "dlimg_amd_bench_prepost", "dlimg_amd_bench_gemm", "dlimg_amd_bench_gemm_streams", "dlimg_amd_bench_gemm_stamps")
 
@@ -609,9 +610,11 @@ class ext:
         return out
 
     @classmethod
-    def force_gemm_tile(cls, tile: int = -1) -> None:
-        """Tile configuration the GEMM test hooks use wherever it fits (-1: the product's own choice)."""
+    def force_gemm_tile(cls, tile: int = -1, consumer_tile: int = -1) -> None:
+        """Tile configuration the GEMM test hooks use wherever it fits (-1: the product's own choice); consumer_tile: a
+        separate one for the LayerNorm-folded consumer of test_gemm_ln."""
         _check(cls._l().dlimg_amd_test_force_gemm_tile(int(tile)))
+        _check(cls._l().dlimg_amd_test_force_gemm_consumer_tile(int(consumer_tile)))
 
     @classmethod
     def test_gemm(cls, A: np.ndarray, W: np.ndarray, bias=None, resid=None, act: int = 0, want_f16: bool = False):

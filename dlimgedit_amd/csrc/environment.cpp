@@ -193,7 +193,9 @@ EnvironmentImpl::SamLanes::SamLanes(std::string const& weight_path, int device, 
     // images in flight per GPU, measured on MI355X: ViT-B 3 -> 4 lanes +5 % (5-8 lanes worse); ViT-H 4 lanes -6 %
     // against 3 (its kernels already cover the chip)
     if (count <= 0) count = weights->geom_.embed_dim <= 768 ? 4 : 3;
-    for (int i = 0; i < count; ++i) lanes.push_back(std::make_unique<SamModel>(weights, i, count));
+    // the lanes of a GPU tell each other whether they have work in flight (sam_model.hpp, LaneBoard)
+    auto board = count > 1 ? std::make_shared<LaneBoard>(device, count) : nullptr;
+    for (int i = 0; i < count; ++i) lanes.push_back(std::make_unique<SamModel>(weights, i, count, board));
 }
 
 EnvironmentImpl::SamLanes& EnvironmentImpl::lanes(int replica) {

@@ -60,8 +60,10 @@ template <typename T> void download(T* host, T const* dev, size_t n) {
 // kernels/gemm.hip in the single-kernel hooks below wherever it fits the problem.  An explicit call, not an environment
 // variable: nothing outside the test hooks can steer the product's tile choice.
 std::atomic<int> g_forced_test_tile{-1};
+std::atomic<int> g_forced_consumer_tile{-1};     // LayerNorm-folded consumers only; -1: as g_forced_test_tile
 void apply_forced_tile(k::GemmArgs& g) {
-    const int t = g_forced_test_tile.load(std::memory_order_relaxed);
+    const int consumer = g_forced_consumer_tile.load(std::memory_order_relaxed);
+    const int t = (g.ln_stats && consumer >= 0) ? consumer : g_forced_test_tile.load(std::memory_order_relaxed);
     if (t < 0 || g.tile >= 0) return;
     if (k::gemm_tile_fits(g, t)) g.tile = t;
 }
@@ -539,6 +541,12 @@ DLIMG_API int dlimg_amd_test_postprocess(float const* planes, int n_planes, floa
 
 DLIMG_API int dlimg_amd_test_force_gemm_tile(int tile) {
     g_forced_test_tile.store(tile < 0 ? -1 : tile, std::memory_order_relaxed);
+    g_forced_consumer_tile.store(-1, std::memory_order_relaxed);
+    return 0;
+}
+
+DLIMG_API int dlimg_amd_test_force_gemm_consumer_tile(int tile) {
+    g_forced_consumer_tile.store(tile < 0 ? -1 : tile, std::memory_order_relaxed);
     return 0;
 }
 

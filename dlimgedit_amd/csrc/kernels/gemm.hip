@@ -881,14 +881,23 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(k::GemmArgs a) {
 // reader was group 1 in slot 2t-1.  [Two A buffers would do only with the A request of tile t+2 issued after BOTH
 // groups have read tile t, i.e. in a second read slot.]
 // vmcnt(6): the six requests of tile t+2 issued in this slot may stay in flight, everything older has landed.
-constexpr int kPP128WBase = 3 * kPPHalfBytes;                        // A buffers first
-constexpr int kPP128Operands = 3 * kPPHalfBytes + 3 * 2 * kPPHalfBytes;   // 144 KB
-constexpr int kPP128Aux = 128 * 8 + 2 * 256 * 4 + 128 * 4 * 8;
-constexpr int kPP128Lds = kPP128Operands + kPP128Aux;
+// r04: the same kernel with BM = 64 (a wave owns 32 x 64: two A row tiles, 16 MFMAs per K tile): the N = 768 GEMMs of ONE
+// image then make 192 workgroups instead of 96.  Its main loop is bound by the LDS-DMA intake like the 128-row one (40 KB per
+// K tile for half the FLOPs), i.e. it costs ~1.7 x the CU time per FLOP -- the wrong trade while other lanes share the chip,
+// the right one for a pass that has the GPU to itself (a synchronous caller of slots 3 / 4: fc2 41 -> ~28 us, proj 18 -> ~10).
+// Same BN, MFMA, K order, epilogue arithmetic and 64-column statistics groups: the bits do not depend on BM.
+constexpr int pp128_a_bytes(int bm) { return bm * 128; }                  // one A buffer: bm rows x 64 halves
+constexpr int pp128_w_base(int bm) { return 3 * pp128_a_bytes(bm); }      // A buffers first
+constexpr int pp128_operands(int bm) { return 3 * pp128_a_bytes(bm) + 3 * 2 * kPPHalfBytes; }   // 144 KB / 120 KB
+constexpr int pp128_lds(int bm) { return pp128_operands(bm) + bm * 8 + 2 * 256 * 4 + bm * 4 * 8; }
 
-template <int ACT, int EPI>
+template <int BM, int ACT, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(k::GemmArgs a) {
-    constexpr int BM = 128, BN = 256;
+    static_assert(BM == 128 || BM == 64, "128 or 64 rows per tile");
+    constexpr int BN = 256;
+    constexpr int NI = BM / 32;                  // 16-row accumulator tiles per wave (the group's BM / 2 rows)
+    constexpr int APIECES = BM / 64;             // DMA wave-instructions per wave for one A tile (8 rows each)
+    constexpr int LOADS = 4 + APIECES;           // ... for one K tile: W half 0, W half 1, A
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = lane_id();
     const int wave = wave_id();
@@ -901,33 +910,38 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(k::GemmArgs a) {
     const int n0 = (tile % ntn) * BN;
     const int nk = a.K / 64;
 
-    float* rowstat = reinterpret_cast<float*>(smem + kPP128Operands);
+    float* rowstat = reinterpret_cast<float*>(smem + pp128_operands(BM));
     float* colvec = rowstat + 2 * BM;
     float2_t* rowpart = reinterpret_cast<float2_t*>(colvec + 2 * BN);
 
-    float4v acc[4][4];
+    float4v acc[NI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
 
-    const half_t* src_a[2];
+    const half_t* src_a[APIECES];
     const half_t* src_w[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int row = (wave * 2 + q) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        src_a[q] = a.A + (size_t)(m0 + row) * a.lda + chunk * 8;
         src_w[q] = a.W + (size_t)(n0 + row) * a.ldw + chunk * 8;
+    }
+#pragma unroll
+    for (int q = 0; q < APIECES; ++q) {          // piece p = APIECES * wave + q of the A tile = rows 8p .. 8p+7
+        const int row = (wave * APIECES + q) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        src_a[q] = a.A + (size_t)(m0 + row) * a.lda + chunk * 8;
     }
     const size_t w_half = (size_t)128 * a.ldw;
     auto stage_a = [&](int t, int abuf) {
-        char* dst = smem + abuf * kPPHalfBytes + wave * 2048;
+        char* dst = smem + abuf * pp128_a_bytes(BM) + wave * (APIECES * 1024);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) glds16(src_a[q] + (size_t)t * 64, dst + q * 1024);
+        for (int q = 0; q < APIECES; ++q) glds16(src_a[q] + (size_t)t * 64, dst + q * 1024);
     };
     auto stage_w = [&](int t, int wbuf, int h) {
-        char* dst = smem + kPP128WBase + (wbuf * 2 + h) * kPPHalfBytes + wave * 2048;
+        char* dst = smem + pp128_w_base(BM) + (wbuf * 2 + h) * kPPHalfBytes + wave * 2048;
 #pragma unroll
         for (int q = 0; q < 2; ++q) glds16(src_w[q] + h * w_half + (size_t)t * 64, dst + q * 1024);
     };
@@ -935,8 +949,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(k::GemmArgs a) {
     const int sw = (l15 >> 1) & 7;
     const int off0 = l15 * 128 + ((quad ^ sw) << 4);
     const int off1 = l15 * 128 + (((quad ^ sw) ^ 4) << 4);
-    const char* a_base = smem + wr * 64 * 128;                                               // + A buffer + i * 2048
-    const char* w_base = smem + kPP128WBase + (wc >> 1) * kPPHalfBytes + (wc & 1) * 64 * 128;  // + W buffer + (nh*32 + j*16)*128
+    const char* a_base = smem + wr * (BM / 2) * 128;                                         // + A buffer + i * 2048
+    const char* w_base = smem + pp128_w_base(BM) + (wc >> 1) * kPPHalfBytes + (wc & 1) * 64 * 128;  // + W buffer + (nh*32 + j*16)*128
     auto frag = [&](const char* p) { return *reinterpret_cast<const half8_t*>(p); };
 
     ColumnVectors<BM, BN, 512, EPI> column_vectors;
@@ -948,37 +962,37 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(k::GemmArgs a) {
     if (nk > 1) { stage_a(1, 1); stage_w(1, 1, 0); stage_w(1, 1, 1); }
     column_vectors.store(colvec);
     row_stats.finish(a, rowstat);
-    if (nk > 1) wait_dma<6>(); else wait_dma<0>();
+    if (nk > 1) wait_dma<LOADS>(); else wait_dma<0>();
     // Stream writers: the residual of the wave's 64 x 64 part (64 registers, which this tile can afford) is requested
     // now and used in the epilogue.  These requests are younger than everything the main loop's counted waits must
     // see landed, and in-order completion means they can only make those waits stricter while they are in flight.
     constexpr bool PRE = EPI == EPI_STATS;
-    float4_t rpre[4][4];
+    float4_t rpre[NI][4];
     if (PRE) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) rpre[i][kk] = float4_t{0.f, 0.f, 0.f, 0.f};
-        if (a.resid) {                           // one uniform branch around all sixteen requests
+        if (a.resid) {                           // one uniform branch around all the requests
             const int resid_row0 = m0 % a.resid_mod;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk)
                     rpre[i][kk] = *reinterpret_cast<const float4_t*>(
-                        a.resid + (size_t)(resid_row0 + wr * 64 + i * 16 + kk * 4 + (lane >> 4)) * a.ldr + n0 + wc * 64 + (lane & 15) * 4);
+                        a.resid + (size_t)(resid_row0 + wr * (BM / 2) + i * 16 + kk * 4 + (lane >> 4)) * a.ldr + n0 + wc * 64 + (lane & 15) * 4);
         }
     }
     pp_barrier();
     if (wr == 1) pp_barrier();
 
-    half8_t fa[4][2], fw[4][2];                  // A: [i][ks]; W: [column tile j of the wave's 64][ks]
+    half8_t fa[NI][2], fw[4][2];                 // A: [i][ks]; W: [column tile j of the wave's 64][ks]
     auto mfma_tile = [&] {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[j][ks], fa[i][ks], acc[i][j], 0, 0, 0);
@@ -987,7 +1001,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(k::GemmArgs a) {
     int buf3 = 0;                                // t % 3
     auto step = [&](int t, auto steady_tag) {
         constexpr bool STEADY = decltype(steady_tag)::value;
-        const char* ab = a_base + buf3 * kPPHalfBytes;
+        const char* ab = a_base + buf3 * pp128_a_bytes(BM);
         const char* wb = w_base + buf3 * 2 * kPPHalfBytes;
         const int next2 = buf3 == 0 ? 2 : buf3 - 1;      // (t + 2) % 3
 #pragma unroll
@@ -996,7 +1010,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(k::GemmArgs a) {
             fw[j][1] = frag(wb + j * 2048 + off1);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             fa[i][0] = frag(ab + i * 2048 + off0);
             fa[i][1] = frag(ab + i * 2048 + off1);
         }
@@ -1005,7 +1019,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(k::GemmArgs a) {
             stage_w(t + 2, next2, 1);
             stage_a(t + 2, next2);
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0) vmcnt(6)\n\ts_barrier" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0) vmcnt(%0)\n\ts_barrier" ::"n"(LOADS) : "memory");
         } else {
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1024,7 +1038,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(k::GemmArgs a) {
     const unsigned long long t_loop_end = DLIMG_STAMPS(a) ? __builtin_amdgcn_s_memtime() : 0ull;
     const unsigned long long r_loop_end = DLIMG_STAMPS(a) ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
-    pp_epilogue<4, ACT, EPI, PRE>(a, acc, smem, rowstat, colvec, rowpart, m0, n0, wr * 64, wc, wave, lane, PRE ? rpre : nullptr);
+    pp_epilogue<NI, ACT, EPI, PRE>(a, acc, smem, rowstat, colvec, rowpart, m0, n0, wr * (BM / 2), wc, wave, lane, PRE ? rpre : nullptr);
     if (DLIMG_STAMPS(a) && threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned long long* d = DLIMG_STAMPS(a) + (size_t)blockIdx.x * 4;
@@ -1096,14 +1110,15 @@ void launch_pp(const k::GemmArgs& a, hipStream_t s, Timing t) {
     launch_flavour(kernels, attr_once, a, (a.M / 256) * (a.N / 256), 512, kPPLds, s, t);
 }
 
+template <int BM>
 void launch_pp128(const k::GemmArgs& a, hipStream_t s, Timing t) {
     static const GemmKernel kernels[5] = {
-        gemm_pp128_kernel<k::ACT_NONE, EPI_PLAIN>, gemm_pp128_kernel<k::ACT_GELU, EPI_PLAIN>,
-        gemm_pp128_kernel<k::ACT_NONE, EPI_NORM>,  gemm_pp128_kernel<k::ACT_GELU, EPI_NORM>,
-        gemm_pp128_kernel<k::ACT_NONE, EPI_STATS>,
+        gemm_pp128_kernel<BM, k::ACT_NONE, EPI_PLAIN>, gemm_pp128_kernel<BM, k::ACT_GELU, EPI_PLAIN>,
+        gemm_pp128_kernel<BM, k::ACT_NONE, EPI_NORM>,  gemm_pp128_kernel<BM, k::ACT_GELU, EPI_NORM>,
+        gemm_pp128_kernel<BM, k::ACT_NONE, EPI_STATS>,
     };
     static k::LdsOptIn attr_once[5];
-    launch_flavour(kernels, attr_once, a, (a.M / 128) * (a.N / 256), 512, kPP128Lds, s, t);
+    launch_flavour(kernels, attr_once, a, (a.M / BM) * (a.N / 256), 512, pp128_lds(BM), s, t);
 }
 
 }  // namespace
@@ -1147,6 +1162,7 @@ constexpr TileCfg kTiles[] = {
     {256, 256, 1, 1.60f},   // 9: ping-pong kernel (gemm_pp_kernel): 8 waves in two groups one barrier apart, BK 64
                             //    (4096^3: 1300 TFLOP/s at the 1.4 GHz the chip holds under that load)
     {128, 256, 1, 0.00f},   // 10: 128 x 256 ping-pong kernel (gemm_pp128_kernel), one read slot + one MFMA slot per K tile
+    {64, 256, 1, 0.00f},    // 11: the same kernel with 64-row tiles: twice the workgroups for a pass that has the GPU to itself
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -1174,8 +1190,14 @@ int gemm_pick_tile(const GemmArgs& a) {
     // the remaining CUs that is worth having even when they cover a quarter of the chip (ViT-H proj / fc2: 80
     // workgroups, +2 % images/s; at 48, ViT-B proj / fc2, the longer kernel costs more than it frees)
     if (shared && forced < 0 && unit % 256 == 0 && a.N % 256 == 0 &&
-        (unit / 256) * (a.N / 256) >= 64 && !wraps_inside(256))
+        (unit / 256) * (a.N / 256) >= 64 && !wraps_inside(256)) {
+        // one image with the GPU to itself and fewer than half the CUs covered (ViT-H's proj / fc2: 80 tiles): the
+        // 128-row tiles double the workgroups (160); same bits for a stream writer (not for a LayerNorm-folded consumer)
+        if (a.alone && !a.ln_stats && a.M == unit && (unit / 256) * (a.N / 256) < 128 && (unit / 128) * (a.N / 256) <= 256 &&
+            !wraps_inside(128))
+            return 10;
         return 9;
+    }
     // The same with the rows of a whole BATCHED pass (several images stacked in M): two images give ViT-B's proj / fc2
     // 96 tiles of 256 x 256.  Tiles 9 and 10 compute the same bits (BN = 256, the same MFMA, K order, epilogue
     // arithmetic and 64-column statistics groups), so the result does not depend on which one a pass uses -- the
@@ -1190,7 +1212,14 @@ int gemm_pick_tile(const GemmArgs& a) {
 #endif
     if (use_pp128 && shared && forced < 0 && unit % 128 == 0 && a.N % 256 == 0 && (unit / 128) * (a.N / 256) >= 64 &&
         !wraps_inside(128)) {
+        // (not for a LayerNorm-folded consumer: its row statistics are merged in an order that depends on the tile height
+        // -- RowStats, threads per row -- so a consumer that lands in this branch keeps tile 10 whatever the pass looks like;
+        // ViT-B / L / H consumers never do: their N gives >= 64 tiles of 256 x 256)
+        if (a.ln_stats) return 10;
         if (batch_pp && a.M % 256 == 0 && (a.M / 256) * (a.N / 256) >= 96 && !wraps_inside(256)) return 9;
+        // one image with the GPU to itself: 64-row tiles while they still fit the chip in one round (ViT-B's patch / proj /
+        // fc2: 96 -> 192 workgroups; ViT-H's 160 would become 320, more than one round: stays)
+        if (a.alone && a.M == unit && unit % 64 == 0 && (unit / 64) * (a.N / 256) <= 256 && !wraps_inside(64)) return 11;
         return 10;
     }
     for (int i = 0; i < kNumTiles; ++i) {
@@ -1235,7 +1264,8 @@ void gemm(const GemmArgs& a, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
     case 7: return launch16<256, 256, 2, 4, 4, 2>(a, s, t);
     case 8: return launch16<128, 128, 2, 2, 4, 2>(a, s, t);
     case 9: return launch_pp(a, s, t);
-    case 10: return launch_pp128(a, s, t);
+    case 10: return launch_pp128<128>(a, s, t);
+    case 11: return launch_pp128<64>(a, s, t);
     default: throw_error("gemm: no tile configuration fits this shape");
     }
 }

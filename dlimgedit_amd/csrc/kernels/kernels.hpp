@@ -65,6 +65,10 @@ struct GemmArgs {
     // CU).  tile: -1 = let gemm() choose; gemm_choose_tile() fixes the choice in the arguments so that a caller who
     // needs the tile width beforehand (stats_out layout) and the launch agree by construction.
     bool shared_gpu = false;
+    // alone: the pass this GEMM belongs to has the GPU to itself (no other lane has work in flight: a synchronous caller).
+    // A one-image launch may then use tiles that double its workgroups at a worse cost per FLOP (gemm.hip, tile 11);
+    // the bits do not depend on it.
+    bool alone = false;
     int tile = -1;
     // Rows of ONE independent unit (an image: 4096 tokens) when M stacks several of them.  The tile is chosen for the
     // unit's shape, so a batch runs the same tiles -- and produces the same bits -- as its images one at a time.

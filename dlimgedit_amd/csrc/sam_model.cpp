@@ -267,8 +267,40 @@ SamWeights::SamWeights(std::string const& weight_path, int device_index) : devic
     HIP_CHECK(hipStreamDestroy(stream_));
 }
 
-SamModel::SamModel(std::shared_ptr<SamWeights const> weights, int lane_index, int lane_count)
-    : device_(weights->device), shared_gpu_(lane_count > 1), weights_(std::move(weights)) {
+LaneBoard::LaneBoard(int device, int lanes) : armed_(new std::atomic<bool>[std::max(1, lanes)]) {
+    HIP_CHECK(hipSetDevice(device));
+    for (int i = 0; i < lanes; ++i) {
+        hipEvent_t e = nullptr;
+        HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        marker_.push_back(e);
+        armed_[i].store(false);
+    }
+}
+
+LaneBoard::~LaneBoard() {
+    for (hipEvent_t e : marker_) (void)hipEventDestroy(e);
+}
+
+void LaneBoard::mark(int lane, hipStream_t stream) {
+    if (lane < 0 || lane >= (int)marker_.size()) return;
+    HIP_CHECK(hipEventRecord(marker_[lane], stream));
+    armed_[lane].store(true, std::memory_order_release);
+}
+
+bool LaneBoard::others_idle(int lane) const {
+    for (int i = 0; i < (int)marker_.size(); ++i) {
+        if (i == lane || !armed_[i].load(std::memory_order_acquire)) continue;
+        const hipError_t st = hipEventQuery(marker_[i]);
+        if (st == hipErrorNotReady) return false;
+        if (st != hipSuccess) (void)hipGetLastError();      // not this call's problem: treated as "busy" is the safe answer
+        if (st != hipSuccess) return false;
+    }
+    return true;
+}
+
+SamModel::SamModel(std::shared_ptr<SamWeights const> weights, int lane_index, int lane_count, std::shared_ptr<LaneBoard> board)
+    : device_(weights->device), shared_gpu_(lane_count > 1), board_(std::move(board)), lane_index_(lane_index),
+      weights_(std::move(weights)) {
     HIP_CHECK(hipSetDevice(device_));
     {
         // The runtime multiplexes streams of one priority onto its hardware queues, shared with the host's other streams.
@@ -376,6 +408,7 @@ template <typename F> void SamModel::timed(Stage st, double work, F&& launch) {
 void SamModel::gemm(k::GemmArgs const& args) {
     k::GemmArgs a = args;
     a.shared_gpu = shared_gpu_;
+    a.alone = alone_;
     a.unit_rows = kTokens;
     if (!profiling_) {
         k::gemm(a, stream_);
@@ -497,11 +530,24 @@ void SamModel::upload_image(int slot, int batch, uint8_t const* pixels, int w, i
     const size_t slot_bytes = (size_t)kImageSize * kImageSize * 4;
     // Rows are packed on the way (the reference's create_image_tensor assumes packed rows when no
     // resize happens, segmentation.cpp:81-106; honouring the stride is identical for packed views).
-    hipEvent_t copied = nullptr;
-    uint8_t* pin = stage_rows(pixels, row, h, stride, &copied);
+    // In pieces of ~1 MiB: piece i crosses PCIe while the host packs piece i + 1 into the pinned area (a 4 MiB image:
+    // 0.30 -> ~0.2 ms of a synchronous caller's 2.6 ms per image; one piece for small images)
+    ImageStage& st = stage_[stage_seq_++ % kStageRing];
+    HIP_CHECK(hipEventSynchronize(st.copied));       // the copy that last read this entry has run
+    st.pin.reserve(row * h);                         // (re-allocation is safe for the same reason)
+    uint8_t* pin = static_cast<uint8_t*>(st.pin.get());
     uint8_t* dev = img_dev_.get() + slot * slot_bytes;
-    HIP_CHECK(hipMemcpyAsync(dev, pin, row * h, hipMemcpyHostToDevice, stream_));
-    HIP_CHECK(hipEventRecord(copied, stream_));
+    const int pieces = (int)std::min<size_t>(8, std::max<size_t>(1, row * h / (1u << 20)));
+    for (int p = 0; p < pieces; ++p) {
+        const int y0 = (int)((long)h * p / pieces), y1 = (int)((long)h * (p + 1) / pieces);
+        if ((size_t)stride == row) {
+            std::memcpy(pin + (size_t)y0 * row, pixels + (size_t)y0 * stride, row * (size_t)(y1 - y0));
+        } else {
+            for (int y = y0; y < y1; ++y) std::memcpy(pin + (size_t)y * row, pixels + (size_t)y * stride, row);
+        }
+        HIP_CHECK(hipMemcpyAsync(dev + (size_t)y0 * row, pin + (size_t)y0 * row, row * (size_t)(y1 - y0), hipMemcpyHostToDevice, stream_));
+    }
+    HIP_CHECK(hipEventRecord(st.copied, stream_));
     preprocess_device_image(slot, batch, dev, w, h, (int)row, channels);
 }
 
@@ -575,6 +621,9 @@ void SamModel::upload_and_resize_image(int slot, int batch, uint8_t const* pixel
 void SamModel::encode(int batch, float* const* emb_dst) {
     SamWeights const& W = *weights_;
     DLIMG_ASSERT(batch > 0 && batch <= enc_batch_);
+    // one image, and no other lane of this GPU has anything in flight: the pass may trade CU time for latency
+    alone_ = batch == 1 && shared_gpu_ && board_ && board_->others_idle(lane_index_);
+    mark_activity();                             // from here on this lane counts as busy for its siblings
     const int D = W.geom_.embed_dim, H = W.geom_.num_heads, hd = W.geom_.head_dim(), mlp = W.geom_.mlp_dim;
     const int M = batch * kTokens;
 
@@ -591,6 +640,7 @@ void SamModel::encode(int batch, float* const* emb_dst) {
         if (fused) {
             a.out_h = xn_.get(); a.ldc16 = D; a.stats_out = xstat_.get();
             a.shared_gpu = shared_gpu_;
+            a.alone = alone_;
             a.unit_rows = kTokens;
             stat_groups = D / k::gemm_choose_tile(a);    // the launch below uses exactly this tile (a.tile)
         }
@@ -679,6 +729,7 @@ void SamModel::encode(int batch, float* const* emb_dst) {
                 HIP_CHECK(hipMemcpyAsync(emb_dst[i], emb_.get() + i * n, n * sizeof(float), hipMemcpyDeviceToDevice, stream_));
     }
     HIP_CHECK(hipGetLastError());     // a refused launch (bad grid, LDS size) is reported here, not at a later sync
+    mark_activity();                  // behind the last kernel of the pass
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -717,6 +768,7 @@ void SamModel::decode(float const* const* emb, float const* coords, float const*
     constexpr int kChunk = 16;
     for (int c0 = 0; c0 < count; c0 += kChunk)
         decode_chunk(emb + c0, coords + (size_t)c0 * 4, labels + (size_t)c0 * 2, std::min(kChunk, count - c0), c0);
+    mark_activity();
 }
 
 void SamModel::decode_chunk(float const* const* emb, float const* coords, float const* labels, int count, int first) {
@@ -848,6 +900,7 @@ void SamModel::masks_on_device(k::PostJob const* jobs, int count) {
     double bytes = 0;
     for (int i = 0; i < count; ++i) bytes += (double)kLowRes * kLowRes * 4 + (double)jobs[i].out_w * jobs[i].out_h;
     timed(ST_POST, bytes, [&] { k::postprocess_masks(jobs, count, stream_); });
+    mark_activity();
 }
 
 SamModel::MaskSlot& SamModel::acquire_mask_slot() {
@@ -911,6 +964,7 @@ void SamModel::enqueue_masks(MaskSlot& slot, k::PostJob const* jobs, int count, 
         a = b;
     }
     HIP_CHECK(hipEventRecord(slot.done, stream_));
+    mark_activity();
 }
 
 void SamModel::finish_masks(MaskSlot& slot, k::PostJob const* jobs, int count, float* iou_out, int iou_count) {

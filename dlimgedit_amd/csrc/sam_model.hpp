@@ -109,13 +109,34 @@ struct StageStats {
     long launches[ST_COUNT] = {0};
 };
 
+// Which execution lanes of a GPU have work in flight: one marker event per lane, re-recorded behind everything the lane
+// enqueues (encode, decode, mask transfer).  A lane that starts an encoder pass asks whether every OTHER lane's marker has
+// been reached: then the pass has the GPU to itself -- the situation of a synchronous caller of slots 3 / 4, which is what
+// every existing user of the reference is (/root/reference/src/include/dlimgedit/detail/dlimgedit.impl.hpp:70-116) -- and
+// its one-image GEMMs may trade CU time for latency (kernels/gemm.hip, tile 11).  hipEventQuery on an event another
+// thread is re-recording is allowed; a stale answer only costs or gains a tile choice, never a result (same bits).
+class LaneBoard {
+  public:
+    LaneBoard(int device, int lanes);
+    ~LaneBoard();
+    LaneBoard(LaneBoard const&) = delete;
+    LaneBoard& operator=(LaneBoard const&) = delete;
+    void mark(int lane, hipStream_t stream);
+    bool others_idle(int lane) const;
+
+  private:
+    std::vector<hipEvent_t> marker_;
+    std::unique_ptr<std::atomic<bool>[]> armed_;
+};
+
 class SamModel {
   public:
     // One execution lane: own stream, workspaces and staging buffers over shared weights.  Several lanes
     // let independent images overlap on the GPU (tails and small kernels of one image hide behind the
     // large kernels of another) -- the serving counterpart of the reference's "Environment is
     // thread-safe" contract (reference: src/include/dlimgedit/dlimgedit.hpp:98-101).
-    explicit SamModel(std::shared_ptr<SamWeights const> weights, int lane_index = 0, int lane_count = 1);
+    explicit SamModel(std::shared_ptr<SamWeights const> weights, int lane_index = 0, int lane_count = 1,
+                      std::shared_ptr<LaneBoard> board = nullptr);
     ~SamModel();
     SamModel(SamModel const&) = delete;
     SamModel& operator=(SamModel const&) = delete;
@@ -208,6 +229,10 @@ class SamModel {
 
     int device_ = 0;
     bool shared_gpu_ = false;            // other lanes run on this device too (GEMM tile choice, kernels/gemm.hip)
+    std::shared_ptr<LaneBoard> board_;   // activity of the sibling lanes (null: a lane on its own)
+    int lane_index_ = 0;
+    bool alone_ = false;                 // the encoder pass being enqueued found every other lane idle (set by encode())
+    void mark_activity() { if (board_) board_->mark(lane_index_, stream_); }
     hipStream_t stream_ = nullptr;
     std::mutex mutex_;
 

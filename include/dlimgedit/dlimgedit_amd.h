@@ -123,6 +123,9 @@ DLIMG_API int dlimg_amd_test_postprocess(float const* planes, int n_planes, floa
 /* Forces tile configuration `tile` (index into kernels/gemm.hip's table; < 0: off) in the GEMM test hooks below wherever it
  * fits the problem.  Affects only dlimg_amd_test_gemm / dlimg_amd_test_gemm_ln / the bench hooks, never the product path. */
 DLIMG_API int dlimg_amd_test_force_gemm_tile(int tile);
+/* A separate tile for the LayerNorm-folded consumer GEMM of dlimg_amd_test_gemm_ln (< 0: the one forced above); reset by
+ * every dlimg_amd_test_force_gemm_tile call. */
+DLIMG_API int dlimg_amd_test_force_gemm_consumer_tile(int tile);
 /* C = epilogue(A[M,K] . W[N,K]^T): bias[N], resid[resid_rows][N] (row m % resid_rows), act 0/1(GELU). */
 DLIMG_API int dlimg_amd_test_gemm(int M, int N, int K, uint16_t const* A, uint16_t const* W, float const* bias,
                                   float const* resid, int resid_rows, int act, float* out_f32, uint16_t* out_f16);

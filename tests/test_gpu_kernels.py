@@ -167,7 +167,9 @@ def test_gemm_parity(ext, M, N, K, act, with_bias, resid_rows):
                                         (9, 512, 512, 192), (9, 256, 256, 64), (9, 256, 512, 128), (9, 512, 256, 448),
                                         (9, 768, 512, 1024),
                                         (10, 256, 512, 192), (10, 128, 256, 64), (10, 384, 256, 448), (10, 256, 768, 1024),
-                                        (10, 128, 256, 128)])
+                                        (10, 128, 256, 128),
+                                        (11, 192, 512, 192), (11, 64, 256, 64), (11, 320, 256, 448), (11, 128, 768, 1024),
+                                        (11, 64, 256, 128)])
 def test_gemm_every_tile_configuration(ext, monkeypatch, tile, M, N, K):
     """Each tile configuration (waves layout, K-tile, pipeline depth) against the fp32 product, incl. K tails
     shorter than the pipeline depth."""
@@ -204,6 +206,8 @@ def test_gemm_identity_layout(ext):
     (4096, 768, 768, 2304, 0, 9),          # ... at ViT-B's proj -> LN1 -> qkv
     (512, 1024, 256, 512, 1, 10),          # 128x256 ping-pong kernel on both sides
     (4096, 768, 3072, 768, 0, 10),         # ... as ViT-B's fc2 (producer of the stream and its statistics)
+    (512, 1024, 256, 512, 1, 11),          # 64x256 ping-pong kernel on both sides
+    (4096, 768, 3072, 768, 0, 11),         # ... as ViT-B's fc2 when a pass has the GPU to itself
     (256, 256, 128, 256, 0, 2),
     (256, 256, 128, 384, 0, 8),
 ])
@@ -432,3 +436,30 @@ def test_gemm_many_rounds_of_tiles_with_folded_layernorm(ext):
             rows = slice(h * 4096, (h + 1) * 4096)
             xp, xhp, yp = ext.test_gemm_ln(A1[rows], W1, b1, resid[rows], W2, gamma, beta, b2, 1e-6, act)
             assert np.array_equal(xp, x[rows]) and np.array_equal(xhp, xh[rows]) and np.array_equal(yp, y[rows]), (act, h)
+
+
+def test_ping_pong_tiles_compute_the_same_bits(ext):
+    """Tiles 9 (256 x 256), 10 (128 x 256) and 11 (64 x 256) of kernels/gemm.hip use the same MFMA, K order, epilogue
+    arithmetic and 64-column statistics groups, so WHICH of them writes the residual stream (two images: 9; one image
+    beside other lanes: 10; one image with the GPU to itself: 11) must not change a bit of the stream, of its f16 copy or
+    of the row statistics it leaves -- the latter seen through the LayerNorm-folded consumer, which the product always
+    runs on tile 9 for these shapes (gemm_pick_tile keeps a consumer's tile independent of the pass: its merge of the
+    statistics depends on the tile height).  ViT-B's fc2 -> LN -> qkv shapes, with and without GELU."""
+    rng = np.random.default_rng(2024)
+    M, D, K1, N = 1024, 768, 3072, 2304
+    A1 = rng.standard_normal((M, K1)).astype(np.float16)
+    W1 = (rng.standard_normal((D, K1)) / np.sqrt(K1)).astype(np.float16)
+    b1 = rng.standard_normal(D).astype(np.float32)
+    resid = (rng.standard_normal((M, D)) * 3 + 1).astype(np.float32)
+    gamma = (1 + 0.2 * rng.standard_normal(D)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(D)).astype(np.float32)
+    W2 = (rng.standard_normal((N, D)) / np.sqrt(D)).astype(np.float32)
+    b2 = rng.standard_normal(N).astype(np.float32)
+    for act in (0, 1):
+        results = []
+        for tile in (9, 10, 11):
+            ext.force_gemm_tile(tile, consumer_tile=9)
+            results.append(ext.test_gemm_ln(A1, W1, b1, resid, W2, gamma, beta, b2, 1e-6, act))
+        for other, tile in zip(results[1:], (10, 11)):
+            for a, b, what in zip(results[0], other, ("stream", "f16 copy", "consumer (statistics)")):
+                assert np.array_equal(a, b), (act, tile, what)
