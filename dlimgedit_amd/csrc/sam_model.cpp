@@ -267,13 +267,15 @@ SamWeights::SamWeights(std::string const& weight_path, int device_index) : devic
     HIP_CHECK(hipStreamDestroy(stream_));
 }
 
-LaneBoard::LaneBoard(int device, int lanes) : armed_(new std::atomic<bool>[std::max(1, lanes)]) {
+LaneBoard::LaneBoard(int device, int lanes)
+    : armed_(new std::atomic<bool>[std::max(1, lanes)]), enqueuing_(new std::atomic<bool>[std::max(1, lanes)]) {
     HIP_CHECK(hipSetDevice(device));
     for (int i = 0; i < lanes; ++i) {
         hipEvent_t e = nullptr;
         HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         marker_.push_back(e);
         armed_[i].store(false);
+        enqueuing_[i].store(false);
     }
 }
 
@@ -281,15 +283,26 @@ LaneBoard::~LaneBoard() {
     for (hipEvent_t e : marker_) (void)hipEventDestroy(e);
 }
 
+void LaneBoard::begin(int lane) {
+    if (lane >= 0 && lane < (int)marker_.size()) enqueuing_[lane].store(true, std::memory_order_release);
+}
+
+void LaneBoard::end(int lane) noexcept {
+    if (lane >= 0 && lane < (int)marker_.size()) enqueuing_[lane].store(false, std::memory_order_release);
+}
+
 void LaneBoard::mark(int lane, hipStream_t stream) {
     if (lane < 0 || lane >= (int)marker_.size()) return;
     HIP_CHECK(hipEventRecord(marker_[lane], stream));
     armed_[lane].store(true, std::memory_order_release);
+    enqueuing_[lane].store(false, std::memory_order_release);
 }
 
 bool LaneBoard::others_idle(int lane) const {
     for (int i = 0; i < (int)marker_.size(); ++i) {
-        if (i == lane || !armed_[i].load(std::memory_order_acquire)) continue;
+        if (i == lane) continue;
+        if (enqueuing_[i].load(std::memory_order_acquire)) return false;       // a pass is being enqueued there right now
+        if (!armed_[i].load(std::memory_order_acquire)) continue;
         const hipError_t st = hipEventQuery(marker_[i]);
         if (st == hipErrorNotReady) return false;
         if (st != hipSuccess) (void)hipGetLastError();      // not this call's problem: treated as "busy" is the safe answer
@@ -623,7 +636,11 @@ void SamModel::encode(int batch, float* const* emb_dst) {
     DLIMG_ASSERT(batch > 0 && batch <= enc_batch_);
     // one image, and no other lane of this GPU has anything in flight: the pass may trade CU time for latency
     alone_ = batch == 1 && shared_gpu_ && board_ && board_->others_idle(lane_index_);
-    mark_activity();                             // from here on this lane counts as busy for its siblings
+    begin_activity();                            // from here on this lane counts as busy for its siblings
+    struct EndOnExit {                           // (an enqueue that throws must not leave the lane "busy" for ever)
+        LaneBoard* board; int lane;
+        ~EndOnExit() { if (board) board->end(lane); }
+    } end_on_exit{board_.get(), lane_index_};
     const int D = W.geom_.embed_dim, H = W.geom_.num_heads, hd = W.geom_.head_dim(), mlp = W.geom_.mlp_dim;
     const int M = batch * kTokens;
 

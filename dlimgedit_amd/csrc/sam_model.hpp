@@ -121,12 +121,15 @@ class LaneBoard {
     ~LaneBoard();
     LaneBoard(LaneBoard const&) = delete;
     LaneBoard& operator=(LaneBoard const&) = delete;
-    void mark(int lane, hipStream_t stream);
+    void begin(int lane);                         // the lane starts enqueuing a pass: busy until the next mark() / end()
+    void end(int lane) noexcept;                  // (no event: for the error path of an enqueue)
+    void mark(int lane, hipStream_t stream);      // behind what the lane has just enqueued
     bool others_idle(int lane) const;
 
   private:
     std::vector<hipEvent_t> marker_;
     std::unique_ptr<std::atomic<bool>[]> armed_;
+    std::unique_ptr<std::atomic<bool>[]> enqueuing_;
 };
 
 class SamModel {
@@ -233,6 +236,7 @@ class SamModel {
     int lane_index_ = 0;
     bool alone_ = false;                 // the encoder pass being enqueued found every other lane idle (set by encode())
     void mark_activity() { if (board_) board_->mark(lane_index_, stream_); }
+    void begin_activity() { if (board_) board_->begin(lane_index_); }
     hipStream_t stream_ = nullptr;
     std::mutex mutex_;
 
