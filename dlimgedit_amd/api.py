@@ -192,6 +192,7 @@ class Image:
 
     def pixels(self) -> np.ndarray:
         buf = (C.c_uint8 * self.size()).from_address(self._ptr)
+        buf._owner = self                        # the array keeps the Image (and with it the library's allocation) alive
         return np.frombuffer(buf, dtype=np.uint8).reshape(self._extent.height, self._extent.width, count(self._channels))
 
     def view(self) -> ImageView:

@@ -40,6 +40,7 @@ SOURCES = [
     "kernels/objects.hip",
     "resize_tables.cpp",
     "image_io.cpp",
+    "jpeg_decode.cpp",
     "weights.cpp",
     "sam_model.cpp",
     "environment.cpp",

@@ -7,7 +7,9 @@
 //   load_image  PNG: grey, grey+alpha, RGB, RGBA, palette; 1/2/4/8/16 bits; non-interlaced and Adam7; tRNS as alpha.
 //               Channel counts come out as stb_image reports them with req_comp = 0 (file's own count; palette = 3, or
 //               4 with tRNS), and 2-channel files are rejected with the reference's message.  16-bit samples keep
-//               their high byte (stb_image's conversion).  JPEG and the other formats stb_image reads are not decoded.
+//               their high byte (stb_image's conversion).  JPEG: csrc/jpeg_decode.cpp (baseline and progressive, grey and
+//               YCbCr / RGB; stb_image's integer IDCT, up-sampling and colour conversion).  The other formats stb_image
+//               reads (BMP, GIF, PSD, TGA, HDR, PIC, PNM) are not decoded.
 #include "common.hpp"
 #include "segmentation.hpp"
 
@@ -20,6 +22,9 @@
 #include <vector>
 
 namespace dlimg {
+
+uint8_t* decode_jpeg(uint8_t const* data, size_t size, char const* filepath, int* out_extent, int* out_channels);
+
 namespace {
 
 struct File {
@@ -135,8 +140,14 @@ uint8_t* load_image_file(char const* filepath, int* out_extent, int* out_channel
     }
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
     if (data.size() < 8 || std::memcmp(data.data(), sig, 8) != 0) {
-        if (data.size() > 2 && data[0] == 0xff && data[1] == 0xd8)
-            throw fail("JPEG decoding is not part of the MI355X build of dlimgedit (PNG only); pass pixels through ImageView");
+        if (data.size() > 2 && data[0] == 0xff && data[1] == 0xd8) {
+            uint8_t* pixels = decode_jpeg(data.data(), data.size(), filepath, out_extent, out_channels);     // csrc/jpeg_decode.cpp
+            if (*out_channels != 1 && *out_channels != 3 && *out_channels != 4) {
+                delete[] pixels;
+                throw Exception("Unsupported number of channels (" + std::to_string(*out_channels) + ") in " + filepath);
+            }
+            return pixels;
+        }
         throw fail("unknown image type");
     }
     uint32_t w = 0, h = 0;
