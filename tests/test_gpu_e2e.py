@@ -384,3 +384,29 @@ def test_hard_edged_images_against_the_oracle(api, session, seed):
         if (want_mask > 0).mean() >= 0.02:          # IoU of a sliver says nothing
             at_least(f"e2e.hard_edges.{seed}.{name}.mask_iou", iou(got_mask, want_mask), IOU_BAR)
     seg.close()
+
+
+def test_the_reference_s_truck_case_on_its_own_photograph(api, session):
+    """The reference's integration test, restated (test/test_segmentation.cpp:137-140): Image::load("truck.jpg") ->
+    Segmentation::process -> compute_mask(Point{486, 722}).  Its golden mask is a git-LFS stub and pins MobileSAM weights,
+    so the comparison is with the oracle on the same decoded pixels and the same seeded weights -- but the INPUT is the
+    reference's own photograph (tests/golden/truck.jpg, 1800 x 1200): a real image through the JPEG reader, the device
+    resize, the encoder and the decoder, where every other test feeds synthetic pictures."""
+    from pathlib import Path
+    from oracle import sam_oracle as O
+    env, params, cfg, *_ = session
+    img = api.Image.load(Path(__file__).resolve().parent / "golden" / "truck.jpg")
+    assert img.extent() == api.Extent(1800, 1200) and img.channels() == api.Channels.rgb
+    pixels = img.pixels()
+    seg = api.Segmentation.process(img.view(), env)
+    assert seg.extent() == api.Extent(1800, 1200)
+    ora = O.OracleSegmentation(params, cfg).process(np.ascontiguousarray(pixels), O.CH_RGB)
+    within("e2e.truck.embedding", np.abs(api.ext.get_embedding(seg) - ora.embedding).max(), EMB_TOL)
+    for name, gp, op in (("point", api.Point(486, 722), dict(point=(486, 722))),
+                         ("box", api.Region(api.Point(180, 300), api.Point(1500, 1000)), dict(region=(180, 300, 1500, 1000)))):
+        got, want = seg.compute_mask(gp), ora.compute_mask(**op)
+        assert got.shape == (1200, 1800)
+        within(f"e2e.truck.{name}.differing_pixels", (got != want).mean(), 0.002)
+        if (want > 0).mean() >= 0.02:
+            at_least(f"e2e.truck.{name}.mask_iou", iou(got, want), IOU_BAR)
+    seg.close()
