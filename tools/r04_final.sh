@@ -3,6 +3,7 @@
 # probe, and the profile collection of the bench command (one gpurun call)
 set -o pipefail
 O=gpurun_out/r04_final; mkdir -p $O
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc $?"; tail -3 $O/pytest.log
 timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_vit_b_b1.json 2> $O/bench.err; echo "official rc $?"
 python tools/show_bench.py r04_final/bench_vit_b_b1 | cut -c1-300
 timeout -k 10 300 python bench.py --steps 200 --warmup 10 --repeats 5 --no-abi-path --no-cpu-baseline > $O/bench_vit_b_b1_steps200.json 2>> $O/bench.err; echo "steps200 rc $?"
