@@ -548,9 +548,10 @@ class ext:
     @classmethod
     def queue_config(cls, env) -> dict:
         """Effective settings of the step queue behind encode_and_mask, as the library clamped them."""
-        out = (C.c_int * 4)()
+        out = (C.c_int * 6)()
         _check(cls._l().dlimg_amd_queue_config(env.handle(), out))
-        return {"coalesce": out[0], "step_depth": out[1], "lanes": out[2], "lanes_in_use": out[3]}
+        return {"coalesce": out[0], "step_depth": out[1], "lanes": out[2], "lanes_in_use": out[3],
+                "one_image_passes": out[4], "one_image_passes_alone": out[5]}
 
     @classmethod
     def replica_count(cls, env) -> int:

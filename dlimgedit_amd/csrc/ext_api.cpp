@@ -448,6 +448,9 @@ DLIMG_API int dlimg_amd_queue_config(dlimg_Environment env, int* out) {
         out[1] = e.step_depth;
         out[2] = e.lane_count(0);
         out[3] = std::max(1, e.effective_lane_count(0));
+        LaneBoard const* board = e.lane(0, 0).board();
+        out[4] = board ? (int)std::min<long>(board->passes(), 0x7fffffff) : 0;
+        out[5] = board ? (int)std::min<long>(board->alone_passes(), 0x7fffffff) : 0;
     });
 }
 

@@ -636,6 +636,7 @@ void SamModel::encode(int batch, float* const* emb_dst) {
     DLIMG_ASSERT(batch > 0 && batch <= enc_batch_);
     // one image, and no other lane of this GPU has anything in flight: the pass may trade CU time for latency
     alone_ = batch == 1 && shared_gpu_ && board_ && board_->others_idle(lane_index_);
+    if (board_ && batch == 1) board_->count_pass(alone_);
     begin_activity();                            // from here on this lane counts as busy for its siblings
     struct EndOnExit {                           // (an enqueue that throws must not leave the lane "busy" for ever)
         LaneBoard* board; int lane;

@@ -125,8 +125,13 @@ class LaneBoard {
     void end(int lane) noexcept;                  // (no event: for the error path of an enqueue)
     void mark(int lane, hipStream_t stream);      // behind what the lane has just enqueued
     bool others_idle(int lane) const;
+    // diagnostics: encoder passes of one image enqueued so far, and how many of them found every other lane idle
+    void count_pass(bool alone) { passes_.fetch_add(1, std::memory_order_relaxed); if (alone) alone_.fetch_add(1, std::memory_order_relaxed); }
+    long passes() const { return passes_.load(std::memory_order_relaxed); }
+    long alone_passes() const { return alone_.load(std::memory_order_relaxed); }
 
   private:
+    std::atomic<long> passes_{0}, alone_{0};
     std::vector<hipEvent_t> marker_;
     std::unique_ptr<std::atomic<bool>[]> armed_;
     std::unique_ptr<std::atomic<bool>[]> enqueuing_;
@@ -148,6 +153,7 @@ class SamModel {
     hipStream_t stream() const { return stream_; }
     std::mutex& mutex() { return mutex_; }
     int device() const { return device_; }
+    LaneBoard const* board() const { return board_.get(); }
 
     // All methods below require mutex() to be held by the caller, unless stated otherwise.  The mutex covers the
     // ENQUEUE of a request (host-side state, staging areas), not its execution: workspaces are re-used in stream

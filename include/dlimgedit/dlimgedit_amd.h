@@ -78,7 +78,9 @@ DLIMG_API int dlimg_amd_lane_count(dlimg_Environment env);
 
 /* What the step queue behind dlimg_amd_encode_and_mask really uses (the library clamps DLIMGEDIT_COALESCE / _STEP_DEPTH /
  * _LANES and has its own defaults): out[0] = requests coalesced per pass, out[1] = passes that may wait on a lane,
- * out[2] = execution lanes of replica 0, out[3] = lanes requests are currently spread over (1 while per-kernel clocks run). */
+ * out[2] = execution lanes of replica 0, out[3] = lanes requests are currently spread over (1 while per-kernel clocks run),
+ * out[4] = one-image encoder passes enqueued on replica 0 so far, out[5] = how many of them found every other lane idle and
+ * ran in the "GPU to itself" tile configuration (six ints). */
 DLIMG_API int dlimg_amd_queue_config(dlimg_Environment env, int* out);
 
 /* Multi-GPU: number of replicas of the environment (entries of DLIMGEDIT_DEVICES; 1 by default) and, for a

@@ -225,3 +225,46 @@ def test_encoder_is_bit_stable_under_concurrent_lanes(model_dirs):
     env.close()
     assert not errors, errors
     assert not bad, bad[:5]
+
+
+def test_a_synchronous_caller_is_recognised_as_alone_and_concurrent_callers_are_not(model_dirs):
+    """LaneBoard (csrc/sam_model.hpp): an encoder pass of one image that finds every other lane of its GPU idle runs its
+    stream writers on the tiles that trade CU time for latency.  A synchronous caller (one request at a time, each waited
+    for: every user of the reference's wrapper) must be recognised every time; four threads that keep the lanes busy must
+    mostly not be.  Results are the same bits either way (test_ping_pong_tiles_compute_the_same_bits, batch == single)."""
+    from dlimgedit_amd import api
+    mdir, _, _ = model_dirs("vit_test")
+    env = api.Environment(api.Options(api.Backend.gpu, mdir))
+    view = api.ImageView(synthetic_image(5), api.Channels.rgba)
+    base = api.ext.queue_config(env)
+    want = None
+    for _ in range(6):
+        seg = api.Segmentation.process(view, env)
+        emb = api.ext.get_embedding(seg)
+        want = emb if want is None else want
+        assert np.array_equal(emb, want)
+        seg.compute_mask(api.Point(300, 700))
+        seg.close()
+    after = api.ext.queue_config(env)
+    assert after["one_image_passes"] - base["one_image_passes"] == 6
+    assert after["one_image_passes_alone"] - base["one_image_passes_alone"] == 6
+    errors = []
+
+    def worker():
+        try:
+            for _ in range(25):
+                seg = api.Segmentation.process(view, env)
+                assert np.array_equal(api.ext.get_embedding(seg), want)        # same bits beside busy lanes
+                seg.close()
+        except Exception as e:       # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=worker) for _ in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
+    busy = api.ext.queue_config(env)
+    n, alone = busy["one_image_passes"] - after["one_image_passes"], busy["one_image_passes_alone"] - after["one_image_passes_alone"]
+    assert n == 100 and alone < n, (n, alone)          # (how many depends on the timing; that not all are is certain)
+    print(f"concurrent callers: {alone} of {n} one-image passes found the other lanes idle")
+    env.close()
