@@ -255,7 +255,7 @@ def main() -> None:
         st = profiled(1)
         g, gl = st["gemm"], st_lanes["gemm"]
         flavours = {"gemm_stats": "gemm_pp_kernel<ACT_NONE, EPI_STATS> / gemm_pp128_kernel<.., EPI_STATS>: patch, proj, fc2 "
-                                  "(bias + fp32 residual in, fp32 stream + f16 copy + row statistics out)",
+                                  "(bias + residual in, residual stream as an f16 pair + row statistics out)",
                     "gemm_norm": "gemm_pp_kernel<ACT_NONE, EPI_NORM>: qkv (LayerNorm folded in, f16 out)",
                     "gemm_norm_gelu": "gemm_pp_kernel<ACT_GELU, EPI_NORM>: fc1 (LayerNorm folded in, GELU, f16 out)",
                     "gemm_other": "gemm_f16_kernel: neck 1x1 / 3x3"}

@@ -396,6 +396,7 @@ class ext:
                 "dlimg_amd_test_force_gemm_consumer_tile": ([ci], ci),
                 "dlimg_amd_test_gemm": ([ci, ci, ci, vp, vp, vp, vp, ci, ci, vp, vp], ci),
                 "dlimg_amd_test_gemm_ln": ([ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, cf, ci, vp, vp, vp], ci),
+                "dlimg_amd_test_gemm_stream": ([ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp], ci),
                 "dlimg_amd_test_layernorm": ([vp, vp, vp, cf, ci, ci, ci, vp, vp], ci),
                 "dlimg_amd_test_attention": ([ci, vp, vp, vp, vp, ci, ci, ci, vp], ci),
                 "dlimg_amd_test_resize": ([vp, ci, ci, ci, ci, ci, ci, vp], ci),
@@ -423,7 +424,7 @@ class ext:
                "dlimg_amd_queue_config", "dlimg_amd_replica_count", "dlimg_amd_segmentation_device", "dlimg_amd_get_segmentation_masks_device",
                "dlimg_amd_set_profiling",
                "dlimg_amd_take_stage_stats", "dlimg_amd_test_preprocess", "dlimg_amd_test_postprocess",
-               "dlimg_amd_test_force_gemm_tile", "dlimg_amd_test_force_gemm_consumer_tile", "dlimg_amd_test_gemm", "dlimg_amd_test_gemm_ln", "dlimg_amd_test_layernorm", "dlimg_amd_test_attention", "dlimg_amd_test_resize",
+               "dlimg_amd_test_force_gemm_tile", "dlimg_amd_test_force_gemm_consumer_tile", "dlimg_amd_test_gemm", "dlimg_amd_test_gemm_ln", "dlimg_amd_test_gemm_stream", "dlimg_amd_test_layernorm", "dlimg_amd_test_attention", "dlimg_amd_test_resize",
                "dlimg_amd_birefnet_prepare_image", "dlimg_amd_birefnet_process_mask", "dlimg_amd_resize_mask",
                "dlimg_amd_bench_attention", "dlimg_amd_bench_prepost", "dlimg_amd_bench_gemm", "dlimg_amd_bench_gemm_streams", "dlimg_amd_bench_gemm_stamps")
 
@@ -656,6 +657,25 @@ class ext:
                                                cls._ptr(resid), wg.ctypes.data, colsum.ctypes.data, b2.ctypes.data,
                                                eps, act, x.ctypes.data, xh.ctypes.data, y.ctypes.data))
         return x, xh, y
+
+    @classmethod
+    def test_gemm_stream(cls, A, W, bias, resid_hi, resid_lo, pair: bool):
+        """One stream-writing GEMM with row statistics; returns (x fp32 or None, hi, lo or None, stats[M, 48])."""
+        A = np.ascontiguousarray(A, dtype=np.float16)
+        W = np.ascontiguousarray(W, dtype=np.float16)
+        M, K = A.shape
+        D = W.shape[0]
+        bias = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
+        resid_hi = None if resid_hi is None else np.ascontiguousarray(resid_hi, dtype=np.float16)
+        resid_lo = None if resid_lo is None else np.ascontiguousarray(resid_lo, dtype=np.float16)
+        x = None if pair else np.empty((M, D), dtype=np.float32)
+        hi = np.empty((M, D), dtype=np.float16)
+        lo = np.empty((M, D), dtype=np.float16) if pair else None
+        stats = np.empty((M * 48,), dtype=np.float32)
+        _check(cls._l().dlimg_amd_test_gemm_stream(M, D, K, A.ctypes.data, W.ctypes.data, cls._ptr(bias), cls._ptr(resid_hi),
+                                                   cls._ptr(resid_lo), int(pair), cls._ptr(x), hi.ctypes.data,
+                                                   cls._ptr(lo), stats.ctypes.data))
+        return x, hi, lo, stats
 
     @classmethod
     def test_layernorm(cls, x, w, b, eps: float, act: int = 0):

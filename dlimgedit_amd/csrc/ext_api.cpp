@@ -613,6 +613,48 @@ DLIMG_API int dlimg_amd_test_gemm_ln(int M, int D, int K1, int N, uint16_t const
     });
 }
 
+// One stream-writing GEMM of the encoder, x = A.W^T + bias + resid with the per-tile row statistics, in either
+// representation of the stream: fp32 + f16 copy (pair == 0: resid_hi / resid_lo are summed to the fp32 residual on the host
+// side of the kernel, out_x and out_hi are written) or the f16 pair (pair == 1: out_hi / out_lo).  stats: M * 24 * 2 floats.
+DLIMG_API int dlimg_amd_test_gemm_stream(int M, int D, int K, uint16_t const* A, uint16_t const* W, float const* bias,
+                                         uint16_t const* resid_hi, uint16_t const* resid_lo, int pair, float* out_x,
+                                         uint16_t* out_hi, uint16_t* out_lo, float* out_stats) {
+    return guarded([&] {
+        require_gpu();
+        DLIMG_ASSERT(M > 0 && D > 0 && K > 0 && A && W && out_hi && out_stats);
+        DLIMG_ASSERT((resid_hi != nullptr) == (resid_lo != nullptr));
+        DLIMG_ASSERT(pair ? out_lo != nullptr : out_x != nullptr);
+        const size_t n = (size_t)M * D;
+        Upload<half_t> a(reinterpret_cast<half_t const*>(A), (size_t)M * K);
+        Upload<half_t> w(reinterpret_cast<half_t const*>(W), (size_t)D * K);
+        Upload<float> b(bias, bias ? D : 0);
+        Upload<half_t> rh(reinterpret_cast<half_t const*>(resid_hi), resid_hi ? n : 0);
+        Upload<half_t> rl(reinterpret_cast<half_t const*>(resid_lo), resid_lo ? n : 0);
+        std::vector<float> sum(resid_hi && !pair ? n : 0);
+        for (size_t i = 0; i < sum.size(); ++i)
+            sum[i] = (float)reinterpret_cast<half_t const*>(resid_hi)[i] + (float)reinterpret_cast<half_t const*>(resid_lo)[i];
+        Upload<float> r(sum.data(), sum.size());
+        DeviceBuffer<float> x(pair ? 0 : n), stats((size_t)M * 24 * 2);
+        DeviceBuffer<half_t> hi(n), lo(pair ? n : 0);
+        HIP_CHECK(hipMemset(stats.get(), 0, (size_t)M * 24 * 2 * sizeof(float)));
+        k::GemmArgs g;
+        g.A = a.get(); g.lda = K; g.W = w.get(); g.ldw = K; g.bias = bias ? b.get() : nullptr; g.resid_mod = M;
+        if (resid_hi && pair) { g.resid_h = rh.get(); g.resid_l = rl.get(); g.ldrs = D; }
+        else if (resid_hi) { g.resid = r.get(); g.ldr = D; }
+        if (pair) g.out_l = lo.get();
+        else { g.out_f32 = x.get(); g.ldc32 = D; }
+        g.out_h = hi.get(); g.ldc16 = D; g.stats_out = stats.get();
+        g.M = M; g.N = D; g.K = K; g.shared_gpu = true;
+        apply_forced_tile(g);
+        k::gemm(g, nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+        download(out_x, x.get(), pair ? 0 : n);
+        download(reinterpret_cast<half_t*>(out_hi), hi.get(), n);
+        download(reinterpret_cast<half_t*>(out_lo), lo.get(), pair ? n : 0);
+        download(out_stats, stats.get(), (size_t)M * 24 * 2);
+    });
+}
+
 DLIMG_API int dlimg_amd_test_layernorm(float const* x, float const* w, float const* b, float eps, int rows, int dim,
                                        int act, float* out_f32, uint16_t* out_f16) {
     return guarded([&] {

@@ -18,6 +18,8 @@ typedef float float2_t __attribute__((ext_vector_type(2)));
 typedef float float3_t __attribute__((ext_vector_type(3)));
 typedef float float4_t __attribute__((ext_vector_type(4)));
 typedef float float16_t __attribute__((ext_vector_type(16)));
+typedef uint32_t uint2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t uint4_t __attribute__((ext_vector_type(4)));
 
 #define DLIMG_DEVICE __device__ __forceinline__
 

@@ -44,6 +44,20 @@ namespace {
 
 constexpr int BK_CHECK = 64;    // K must be a multiple of this for every configuration
 
+// tuning build only: the stream writers skip their residual read (WRONG results) -- what 4 of the epilogue's 10 bytes per
+// element cost
+#if defined(DLIMG_TUNING) && defined(DLIMG_NO_RESID_READ)
+constexpr bool kNoResidRead = true;
+#else
+constexpr bool kNoResidRead = false;
+#endif
+// ... and skip the write of the f16 copy: what 2 of the 6 bytes written per element cost
+#if defined(DLIMG_TUNING) && defined(DLIMG_NO_COPY_WRITE)
+constexpr bool kNoCopyWrite = true;
+#else
+constexpr bool kNoCopyWrite = false;
+#endif
+
 // LDS rows hold BKT halves (128 or 64 bytes).  The 16-byte chunk index is XOR-swizzled with row bits so that
 // the 16 rows a ds_read_b128 lane group touches land on 16 different 16-byte slots of the 256-byte bank row.
 template <int BKT> DLIMG_DEVICE int swz(int row) { return BKT == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
@@ -554,6 +568,42 @@ DLIMG_DEVICE void pp_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// An f16 pair (hi, lo) of four values in one 16-byte register quadruple: what the residual prefetch buffers hold when the
+// residual stream travels as pairs (GemmArgs::resid_h / resid_l)
+struct HiLo4 { half4_t h, l; };
+DLIMG_DEVICE float4_t hilo_pack(half4_t h, half4_t l) { return __builtin_bit_cast(float4_t, HiLo4{h, l}); }
+// v_fma_mix_f32 reads an f16 half of a register as an fp32 operand (op_sel_hi: which sources are f16; op_sel: their high
+// half), so the conversions of the pair arithmetic cost nothing: hi + lo in one instruction, v - hi in one.  (Selects on
+// src0 / src2 only; DESIGN.md section 6 on why src1 selects of VOP3P instructions are kept out of this build.)
+template <bool HIGH> DLIMG_DEVICE float mix_sum(uint32_t hi, uint32_t lo) {          // f16 + f16 -> fp32 (exact)
+    float r;
+    if (HIGH) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(hi), "v"(lo));
+    else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(hi), "v"(lo));
+    return r;
+}
+template <bool HIGH> DLIMG_DEVICE float mix_rest(float v, uint32_t hi) {             // v - f16 -> fp32
+    float r;
+    if (HIGH) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi), "v"(v));
+    else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi), "v"(v));
+    return r;
+}
+DLIMG_DEVICE float4_t hilo_value(float4_t packed) {
+    const uint4_t x = __builtin_bit_cast(uint4_t, packed);             // h01, h23, l01, l23
+    return float4_t{mix_sum<false>(x[0], x[2]), mix_sum<true>(x[0], x[2]), mix_sum<false>(x[1], x[3]), mix_sum<true>(x[1], x[3])};
+}
+// v -> (hi, lo): hi = f16(v), lo = f16(v - hi), both round-to-nearest-even
+DLIMG_DEVICE HiLo4 hilo_split(float4_t v) {
+    HiLo4 out;
+    out.h = __builtin_convertvector(v, half4_t);
+    const uint2_t hb = __builtin_bit_cast(uint2_t, out.h);
+    const float4_t rest = {mix_rest<false>(v[0], hb[0]), mix_rest<true>(v[1], hb[0]), mix_rest<false>(v[2], hb[1]), mix_rest<true>(v[3], hb[1])};
+    out.l = __builtin_convertvector(rest, half4_t);
+    return out;
+}
+DLIMG_DEVICE float4_t hilo_load(const half_t* hi, const half_t* lo, size_t offset) {
+    return hilo_pack(*reinterpret_cast<const half4_t*>(hi + offset), *reinterpret_cast<const half4_t*>(lo + offset));
+}
+
 // Epilogue of the ping-pong kernels: the wave's (NI * 16) x 64 part of the tile, rows row_base .. of the workgroup's tile.
 // PRE: the residual of the whole wave tile was requested before the main loop (pre[band][kk]; only where the
 // registers allow it) -- the epilogue is bound by the CU's memory pipe (~30 B/clk: 320 KB per 128 x 256 tile of a
@@ -579,8 +629,8 @@ DLIMG_DEVICE void pp_epilogue(const k::GemmArgs& a, float4v (&acc)[NI][4], char*
         if (EPI == EPI_NORM) csum4[j] = *reinterpret_cast<const float4_t*>(colvec + BN + col_base + j * 16);
     }
     char* slab = smem + wave * 8192;             // two slabs of 4 KB per wave, used alternately
-    const int resid_row0 = a.resid ? m0 % a.resid_mod : 0;
-    if (a.out_f32 == nullptr) {
+    const int resid_row0 = (a.resid || a.resid_h) ? m0 % a.resid_mod : 0;
+    if (a.out_f32 == nullptr && a.out_l == nullptr) {
         // ---- f16 rows: slot = 8-byte piece (j*4 + quad) of a 128-byte row, XORed with (row & 7) << 1 (pairs stay adjacent)
         const int rd_row = lane >> 3, rd_chunk = lane & 7;
 #pragma unroll
@@ -613,8 +663,10 @@ DLIMG_DEVICE void pp_epilogue(const k::GemmArgs& a, float4v (&acc)[NI][4], char*
         // compiler branch around each one and drain the memory counter at every join (cdna_hip_programming.md, "Three
         // .s-level traps" (c)): 11-12 k cycles for four bands instead of 3 k.
         auto fp32_bands = [&](auto resid_tag, auto h_tag) {
-            constexpr bool HAS_RESID = decltype(resid_tag)::value;
-            constexpr bool HAS_H = decltype(h_tag)::value;
+            constexpr int RESID = decltype(resid_tag)::value;        // 0 none, 1 fp32, 2 f16 pair (hi + lo)
+            constexpr int OUT = decltype(h_tag)::value;              // 0 fp32, 1 fp32 + f16 copy, 2 f16 pair
+            constexpr bool HAS_RESID = RESID != 0;
+            constexpr bool HAS_H = OUT == 1;
             // ---- fp32 rows of 64 floats: 16-byte slot (j*4 + quad) ^ (row & 7)
             const int rd_row = lane >> 4, rd_slot = lane & 15;
             // the band's residual in whole lines, requested one band ahead of its use (its latency would otherwise be
@@ -625,9 +677,11 @@ DLIMG_DEVICE void pp_epilogue(const k::GemmArgs& a, float4v (&acc)[NI][4], char*
                 for (int kk = 0; kk < 4; ++kk) {
                     dst[kk] = float4_t{0.f, 0.f, 0.f, 0.f};
                     const int r = kk * 4 + rd_row;
-                    if (HAS_RESID)
+                    if (RESID == 1 && !kNoResidRead)
                         dst[kk] = *reinterpret_cast<const float4_t*>(a.resid + (size_t)(resid_row0 + row_base + i * 16 + r) * a.ldr +
                                                                      n0 + wc * 64 + rd_slot * 4);
+                    if (RESID == 2)
+                        dst[kk] = hilo_load(a.resid_h, a.resid_l, (size_t)(resid_row0 + row_base + i * 16 + r) * a.ldrs + n0 + wc * 64 + rd_slot * 4);
                 }
             };
             if (!PRE) request_residual(0, rv[0]);
@@ -650,11 +704,18 @@ DLIMG_DEVICE void pp_epilogue(const k::GemmArgs& a, float4v (&acc)[NI][4], char*
                 for (int kk = 0; kk < 4; ++kk) {
                     const int r = kk * 4 + rd_row;
                     float4_t v = *reinterpret_cast<const float4_t*>(sl + r * 256 + ((rd_slot ^ (r & 7)) << 4));
-                    v += PRE ? pre[i][kk] : rv[i & 1][kk];
+                    const float4_t rr = PRE ? pre[i][kk] : rv[i & 1][kk];
+                    v += RESID == 2 ? hilo_value(rr) : rr;
                     const size_t m = (size_t)(m0 + row_base + i * 16 + r);
                     const int col = n0 + wc * 64 + rd_slot * 4;
-                    *reinterpret_cast<float4_t*>(a.out_f32 + m * a.ldc32 + col) = v;
-                    if (HAS_H) {
+                    if (OUT == 2) {
+                        const HiLo4 p = hilo_split(v);
+                        *reinterpret_cast<half4_t*>(a.out_h + m * a.ldc16 + col) = p.h;
+                        *reinterpret_cast<half4_t*>(a.out_l + m * a.ldc16 + col) = p.l;
+                    } else {
+                        *reinterpret_cast<float4_t*>(a.out_f32 + m * a.ldc32 + col) = v;
+                    }
+                    if (HAS_H && !kNoCopyWrite) {
                         const half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                         *reinterpret_cast<half4_t*>(a.out_h + m * a.ldc16 + col) = h;
                     }
@@ -677,12 +738,19 @@ DLIMG_DEVICE void pp_epilogue(const k::GemmArgs& a, float4v (&acc)[NI][4], char*
             }
     
         };
-        if (a.resid) {
-            if (a.out_h) fp32_bands(std::true_type{}, std::true_type{});
-            else fp32_bands(std::true_type{}, std::false_type{});
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        if (a.out_l) {                           // the stream as an f16 pair (stream writers of the encoder)
+            if (a.resid_h) fp32_bands(I2{}, I2{});
+            else if (a.resid) fp32_bands(I1{}, I2{});
+            else fp32_bands(I0{}, I2{});
+        } else if (a.resid) {
+            if (a.out_h) fp32_bands(I1{}, I1{});
+            else fp32_bands(I1{}, I0{});
         } else {
-            if (a.out_h) fp32_bands(std::false_type{}, std::true_type{});
-            else fp32_bands(std::false_type{}, std::false_type{});
+            if (a.out_h) fp32_bands(I0{}, I1{});
+            else fp32_bands(I0{}, I0{});
         }
     }
     if (EPI == EPI_STATS) {
@@ -973,7 +1041,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(k::GemmArgs a) {
         for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) rpre[i][kk] = float4_t{0.f, 0.f, 0.f, 0.f};
-        if (a.resid) {                           // one uniform branch around all the requests
+        if (a.resid && !kNoResidRead) {          // one uniform branch around all the requests
             const int resid_row0 = m0 % a.resid_mod;
 #pragma unroll
             for (int i = 0; i < NI; ++i)
@@ -981,6 +1049,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(k::GemmArgs a) {
                 for (int kk = 0; kk < 4; ++kk)
                     rpre[i][kk] = *reinterpret_cast<const float4_t*>(
                         a.resid + (size_t)(resid_row0 + wr * (BM / 2) + i * 16 + kk * 4 + (lane >> 4)) * a.ldr + n0 + wc * 64 + (lane & 15) * 4);
+        } else if (a.resid_h) {                  // the residual as an f16 pair: the same 16 bytes per lane and request
+            const int resid_row0 = m0 % a.resid_mod;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    rpre[i][kk] = hilo_load(a.resid_h, a.resid_l,
+                                            (size_t)(resid_row0 + wr * (BM / 2) + i * 16 + kk * 4 + (lane >> 4)) * a.ldrs + n0 + wc * 64 + (lane & 15) * 4);
         }
     }
     pp_barrier();
@@ -1133,6 +1209,11 @@ const char* gemm_check(const GemmArgs& a) {
     if (((uintptr_t)a.A | (uintptr_t)a.W) & 15) return "gemm: operands must be 16-byte aligned";
     if (a.resid && (a.resid_mod <= 0 || a.resid_mod % 64)) return "gemm: resid_mod must be a positive multiple of 64";
     if (!a.out_f32 && !a.out_h) return "gemm: no output";
+    if (a.out_l && (a.out_f32 || !a.out_h || ((uintptr_t)a.out_l & 7))) return "gemm: an f16-pair result needs out_h and out_l (8-byte aligned) and no out_f32";
+    if ((a.resid_h != nullptr) != (a.resid_l != nullptr) || (a.resid_h && a.resid))
+        return "gemm: the residual is either fp32 or an f16 pair (resid_h and resid_l)";
+    if (a.resid_h && ((((uintptr_t)a.resid_h | (uintptr_t)a.resid_l) & 7) || a.ldrs % 4 || a.resid_mod <= 0 || a.resid_mod % 64))
+        return "gemm: f16-pair residual rows must be 8-byte aligned, resid_mod a positive multiple of 64";
     if ((a.bias && ((uintptr_t)a.bias & 15)) || (a.resid && (((uintptr_t)a.resid & 15) || a.ldr % 4)) ||
         (a.out_f32 && (((uintptr_t)a.out_f32 & 15) || a.ldc32 % 4)) ||
         (a.out_h && (((uintptr_t)a.out_h & 7) || a.ldc16 % 4)))
@@ -1173,7 +1254,8 @@ constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 bool gemm_tile_fits(const GemmArgs& a, int tile) {
     if (tile < 0 || tile >= kNumTiles) return false;
     const TileCfg& t = kTiles[tile];
-    return a.M % t.bm == 0 && a.N % t.bn == 0 && !(a.resid && a.resid_mod % t.bm != 0);
+    if ((a.out_l || a.resid_h) && !(tile >= 9 && tile <= 11)) return false;      // f16-pair stream: ping-pong epilogue only
+    return a.M % t.bm == 0 && a.N % t.bn == 0 && !((a.resid || a.resid_h) && a.resid_mod % t.bm != 0);
 }
 
 int gemm_pick_tile(const GemmArgs& a) {
@@ -1184,7 +1266,7 @@ int gemm_pick_tile(const GemmArgs& a) {
     const int unit = (a.unit_rows > 0 && a.M % a.unit_rows == 0) ? a.unit_rows : a.M;   // rows the choice is made for
     // a residual that wraps (row m % resid_mod) must wrap on tile boundaries: the epilogue adds row offsets to the
     // tile's first residual row without a modulo per element
-    auto wraps_inside = [&](int bm) { return a.resid && a.resid_mod % bm != 0; };
+    auto wraps_inside = [&](int bm) { return (a.resid || a.resid_h) && a.resid_mod % bm != 0; };
     const bool shared = a.shared_gpu;
     // 256x256 workgroups use a CU about 2.5x better than 128x128 ones (LDS fill rate per FLOP); with other lanes on
     // the remaining CUs that is worth having even when they cover a quarter of the chip (ViT-H proj / fc2: 80
@@ -1253,7 +1335,9 @@ int gemm_choose_tile(GemmArgs& a) {
 void gemm(const GemmArgs& a, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
     if (const char* err = gemm_check(a)) throw_error(err);
     const Timing t{start, stop};
-    switch (gemm_pick_tile(a)) {
+    const int tile = gemm_pick_tile(a);
+    if ((a.out_l || a.resid_h) && !(tile >= 9 && tile <= 11)) throw_error("gemm: the f16-pair stream needs a ping-pong tile (N % 256 == 0, shared GPU)");
+    switch (tile) {
     case 0: return launch<128, 384, 2, 2, 64, 2, 1>(a, s, t);
     case 1: return launch<128, 288, 4, 1, 64, 3, 1>(a, s, t);
     case 2: return launch<128, 128, 2, 2, 64, 2, 4>(a, s, t);

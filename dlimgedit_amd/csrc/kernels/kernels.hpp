@@ -49,6 +49,13 @@ struct GemmArgs {
     const float* resid = nullptr; int ldr = 0; int resid_mod = 1;   // added after activation: resid[m % resid_mod][n]
     float* out_f32 = nullptr;   int ldc32 = 0;
     half_t* out_h = nullptr;    int ldc16 = 0;
+    // The residual stream as an f16 PAIR (r04): value = hi + lo, hi = f16(value) -- which is also the A operand of the GEMM
+    // that consumes the stream -- and lo = f16(value - hi): 22 significant bits in 4 bytes.  A stream writer then moves 8 bytes
+    // per element (pair in, pair out) instead of 10 (fp32 in, fp32 + f16 copy out).  resid_h / resid_l: the residual as a
+    // pair (instead of `resid`; rows m % resid_mod, leading dimension ldrs); out_l with out_h: the result as a pair (instead
+    // of out_f32; both with leading dimension ldc16).  Ping-pong tiles (9, 10, 11) only.
+    const half_t* resid_h = nullptr; const half_t* resid_l = nullptr; int ldrs = 0;
+    half_t* out_l = nullptr;
     int M = 0, N = 0, K = 0;
     int act = ACT_NONE;
     // LayerNorm folded into the GEMMs around it (gemm.hip).  Producer: stats_out receives, per tile column block and

@@ -483,7 +483,9 @@ void SamModel::reserve_encoder(int batch) {
     const size_t wide = std::max<size_t>(W.geom_.mlp_dim, 9 * kEmbedDim);
     img_dev_.reserve((size_t)batch * kImageSize * kImageSize * 4);
     patches_.reserve(M * kPatchK);
-    x_.reserve(M * D);
+    split_stream_ = W.fused_ln_ && shared_gpu_ && D % 256 == 0 && split_stream_allowed();
+    if (split_stream_) xlo_.reserve(M * D);
+    else x_.reserve(M * D);
     xn_.reserve(M * D);
     xstat_.reserve(M * 24 * 2);              // at most 24 tile column blocks per row (kernels/gemm.hip)
     qkv_.reserve(M * 3 * D);
@@ -492,6 +494,12 @@ void SamModel::reserve_encoder(int batch) {
     neck_f32_.reserve(M * kEmbedDim);
     emb_.reserve(M * kEmbedDim);
     enc_batch_ = batch;
+}
+
+bool SamModel::split_stream_allowed() {
+    // measurement aid like DLIMGEDIT_FUSED_LN: =0 keeps the fp32 stream (same-box A/B of the two representations)
+    static const bool on = [] { const char* e = std::getenv("DLIMGEDIT_SPLIT_STREAM"); return !e || std::atoi(e) != 0; }();
+    return on;
 }
 
 void SamModel::preprocess_device_image(int slot, int batch, uint8_t const* dev_pixels, int w, int h, int stride,
@@ -652,9 +660,16 @@ void SamModel::encode(int batch, float* const* emb_dst) {
     // of LN read + LN write + GEMM read.
     const bool fused = W.fused_ln_;
     int stat_groups = 0;                         // tile column blocks of the GEMM that last wrote the stream
+    const bool split = split_stream_;
+    auto stream_residual = [&](k::GemmArgs& a) {                 // += the stream itself, in place
+        if (split) { a.resid_h = xn_.get(); a.resid_l = xlo_.get(); a.ldrs = D; }
+        else { a.resid = x_.get(); a.ldr = D; }
+        a.resid_mod = M;
+    };
     auto writes_stream = [&](k::GemmArgs& a) {
-        a.resid_mod = a.resid == x_.get() ? M : a.resid_mod;
-        a.out_f32 = x_.get(); a.ldc32 = D; a.M = M; a.N = D;
+        a.M = M; a.N = D;
+        if (split) { a.out_l = xlo_.get(); }
+        else { a.out_f32 = x_.get(); a.ldc32 = D; }
         if (fused) {
             a.out_h = xn_.get(); a.ldc16 = D; a.stats_out = xstat_.get();
             a.shared_gpu = shared_gpu_;
@@ -699,7 +714,7 @@ void SamModel::encode(int batch, float* const* emb_dst) {
         }
         g = k::GemmArgs{};
         g.A = att_.get(); g.lda = D; g.W = L.proj.w.get(); g.ldw = D; g.bias = L.proj.b.get(); g.K = D;
-        g.resid = x_.get(); g.ldr = D;
+        stream_residual(g);
         writes_stream(g);
         gemm(g);
         g = k::GemmArgs{};
@@ -708,7 +723,7 @@ void SamModel::encode(int batch, float* const* emb_dst) {
         gemm(g);
         g = k::GemmArgs{};
         g.A = hid_.get(); g.lda = mlp; g.W = L.fc2.w.get(); g.ldw = mlp; g.bias = L.fc2.b.get(); g.K = mlp;
-        g.resid = x_.get(); g.ldr = D;
+        stream_residual(g);
         writes_stream(g);
         gemm(g);
     }

@@ -257,8 +257,14 @@ class SamModel {
     ImageStage stage_[kStageRing];
     unsigned stage_seq_ = 0;
     uint8_t* stage_rows(uint8_t const* pixels, size_t row_bytes, int rows, int stride, hipEvent_t* copied);
-    DeviceBuffer<half_t> patches_, xn_, qkv_, att_, hid_;
+    DeviceBuffer<half_t> patches_, xn_, xlo_, qkv_, att_, hid_;
     DeviceBuffer<float> x_, xstat_, neck_f32_, emb_;
+    // The residual stream as an f16 pair (xn_ = hi, which is also the consumers' A operand; xlo_ = lo) instead of fp32 x_ +
+    // its f16 copy xn_: 8 instead of 10 bytes per element through every stream writer (kernels.hpp, GemmArgs::out_l).
+    // Needs the ping-pong epilogue for every stream writer: folded LayerNorms, several lanes (the shared-GPU tile choice) and
+    // an embedding width that is a multiple of 256 (ViT-B / L / H; the reduced test variants keep the fp32 stream).
+    bool split_stream_ = false;
+    static bool split_stream_allowed();
 
     // ---- longest-side resize (images whose longest side is not 1024)
     struct AxisDev {

@@ -131,6 +131,13 @@ DLIMG_API int dlimg_amd_test_force_gemm_consumer_tile(int tile);
 /* C = epilogue(A[M,K] . W[N,K]^T): bias[N], resid[resid_rows][N] (row m % resid_rows), act 0/1(GELU). */
 DLIMG_API int dlimg_amd_test_gemm(int M, int N, int K, uint16_t const* A, uint16_t const* W, float const* bias,
                                   float const* resid, int resid_rows, int act, float* out_f32, uint16_t* out_f16);
+/* One stream-writing GEMM of the encoder, x = A[M,K] . W[D,K]^T + bias + (resid_hi + resid_lo), with its per-tile row
+ * statistics (out_stats: M * 24 * 2 floats), in either representation of the residual stream: pair == 0 writes fp32 out_x and
+ * its f16 copy out_hi, pair == 1 the f16 pair out_hi / out_lo (hi = f16(x), lo = f16(x - hi)); resid_hi / resid_lo may both be
+ * NULL.  The two must agree exactly: hi, the statistics, and lo recomputed from out_x (tests/test_gpu_kernels.py). */
+DLIMG_API int dlimg_amd_test_gemm_stream(int M, int D, int K, uint16_t const* A, uint16_t const* W, float const* bias,
+                                         uint16_t const* resid_hi, uint16_t const* resid_lo, int pair, float* out_x,
+                                         uint16_t* out_hi, uint16_t* out_lo, float* out_stats);
 /* Two chained GEMMs with the LayerNorm between them folded in ("LayerNorm inside the GEMMs"):
  *   x = A1[M,K1] . W1[D,K1]^T + bias1 + resid[M,D]        -> out_x [M,D] fp32 and out_xh [M,D] f16
  *   y = act(rstd * (xh . Wg[N,D]^T - mean * colsum[N]) + bias2[N])   -> out_y [M,N]; mean / rstd of the rows of x,

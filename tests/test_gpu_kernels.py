@@ -463,3 +463,33 @@ def test_ping_pong_tiles_compute_the_same_bits(ext):
         for other, tile in zip(results[1:], (10, 11)):
             for a, b, what in zip(results[0], other, ("stream", "f16 copy", "consumer (statistics)")):
                 assert np.array_equal(a, b), (act, tile, what)
+
+
+@pytest.mark.parametrize("tile", [9, 10, 11])
+@pytest.mark.parametrize("with_resid", [False, True])
+def test_pair_stream_is_the_fp32_stream_split_in_two(ext, tile, with_resid):
+    """The residual stream as an f16 pair (GemmArgs::out_l / resid_h / resid_l, kernels/gemm.hip): hi = f16(x) -- the f16 copy
+    the fp32 representation leaves as well -- and lo = f16(x - hi), where x is the fp32 value the other representation
+    stores.  Same residual (hi + lo, summed in fp32 either way), so: hi and the row statistics equal bit for bit, lo equal to
+    the split of the fp32 result done here, and hi + lo within 2^-22 relative of x.  ViT-B's fc2 shape, every ping-pong tile."""
+    rng = np.random.default_rng(77 + tile)
+    M, D, K = 1024, 768, 3072
+    A = rng.standard_normal((M, K)).astype(np.float16)
+    W = (rng.standard_normal((D, K)) / np.sqrt(K)).astype(np.float16)
+    bias = rng.standard_normal(D).astype(np.float32)
+    rh = rl = None
+    if with_resid:
+        r = (rng.standard_normal((M, D)) * 3 + 1).astype(np.float32)
+        r[::7, ::5] *= 40                                       # the few large channels a SAM stream carries
+        rh = r.astype(np.float16)
+        rl = (r - rh.astype(np.float32)).astype(np.float16)
+    ext.force_gemm_tile(tile)
+    x, hi32, _, st32 = ext.test_gemm_stream(A, W, bias, rh, rl, pair=False)
+    _, hi, lo, st = ext.test_gemm_stream(A, W, bias, rh, rl, pair=True)
+    assert np.array_equal(hi.view(np.uint16), hi32.view(np.uint16))
+    assert np.array_equal(st.view(np.uint32), st32.view(np.uint32))
+    assert np.array_equal(hi, x.astype(np.float16))
+    want_lo = (x - hi.astype(np.float32)).astype(np.float16)
+    assert np.array_equal(lo.view(np.uint16), want_lo.view(np.uint16))
+    back = hi.astype(np.float32) + lo.astype(np.float32)
+    assert np.all(np.abs(back - x) <= np.abs(x) * 2.0 ** -21 + 2.0 ** -24)

@@ -19,6 +19,9 @@
 //   case 11 the compiler's third FMA (two v_mov + op_sel:[0,1,0] on {w0, w1}) with everything around it settled
 //   case 12 / 13  one settled packed FMA with the low-lane select on src0 (op_sel:[1,0,0]) / on src2 (op_sel:[0,0,1])
 //   case 14 / 15  v_pk_mul_f32 with op_sel:[1,0] / op_sel:[0,1];  case 16  v_pk_add_f32 with op_sel:[0,1]
+//   case 17 / 18  v_fma_mix_f32 the way the GEMM epilogue's f16-pair arithmetic uses it (kernels/gemm.hip, mix_sum / mix_rest):
+//                 f16 half + f16 half (selects on src0 and src2: op_sel:[1,0,1] / [0,0,0], op_sel_hi:[1,0,1]) and
+//                 fp32 - f16 half (op_sel:[1,0,0] / [0,0,0], op_sel_hi:[1,0,0])
 //   hipcc --offload-arch=gfx950 -O2 -fno-slp-vectorize -o tools/_bin/pkfma_hazard tools/pkfma_hazard.cpp
 //   tools/_bin/pkfma_hazard [seconds per run]
 // (-fno-slp-vectorize: otherwise the REFERENCE sums are paired into the very pattern under test.)
@@ -129,6 +132,12 @@ __device__ __forceinline__ void chain(float4v a /* row 1 */, float4v b /* row 2 
         asm volatile(LOAD_REGS BUILD_PAIRS SETTLED("v_pk_mul_f32 v[46:47], v[20:21], v[32:33] op_sel:[0,1]\n\t") STORE_REGS OPERANDS);
     else if (CASE == 16)    // v_pk_add_f32 with the select on src1
         asm volatile(LOAD_REGS BUILD_PAIRS SETTLED("v_pk_add_f32 v[46:47], v[20:21], v[32:33] op_sel:[0,1]\n\t") STORE_REGS OPERANDS);
+    else if (CASE == 17)    // a[0] / b[0] carry two packed f16 each: LOW result = high halves summed, HIGH result = low halves summed
+        asm volatile(LOAD_REGS "v_fma_mix_f32 v46, v8, 1.0, v12 op_sel:[1,0,1] op_sel_hi:[1,0,1]\n\t"
+                     "v_fma_mix_f32 v47, v8, 1.0, v12 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t" STORE_REGS OPERANDS);
+    else if (CASE == 18)    // w1 - high half of a[0], w0 - low half of a[0]
+        asm volatile(LOAD_REGS "v_fma_mix_f32 v46, v8, -1.0, v1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                     "v_fma_mix_f32 v47, v8, -1.0, v0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t" STORE_REGS OPERANDS);
     else                    // ... with s_nop 0 between them
         asm volatile(LOAD_REGS BUILD_PAIRS FMA_SEL("v[4:5]", "v[16:17]", "v[38:39]", "v[4:5]") "s_nop 0\n\t" FMA_SEL("v[4:5]", "v[18:19]", "v[2:3]", "v[4:5]") "s_nop 0\n\t"
                      FMA_SEL("v[4:5]", "v[20:21]", "v[28:29]", "v[4:5]") "s_nop 0\n\t" FMA_SEL("v[46:47]", "v[22:23]", "v[0:1]", "v[4:5]") STORE_REGS OPERANDS);
@@ -145,11 +154,18 @@ __global__ __launch_bounds__(256) void victim(unsigned long long* out, Sample* s
         float4v a, b, w;
         for (int i = 0; i < 4; ++i) { a[i] = rnd(s) * 2.0f; b[i] = rnd(s) * 2.0f; w[i] = rnd(s); }
         float lo, hi;
+        _Float16 ah[2] = {(_Float16)a[0], (_Float16)a[1]}, bh[2] = {(_Float16)b[0], (_Float16)b[1]};
+        if (CASE == 17 || CASE == 18) {      // two f16 in one register
+            a[0] = __uint_as_float((unsigned)__builtin_bit_cast(unsigned short, ah[0]) | ((unsigned)__builtin_bit_cast(unsigned short, ah[1]) << 16));
+            b[0] = __uint_as_float((unsigned)__builtin_bit_cast(unsigned short, bh[0]) | ((unsigned)__builtin_bit_cast(unsigned short, bh[1]) << 16));
+        }
         chain<CASE>(a, b, w, lo, hi);
         float ref_lo = fmaf(b[0], w[0], fmaf(b[1], w[1], fmaf(b[2], w[2], fmaf(b[3], w[3], 0.0f))));
         float ref_hi = fmaf(a[0], w[0], fmaf(a[1], w[1], fmaf(a[2], w[2], fmaf(a[3], w[3], 0.0f))));
         if (CASE == 14 || CASE == 15) { ref_lo = __fmul_rn(b[1], w[1]); ref_hi = __fmul_rn(a[1], w[1]); }
         if (CASE == 16) { ref_lo = __fadd_rn(b[1], w[1]); ref_hi = __fadd_rn(a[1], w[1]); }
+        if (CASE == 17) { ref_lo = __fadd_rn((float)ah[1], (float)bh[1]); ref_hi = __fadd_rn((float)ah[0], (float)bh[0]); }
+        if (CASE == 18) { ref_lo = __fsub_rn(w[1], (float)ah[1]); ref_hi = __fsub_rn(w[0], (float)ah[0]); }
         const bool wl = __float_as_uint(lo) != __float_as_uint(ref_lo), wh = __float_as_uint(hi) != __float_as_uint(ref_hi);
         if ((wl || wh) && bad_lo + bad_hi == 0) {
             const unsigned long long slot = atomicAdd(&out[3], 1ull);
@@ -291,5 +307,9 @@ int main(int argc, char** argv) {
     run_case<14>("mfma", 1, seconds, dev_out, dev_samples, dev_buf, nbuf);
     run_case<15>("mfma", 1, seconds, dev_out, dev_samples, dev_buf, nbuf);
     run_case<16>("mfma", 1, seconds, dev_out, dev_samples, dev_buf, nbuf);
+    run_case<17>("mfma", 1, seconds, dev_out, dev_samples, dev_buf, nbuf);
+    run_case<18>("mfma", 1, seconds, dev_out, dev_samples, dev_buf, nbuf);
+    run_case<17>("mfma+v_exp", 3, seconds, dev_out, dev_samples, dev_buf, nbuf);
+    run_case<18>("mfma+v_exp", 3, seconds, dev_out, dev_samples, dev_buf, nbuf);
     return 0;
 }
