@@ -133,6 +133,7 @@ EnvironmentImpl::EnvironmentImpl(dlimg_Options const& options) : backend(options
         const int v = std::atoi(e);
         coalesce = v < 1 ? 1 : (v > 8 ? 8 : v);
     }
+    if (const char* e = std::getenv("DLIMGEDIT_STEP_WORKERS")) use_step_workers = std::atoi(e) != 0;
     if (const char* e = std::getenv("DLIMGEDIT_STEP_DEPTH")) {
         const int v = std::atoi(e);
         step_depth = v < 1 ? 1 : (v > 64 ? 64 : v);
@@ -149,7 +150,53 @@ EnvironmentImpl::EnvironmentImpl(dlimg_Options const& options) : backend(options
     }
 }
 
+LaneWorker::LaneWorker() : thread_([this] { run(); }) {}
+
+LaneWorker::~LaneWorker() {
+    {
+        std::lock_guard<std::mutex> lock(mutex_);
+        stop_ = true;
+    }
+    wake_.notify_all();
+    if (thread_.joinable()) thread_.join();
+}
+
+void LaneWorker::post(std::function<void()> task) {
+    {
+        std::lock_guard<std::mutex> lock(mutex_);
+        tasks_.push_back(std::move(task));
+    }
+    wake_.notify_one();
+}
+
+void LaneWorker::drain() {
+    std::unique_lock<std::mutex> lock(mutex_);
+    idle_.wait(lock, [&] { return tasks_.empty() && !running_; });
+}
+
+void LaneWorker::run() {
+    std::unique_lock<std::mutex> lock(mutex_);
+    for (;;) {
+        wake_.wait(lock, [&] { return stop_ || !tasks_.empty(); });
+        if (tasks_.empty()) return;                    // stop_ and nothing left
+        std::function<void()> task = std::move(tasks_.front());
+        tasks_.pop_front();
+        running_ = true;
+        lock.unlock();
+        task();                                        // tasks report their own failures (they must not throw)
+        lock.lock();
+        running_ = false;
+        if (tasks_.empty()) idle_.notify_all();
+    }
+}
+
+void EnvironmentImpl::drain_step_workers() {
+    for (auto& w : step_workers)
+        if (w) w->drain();
+}
+
 EnvironmentImpl::~EnvironmentImpl() {
+    step_workers.clear();        // finishes the passes already handed over, then joins: before the lanes go away
     // Requests accepted by dlimg_amd_encode_and_mask but never launched (a request still waiting for its coalescing
     // partner): the caller destroyed the environment without dlimg_amd_synchronize.  Their masks will not be written;
     // say so instead of dropping them silently (a destructor cannot return an error).
@@ -157,7 +204,8 @@ EnvironmentImpl::~EnvironmentImpl() {
         std::fprintf(stderr, "dlimgedit: environment destroyed with %zu queued request(s) that were never launched "
                              "(call dlimg_amd_synchronize first)\n", pending.size());
     for (auto& lane : step_passes)
-        for (auto& pass : lane) (void)hipEventDestroy(pass.done);
+        for (auto& pass : lane)
+            if (pass.ticket && pass.ticket->done) (void)hipEventDestroy(pass.ticket->done);
 }
 
 std::string EnvironmentImpl::find_sam_weights() const {

@@ -16,10 +16,13 @@
 #include <dlimgedit/dlimgedit.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <deque>
 #include <filesystem>
+#include <functional>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace dlimg {
@@ -41,6 +44,29 @@ class EmbeddingPool {
     int device_;
     std::mutex mutex_;
     std::vector<float*> free_;
+};
+
+// A host thread that enqueues the passes of ONE execution lane (the device-step queue below): a pass is ~95 kernel
+// launches = 0.3-0.6 ms of host time, and a caller that feeds four lanes from one thread gives the fourth lane its first
+// kernel 1.3-1.7 ms after the first (measured, tools/enqueue_time.py) -- every burst starts with most of the chip idle.
+// With a worker per lane the caller only plans and hands over; the lanes' launch streams are written in parallel.
+// Tasks run in the order they were posted; the destructor finishes what is queued and joins.
+class LaneWorker {
+  public:
+    LaneWorker();
+    ~LaneWorker();
+    LaneWorker(LaneWorker const&) = delete;
+    LaneWorker& operator=(LaneWorker const&) = delete;
+    void post(std::function<void()> task);
+    void drain();                          // returns when nothing is queued and nothing is running
+
+  private:
+    void run();
+    std::mutex mutex_;
+    std::condition_variable wake_, idle_;
+    std::deque<std::function<void()>> tasks_;
+    bool running_ = false, stop_ = false;
+    std::thread thread_;
 };
 
 class EnvironmentImpl {
@@ -91,15 +117,24 @@ class EnvironmentImpl {
     // a multiple of lanes x coalesce then finishes on all lanes together instead of leaving some idle at the end.
     // DLIMGEDIT_STEP_DEPTH (1..64, default 2).
     struct PendingStep { dlimg_ImageView view; int x, y; uint8_t* mask; };
-    struct StepPass { hipEvent_t done; int images; };
+    // A planned pass on its way: handed to the lane's worker (state 0), then on the lane's stream with `done` recorded
+    // behind it (1), or failed while being enqueued (2: its requests are counted in dropped_steps)
+    struct StepTicket { std::atomic<int> state{0}; hipEvent_t done = nullptr; };
+    struct StepPass { std::shared_ptr<StepTicket> ticket; int images; };
     std::mutex pending_mutex;
     std::vector<PendingStep> pending;
     std::vector<std::deque<StepPass>> step_passes;     // per lane of replica 0, oldest first (pending_mutex)
     int coalesce = 2;
     int step_depth = 2;
     int step_cursor = 0;                               // lane after the one used last (pending_mutex)
+    // One enqueue thread per lane of replica 0, created with the first queued request (pending_mutex);
+    // DLIMGEDIT_STEP_WORKERS=0: the calling thread enqueues the passes itself, as before r04
+    std::vector<std::unique_ptr<LaneWorker>> step_workers;
+    bool use_step_workers = true;
+    void drain_step_workers();                         // every pass handed to a worker is on its stream (or has failed)
+    std::mutex step_error_mutex;                       // the two below: written by the workers
     std::string step_error;                            // first failure of a queued pass since the last synchronize (sticky)
-    int dropped_steps = 0;                             // requests that failure took with it (pending_mutex)
+    int dropped_steps = 0;                             // requests that failure took with it
 
   private:
     struct SamLanes {

@@ -215,9 +215,9 @@ namespace dlimg {
 namespace {
 
 // One batched pass of the device-resident hot path over `steps` on lane `lane` of replica 0: pre-process, encode, decode
-// one point prompt per image (single-mask mode), masks to the callers' device buffers.  Enqueues only, and notes the pass
-// in env.step_passes.  pending_mutex held by the caller.
-void run_device_steps(EnvironmentImpl& env, int lane, EnvironmentImpl::PendingStep const* steps, int count) {
+// one point prompt per image (single-mask mode), masks to the callers' device buffers.  Enqueues only; returns the
+// event recorded behind the pass.
+hipEvent_t enqueue_device_steps(EnvironmentImpl& env, int lane, EnvironmentImpl::PendingStep const* steps, int count) {
     SamModel& m = env.lane(0, lane);
     std::lock_guard<std::mutex> lock(m.mutex());
     HIP_CHECK(hipSetDevice(m.device()));
@@ -239,7 +239,51 @@ void run_device_steps(EnvironmentImpl& env, int lane, EnvironmentImpl::PendingSt
         jobs[i] = k::PostJob{m.logits() + (size_t)i * 4 * kLowRes * kLowRes, m.iou() + (size_t)i * 4, steps[i].mask,
                              rs[i].original.width, rs[i].original.height, rs[i].resized.width, rs[i].resized.height};
     m.masks_on_device(jobs.data(), count);
-    env.step_passes[lane].push_back(EnvironmentImpl::StepPass{m.completion(), count});
+    return m.completion();
+}
+
+// A pass whose enqueue failed takes only ITS OWN requests with it: the failure is kept as a sticky error that the next
+// dlimg_amd_synchronize returns -- the callers whose requests were dropped got a success code when they queued them
+// (possibly on other threads), synchronize is where they learn that a mask will not arrive.
+void note_failed_pass(EnvironmentImpl& env, int images, const char* what) {
+    std::lock_guard<std::mutex> lock(env.step_error_mutex);
+    env.dropped_steps += images;
+    if (env.step_error.empty()) env.step_error = what;
+}
+
+// Hands one planned pass to its lane: to the lane's enqueue thread (LaneWorker, environment.hpp), or enqueued right here
+// with DLIMGEDIT_STEP_WORKERS=0.  Notes the pass in env.step_passes either way.  pending_mutex held by the caller.
+void run_device_steps(EnvironmentImpl& env, int lane, EnvironmentImpl::PendingStep const* steps, int count) {
+    auto ticket = std::make_shared<EnvironmentImpl::StepTicket>();
+    if ((int)env.step_passes.size() < env.lane_count(0)) env.step_passes.resize(env.lane_count(0));
+    if (!env.use_step_workers) {
+        try {
+            ticket->done = enqueue_device_steps(env, lane, steps, count);
+            ticket->state.store(1, std::memory_order_release);
+        } catch (std::exception const& ex) {
+            note_failed_pass(env, count, ex.what());
+            throw;
+        }
+        env.step_passes[lane].push_back(EnvironmentImpl::StepPass{ticket, count});
+        return;
+    }
+    if ((int)env.step_workers.size() < env.lane_count(0)) env.step_workers.resize(env.lane_count(0));
+    if (!env.step_workers[lane]) env.step_workers[lane] = std::make_unique<LaneWorker>();
+    env.step_passes[lane].push_back(EnvironmentImpl::StepPass{ticket, count});
+    std::vector<EnvironmentImpl::PendingStep> owned(steps, steps + count);
+    EnvironmentImpl* e = &env;
+    env.step_workers[lane]->post([e, lane, ticket, owned = std::move(owned)] {
+        try {
+            ticket->done = enqueue_device_steps(*e, lane, owned.data(), (int)owned.size());
+            ticket->state.store(1, std::memory_order_release);
+        } catch (std::exception const& ex) {
+            note_failed_pass(*e, (int)owned.size(), ex.what());
+            ticket->state.store(2, std::memory_order_release);
+        } catch (...) {
+            note_failed_pass(*e, (int)owned.size(), "unknown error");
+            ticket->state.store(2, std::memory_order_release);
+        }
+    });
 }
 
 // Forgets the passes that have finished and returns the lanes requests are spread over.
@@ -248,7 +292,14 @@ int retire_device_steps(EnvironmentImpl& env) {
     if ((int)env.step_passes.size() < env.lane_count(0)) env.step_passes.resize(env.lane_count(0));
     for (size_t l = 0; l < env.step_passes.size(); ++l) {
         auto& q = env.step_passes[l];
-        while (!q.empty() && env.lane(0, (int)l).poll_and_recycle(q.front().done)) q.pop_front();
+        while (!q.empty()) {
+            EnvironmentImpl::StepTicket& t = *q.front().ticket;
+            const int state = t.state.load(std::memory_order_acquire);
+            if (state == 0) break;                                     // still with the lane's enqueue thread
+            if (state == 1 && !env.lane(0, (int)l).poll_and_recycle(t.done)) break;
+            t.done = nullptr;                                          // recycled (or never recorded: state 2)
+            q.pop_front();
+        }
     }
     return lanes;
 }
@@ -275,17 +326,15 @@ void flush_device_steps(EnvironmentImpl& env, bool all) {
     queue_state(env, lanes, st);
     const std::vector<StepPlanPass> plan = plan_device_steps(st, (int)env.pending.size(), env.coalesce, env.step_depth, all);
     env.step_cursor = st.cursor;
-    // A pass that fails to enqueue takes only ITS OWN requests with it: the passes launched before it stay launched, the
-    // requests behind it stay queued for the next call, and the failure is kept as a sticky error that the next
-    // dlimg_amd_synchronize returns -- the callers whose requests were dropped got a success code when they queued them
-    // (possibly on other threads), synchronize is where they learn that a mask will not arrive.
+    // A pass that fails to enqueue takes only ITS OWN requests with it (note_failed_pass): the passes launched before it
+    // stay launched, the requests behind it stay queued for the next call.  With enqueue threads nothing fails here.
     size_t done = 0;
     try {
         for (StepPlanPass const& pass : plan) {
             run_device_steps(env, pass.lane, env.pending.data() + done, pass.images);
             done += (size_t)pass.images;
         }
-    } catch (std::exception const& ex) {
+    } catch (std::exception const&) {
         size_t lost = 0;
         size_t at = 0;
         for (StepPlanPass const& pass : plan) {          // the pass that threw is the first one not counted in `done`
@@ -293,8 +342,6 @@ void flush_device_steps(EnvironmentImpl& env, bool all) {
             at += (size_t)pass.images;
         }
         env.pending.erase(env.pending.begin(), env.pending.begin() + std::min(env.pending.size(), done + lost));
-        env.dropped_steps += (int)lost;
-        if (env.step_error.empty()) env.step_error = ex.what();
         throw;
     }
     env.pending.erase(env.pending.begin(), env.pending.begin() + done);
@@ -424,12 +471,14 @@ DLIMG_API int dlimg_amd_synchronize(dlimg_Environment env) {
                 try {
                     flush_device_steps(e, true);
                 } catch (std::exception const&) {
-                }                                   // recorded in e.step_error by flush_device_steps
+                }                                   // recorded in e.step_error (note_failed_pass)
             }
+            e.drain_step_workers();                 // (the workers never take pending_mutex)
         }
         for_each_lane(e, [](SamModel& m) { m.synchronize(); });
         std::lock_guard<std::mutex> lock(e.pending_mutex);
         retire_device_steps(e);
+        std::lock_guard<std::mutex> errors(e.step_error_mutex);
         if (!e.step_error.empty()) {
             const std::string msg = "dlimg_amd_encode_and_mask: " + std::to_string(e.dropped_steps) +
                                     " queued request(s) were dropped because their pass failed: " + e.step_error;
@@ -460,6 +509,7 @@ DLIMG_API int dlimg_amd_set_profiling(dlimg_Environment env, int enabled) {
         {
             std::lock_guard<std::mutex> lock(e.pending_mutex);
             flush_device_steps(e, true);
+            e.drain_step_workers();
         }
         // drain everything; mode 1 pins requests to lane 0 while the clocks run (every kernel alone on the chip),
         // mode 2 leaves the lanes as they are (the regime the throughput figure is measured in)
