@@ -396,6 +396,7 @@ class ext:
                 "dlimg_amd_test_force_gemm_consumer_tile": ([ci], ci),
                 "dlimg_amd_test_gemm": ([ci, ci, ci, vp, vp, vp, vp, ci, ci, vp, vp], ci),
                 "dlimg_amd_test_gemm_ln": ([ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, cf, ci, vp, vp, vp], ci),
+                "dlimg_amd_test_lane_worker": ([ci, ci, vp], ci),
                 "dlimg_amd_test_gemm_stream": ([ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp], ci),
                 "dlimg_amd_test_layernorm": ([vp, vp, vp, cf, ci, ci, ci, vp, vp], ci),
                 "dlimg_amd_test_attention": ([ci, vp, vp, vp, vp, ci, ci, ci, vp], ci),
@@ -419,7 +420,7 @@ class ext:
         return lib
 
     EXPORTS = ("dlimg_amd_device_count", "dlimg_amd_model_geometry", "dlimg_amd_get_embedding", "dlimg_amd_get_logits",
-               "dlimg_amd_decoder_state", "dlimg_amd_test_plan_steps", "dlimg_amd_test_mask_pieces", "dlimg_amd_device_alloc", "dlimg_amd_device_free", "dlimg_amd_copy_to_device", "dlimg_amd_copy_to_host",
+               "dlimg_amd_decoder_state", "dlimg_amd_test_plan_steps", "dlimg_amd_test_lane_worker", "dlimg_amd_test_mask_pieces", "dlimg_amd_device_alloc", "dlimg_amd_device_free", "dlimg_amd_copy_to_device", "dlimg_amd_copy_to_host",
                "dlimg_amd_encode_and_mask", "dlimg_amd_encode_only", "dlimg_amd_synchronize", "dlimg_amd_lane_count",
                "dlimg_amd_queue_config", "dlimg_amd_replica_count", "dlimg_amd_segmentation_device", "dlimg_amd_get_segmentation_masks_device",
                "dlimg_amd_set_profiling",
@@ -657,6 +658,15 @@ class ext:
                                                cls._ptr(resid), wg.ctypes.data, colsum.ctypes.data, b2.ctypes.data,
                                                eps, act, x.ctypes.data, xh.ctypes.data, y.ctypes.data))
         return x, xh, y
+
+    @classmethod
+    def test_lane_worker(cls, tasks: int, sleep_us: int = 0):
+        """Runs the LaneWorker host-logic check; returns the order the tasks ran in (tasks + 1 entries when all ran)."""
+        order = np.full(tasks + 1, -1, dtype=np.int32)
+        ran = cls._l().dlimg_amd_test_lane_worker(tasks, sleep_us, order.ctypes.data)
+        if ran < 0:
+            _check(1)
+        return order[:ran].tolist()
 
     @classmethod
     def test_gemm_stream(cls, A, W, bias, resid_hi, resid_lo, pair: bool):

@@ -190,13 +190,28 @@ void LaneWorker::run() {
     }
 }
 
+LaneWorker& EnvironmentImpl::lane_worker(int replica, int lane) {
+    std::lock_guard<std::mutex> lock(workers_mutex_);
+    if ((int)workers_.size() < replica_count()) workers_.resize(replica_count());
+    auto& row = workers_.at(replica);
+    if ((int)row.size() <= lane) row.resize(lane + 1);
+    if (!row[lane]) row[lane] = std::make_unique<LaneWorker>();
+    return *row[lane];
+}
+
 void EnvironmentImpl::drain_step_workers() {
-    for (auto& w : step_workers)
-        if (w) w->drain();
+    std::vector<LaneWorker*> all;
+    {
+        std::lock_guard<std::mutex> lock(workers_mutex_);
+        if (!workers_.empty())
+            for (auto& w : workers_[0])
+                if (w) all.push_back(w.get());
+    }
+    for (LaneWorker* w : all) w->drain();
 }
 
 EnvironmentImpl::~EnvironmentImpl() {
-    step_workers.clear();        // finishes the passes already handed over, then joins: before the lanes go away
+    workers_.clear();            // finishes the passes already handed over, then joins: before the lanes go away
     // Requests accepted by dlimg_amd_encode_and_mask but never launched (a request still waiting for its coalescing
     // partner): the caller destroyed the environment without dlimg_amd_synchronize.  Their masks will not be written;
     // say so instead of dropping them silently (a destructor cannot return an error).

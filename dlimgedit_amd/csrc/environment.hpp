@@ -101,6 +101,10 @@ class EnvironmentImpl {
     // Device buffers for image embeddings, recycled per replica (see EmbeddingPool).
     std::shared_ptr<EmbeddingPool> embedding_pool(int replica) const { return replicas_.at(replica)->pool; }
 
+    // The enqueue thread of one lane (LaneWorker), created on first use.  Used by the device-step queue and by batch
+    // calls that spread several passes over the lanes (segmentation.cpp, process_batch).
+    LaneWorker& lane_worker(int replica, int lane);
+
     // While set, every request goes to lane 0 of its replica (per-kernel clocks must not see other lanes' kernels).
     void set_single_lane(bool on) { single_lane_.store(on || forced_single_lane_); }
 
@@ -127,9 +131,8 @@ class EnvironmentImpl {
     int coalesce = 2;
     int step_depth = 2;
     int step_cursor = 0;                               // lane after the one used last (pending_mutex)
-    // One enqueue thread per lane of replica 0, created with the first queued request (pending_mutex);
-    // DLIMGEDIT_STEP_WORKERS=0: the calling thread enqueues the passes itself, as before r04
-    std::vector<std::unique_ptr<LaneWorker>> step_workers;
+    // The passes are enqueued by the lanes' own host threads (lane_worker below);
+    // DLIMGEDIT_STEP_WORKERS=0: the calling thread enqueues them itself, as before r04
     bool use_step_workers = true;
     void drain_step_workers();                         // every pass handed to a worker is on its stream (or has failed)
     std::mutex step_error_mutex;                       // the two below: written by the workers
@@ -151,6 +154,8 @@ class EnvironmentImpl {
     SamLanes& lanes(int replica);
     std::string find_sam_weights() const;
     std::vector<std::unique_ptr<Replica>> replicas_;
+    std::mutex workers_mutex_;
+    std::vector<std::vector<std::unique_ptr<LaneWorker>>> workers_;      // [replica][lane] (workers_mutex_)
     std::atomic<unsigned> next_replica_{0};
     std::atomic<bool> single_lane_{false};
     bool forced_single_lane_ = false;     // DLIMGEDIT_SINGLE_LANE

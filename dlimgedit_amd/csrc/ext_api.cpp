@@ -9,6 +9,8 @@
 #include <dlimgedit/dlimgedit_amd.h>
 
 #include <atomic>
+#include <chrono>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -267,12 +269,10 @@ void run_device_steps(EnvironmentImpl& env, int lane, EnvironmentImpl::PendingSt
         env.step_passes[lane].push_back(EnvironmentImpl::StepPass{ticket, count});
         return;
     }
-    if ((int)env.step_workers.size() < env.lane_count(0)) env.step_workers.resize(env.lane_count(0));
-    if (!env.step_workers[lane]) env.step_workers[lane] = std::make_unique<LaneWorker>();
     env.step_passes[lane].push_back(EnvironmentImpl::StepPass{ticket, count});
     std::vector<EnvironmentImpl::PendingStep> owned(steps, steps + count);
     EnvironmentImpl* e = &env;
-    env.step_workers[lane]->post([e, lane, ticket, owned = std::move(owned)] {
+    env.lane_worker(0, lane).post([e, lane, ticket, owned = std::move(owned)] {
         try {
             ticket->done = enqueue_device_steps(*e, lane, owned.data(), (int)owned.size());
             ticket->state.store(1, std::memory_order_release);
@@ -394,6 +394,42 @@ DLIMG_API int dlimg_amd_test_mask_pieces(int count, long long const* mask_bytes,
         copies = n;
     });
     return rc == 0 ? copies : -1;
+}
+
+// LaneWorker (environment.hpp) without a GPU: `tasks` tasks that each sleep `sleep_us` and then note their index; drain()
+// must return only after all of them, in posting order; one more task posted afterwards must have run by the time the
+// destructor returns.  out_order: tasks + 1 entries.  Returns the number of tasks that ran.
+DLIMG_API int dlimg_amd_test_lane_worker(int tasks, int sleep_us, int* out_order) {
+    int ran = -1;
+    const int rc = guarded([&] {
+        DLIMG_ASSERT(tasks >= 0 && out_order != nullptr);
+        std::vector<int> order;
+        std::mutex m;
+        int after_drain = -1;
+        {
+            LaneWorker w;
+            for (int i = 0; i < tasks; ++i)
+                w.post([&, i] {
+                    if (sleep_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(sleep_us));
+                    std::lock_guard<std::mutex> lock(m);
+                    order.push_back(i);
+                });
+            w.drain();
+            {
+                std::lock_guard<std::mutex> lock(m);
+                after_drain = (int)order.size();
+            }
+            w.post([&] {
+                if (sleep_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(sleep_us));
+                std::lock_guard<std::mutex> lock(m);
+                order.push_back(tasks);
+            });
+        }                                        // the destructor finishes what is queued
+        if (after_drain != tasks) throw Exception("LaneWorker::drain returned with tasks outstanding");
+        for (size_t i = 0; i < order.size(); ++i) out_order[i] = order[i];
+        ran = (int)order.size();
+    });
+    return rc == 0 ? ran : -1;
 }
 
 DLIMG_API int dlimg_amd_test_plan_steps(int lanes, int* passes_in_flight, int* images_in_flight, int* cursor, int pending, int width,

@@ -153,6 +153,7 @@ class SamModel {
     hipStream_t stream() const { return stream_; }
     std::mutex& mutex() { return mutex_; }
     int device() const { return device_; }
+    int lane_index() const { return lane_index_; }
     LaneBoard const* board() const { return board_.get(); }
 
     // All methods below require mutex() to be held by the caller, unless stated otherwise.  The mutex covers the

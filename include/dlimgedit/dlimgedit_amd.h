@@ -59,10 +59,16 @@ DLIMG_API int dlimg_amd_device_alloc(dlimg_Environment env, size_t bytes, void**
 DLIMG_API int dlimg_amd_device_free(dlimg_Environment env, void* ptr);
 DLIMG_API int dlimg_amd_copy_to_device(dlimg_Environment env, void* dst_dev, void const* src_host, size_t bytes);
 DLIMG_API int dlimg_amd_copy_to_host(dlimg_Environment env, void* dst_host, void const* src_dev, size_t bytes);
+/* Host logic of the lanes' enqueue threads (csrc/environment.hpp, LaneWorker), callable without a GPU (tests): `tasks` tasks
+ * sleeping sleep_us each; drain must wait for all of them, they run in posting order, and a task posted after the drain has
+ * run when the worker is destroyed.  out_order: tasks + 1 entries.  Returns the number of tasks that ran, -1 on error. */
+DLIMG_API int dlimg_amd_test_lane_worker(int tasks, int sleep_us, int* out_order);
 /* One pass of the hot path over `count` images already in HBM: pre-process, encode (one batched
  * pass), decode one point prompt per image (single-mask mode) and write the 0/255 masks to
  * dev_masks[i] (width*height bytes each, device memory).  Views carry DEVICE pixel pointers.
  * points: count x {x,y}.  Asynchronous: returns once the request is accepted; call dlimg_amd_synchronize to wait.
+ * The passes are put on the lanes' streams by one host thread per lane (DLIMGEDIT_STEP_WORKERS=0: by the calling thread);
+ * a pass that cannot be enqueued drops its own requests only, and dlimg_amd_synchronize reports how many and why.
  * Independent single-image requests are coalesced into batched passes of DLIMGEDIT_COALESCE images (default 2, 1 = off;
  * dynamic batching -- the results are bit-identical to single-image passes); a request that is still waiting for a
  * partner is launched by the next request or by dlimg_amd_synchronize (which deals what is left evenly over the lanes). */

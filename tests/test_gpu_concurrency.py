@@ -268,3 +268,46 @@ def test_a_synchronous_caller_is_recognised_as_alone_and_concurrent_callers_are_
     assert n == 100 and alone < n, (n, alone)          # (how many depends on the timing; that not all are is certain)
     print(f"concurrent callers: {alone} of {n} one-image passes found the other lanes idle")
     env.close()
+
+
+@pytest.mark.parametrize("workers", ["1", "0"])
+def test_step_queue_with_and_without_enqueue_threads(model_dirs, workers, monkeypatch):
+    """dlimg_amd_encode_and_mask with the lanes' own enqueue threads (default) and with the caller enqueueing
+    (DLIMGEDIT_STEP_WORKERS=0): three bursts of single requests (coalesced into passes of two, the odd one dealt out by
+    synchronize) and one call that is a batch already; every mask equal to the ABI path's.  A request that is refused up
+    front (NULL mask pointer) leaves nothing behind for synchronize to report."""
+    from dlimgedit_amd import api
+    monkeypatch.setenv("DLIMGEDIT_STEP_WORKERS", workers)
+    mdir, params, cfg = model_dirs("vit_test")
+    env = api.Environment(api.Options(api.Backend.gpu, mdir))
+    ext = api.ext
+    imgs = [synthetic_image(70 + i) for i in range(5)]
+    ptrs, mptrs = [], []
+    for im in imgs:
+        p = ext.device_alloc(env, im.nbytes)
+        ext.copy_to_device(env, p, im)
+        ptrs.append(p)
+        mptrs.append(ext.device_alloc(env, 1024 * 1024))
+    try:
+        want = [api.Segmentation.process(api.ImageView(im, api.Channels.rgba), env).compute_mask(api.Point(300, 700)) for im in imgs]
+        for rep in range(3):
+            for p, m in zip(ptrs, mptrs):
+                ext.encode_and_mask(env, ext.device_views([p], 1024, 1024), [api.Point(300, 700)], [m])
+            ext.synchronize(env)
+            for w, m in zip(want, mptrs):
+                got = np.zeros((1024, 1024), np.uint8)
+                ext.copy_to_host(env, got, m)
+                assert np.array_equal(got, w), (workers, rep)
+        # one call that is a batch already
+        ext.encode_and_mask(env, ext.device_views(ptrs[:4], 1024, 1024), [api.Point(300, 700)] * 4, mptrs[:4])
+        ext.synchronize(env)
+        for w, m in zip(want[:4], mptrs[:4]):
+            got = np.zeros((1024, 1024), np.uint8)
+            ext.copy_to_host(env, got, m)
+            assert np.array_equal(got, w)
+        with pytest.raises(api.Error):
+            ext.encode_and_mask(env, ext.device_views([ptrs[0]], 1024, 1024), [api.Point(1, 1)], [0])
+        ext.synchronize(env)          # nothing was accepted, nothing to report
+    finally:
+        for p in ptrs + mptrs:
+            ext.device_free(env, p)

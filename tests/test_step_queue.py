@@ -69,3 +69,13 @@ def test_ties_take_turns_when_completion_cannot_be_observed():
         plan, _, _, cursor = api.ext.plan_steps([0] * 4, [0] * 4, cursor, 2, 2, 2, False)
         seen.append(plan[0][0])
     assert seen == [0, 1, 2, 3, 0, 1, 2, 3]
+
+
+def test_lane_worker_runs_tasks_in_order_and_drain_waits():
+    """The lanes' enqueue threads (csrc/environment.hpp, LaneWorker): tasks run one at a time in posting order, drain()
+    returns only when nothing is queued or running, and the destructor finishes what was posted after the drain."""
+    from dlimgedit_amd import api
+    assert api.ext.test_lane_worker(0) == [0]
+    assert api.ext.test_lane_worker(1, 200) == [0, 1]
+    assert api.ext.test_lane_worker(40, 50) == list(range(41))
+    assert api.ext.test_lane_worker(500, 0) == list(range(501))
