@@ -771,22 +771,6 @@ DLIMG_DEVICE void pp_epilogue(const k::GemmArgs& a, float4v (&acc)[NI][4], char*
     }
 }
 
-// Tile of a workgroup of the ping-pong kernels.  The XCD remap gives every XCD a contiguous range of the tile order; INSIDE
-// that range the order is "four rows at a time, down the rows first": with other lanes' kernels on most of the CUs only a
-// handful of this launch's workgroups run on an XCD at any moment, and in row-major order those would be one A panel
-// against eight different W panels, each of which the next row fetches again after the other lanes' traffic has pushed it
-// out of the 4 MB L2.  Rows first, the workgroups in flight cover 4 A panels x 2 W panels, every W panel is used by four
-// workgroups at about the same time and the four A panels stay hot for the whole sweep over the columns.
-DLIMG_DEVICE void pp_tile_origin(int tile, int ntm, int ntn, int bm, int bn, int& m0, int& n0) {
-    constexpr int GROUP = 4;
-    const int per_group = GROUP * ntn;
-    const int first = (tile / per_group) * GROUP;
-    const int rows = min(GROUP, ntm - first);
-    const int within = tile % per_group;
-    m0 = (first + within % rows) * bm;
-    n0 = (within / rows) * bn;
-}
-
 // One tile per workgroup.  [r04, measured and NOT kept (commit e1871cc holds the code and its parity tests): a PERSISTENT
 // form -- grid = ceil(tiles / rounds), each workgroup walking its tiles, the next tile's first operands (96 KB of DMA)
 // requested before the epilogue, slabs in the one LDS region those leave free, the next tile's vectors / statistics into
@@ -809,8 +793,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(k::GemmArgs a) {
 
     const int ntn = a.N / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    int m0, n0;
-    pp_tile_origin(tile, a.M / BM, ntn, BM, BN, m0, n0);
+    const int m0 = (tile / ntn) * BM;
+    const int n0 = (tile % ntn) * BN;
     const int nk = a.K / 64;
 
     float* rowstat = reinterpret_cast<float*>(smem + 2 * kPPBufBytes);
@@ -990,8 +974,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(k::GemmArgs a) {
 
     const int ntn = a.N / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    int m0, n0;
-    pp_tile_origin(tile, a.M / BM, ntn, BM, BN, m0, n0);
+    const int m0 = (tile / ntn) * BM;
+    const int n0 = (tile % ntn) * BN;
     const int nk = a.K / 64;
 
     float* rowstat = reinterpret_cast<float*>(smem + pp128_operands(BM));

@@ -13,7 +13,8 @@ for round in 1 2 3; do
 import json
 d = json.loads(open("gpurun_out/abh/${n}_$round.json").read().strip().splitlines()[-1])
 u = d["roofline"]["under_lanes"]
-print("$round", "$n", round(d["value"], 1), "frac", round(d["roofline"]["frac"], 4), "gemm under lanes us", round(u["avg_gemm_launch_us"], 1), flush=True)
+pk = d["roofline"]["per_kernel"]
+print("$round", "$n", round(d["value"], 1), "alone us:", {k: round(v["avg_launch_us"], 1) for k, v in pk.items()}, "gemm under lanes us", round(u["avg_gemm_launch_us"], 1), flush=True)
 PY
   done
 done
