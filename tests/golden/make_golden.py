@@ -5,7 +5,7 @@ independent implementation of the published SAM model that is importable there (
 The vectors pin the CPU oracle (oracle/sam_oracle.py); the reference's own golden masks are
 git-LFS stubs in the checkout and cannot be used.
 
-    python tests/golden/make_golden.py [--full] [--vit-h] [--only NAME]
+    python tests/golden/make_golden.py [--full] [--vit-l] [--vit-h] [--only NAME]
 
 What is stored (all small, strided samples where tensors are big):
   sam_<variant>.npz   image seed, prompt, embedding samples, low-res logit samples, all four IoU predictions,
@@ -148,6 +148,8 @@ if __name__ == "__main__":
         make_variant("vit_test80", seed=7, image_seed=4)
     if "--full" in sys.argv and want("vit_b"):
         make_variant("vit_b", seed=0, image_seed=0)
+    if "--vit-l" in sys.argv and want("vit_l"):     # a minute or two of CPU time, ~4 GB of memory
+        make_variant("vit_l", seed=0, image_seed=0, compare_oracle=False)
     if "--vit-h" in sys.argv:       # several minutes of CPU time and ~10 GB of memory each
         if want("vit_h"):
             make_variant("vit_h", seed=0, image_seed=0, compare_oracle=False)

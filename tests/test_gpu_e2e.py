@@ -280,7 +280,7 @@ def test_invalid_arguments_are_errors_not_crashes(api, session):
     assert api.api().get_segmentation_mask(seg._handle, None, None, masks, acc) == 1    # neither point nor region
 
 
-@pytest.mark.parametrize("variant", ["vit_b", "vit_h"])
+@pytest.mark.parametrize("variant", ["vit_b", "vit_l", "vit_h"])
 def test_full_size_models_against_committed_golden(api, model_dirs, monkeypatch, variant):
     """The real model sizes through the drop-in ABI against the committed fixtures (tests/golden/sam_<variant>.npz:
     samples of Hugging Face SamModel's embedding / low-res logits and its 1024x1024 masks on the same seeded weights
