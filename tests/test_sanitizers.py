@@ -1,0 +1,145 @@
+"""AddressSanitizer + UndefinedBehaviorSanitizer over the library's image file readers (csrc/image_io.cpp: PNG through
+zlib; csrc/jpeg_decode.cpp: the JPEG decoder) on the CPU: the two pieces of the library that parse bytes it did not
+produce (reference: stb_image behind /root/reference/src/image.cpp:11-23).  The sources are compiled as they lie in the
+tree with ROCm's clang and -fsanitize=address,undefined (tests/sanitize/image_io_harness.cpp supplies main() and the
+error helpers); well-formed files of every flavour the decoder takes must load, damaged ones (truncated anywhere, bytes
+flipped, segment lengths overwritten) may be refused but must never trip a sanitizer."""
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+CLANG = Path("/opt/rocm/lib/llvm/bin/clang++")
+PIL = pytest.importorskip("PIL.Image")
+
+
+@pytest.fixture(scope="module")
+def harness(tmp_path_factory):
+    if not CLANG.exists():
+        pytest.skip("ROCm clang not found")
+    out = tmp_path_factory.mktemp("sanitize") / "io_harness"
+    csrc = ROOT / "dlimgedit_amd" / "csrc"
+    cmd = [str(CLANG), "-std=c++17", "-O1", "-g", "-w", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", f"-I{ROOT / 'include'}", f"-I{csrc}",
+           str(ROOT / "tests" / "sanitize" / "image_io_harness.cpp"), str(csrc / "image_io.cpp"), str(csrc / "jpeg_decode.cpp"),
+           "-lz", "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 and "sanitizer" in (r.stderr + r.stdout).lower() and "cannot find" in (r.stderr + r.stdout).lower():
+        pytest.skip("this clang has no sanitizer runtime")
+    assert r.returncode == 0, r.stderr[-3000:]
+    return out
+
+
+def run(harness, files):
+    r = subprocess.run([str(harness), *map(str, files)], capture_output=True, text=True, timeout=600,
+                       env={"ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0", "UBSAN_OPTIONS": "print_stacktrace=1"})
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-4000:])
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+    loaded = [l for l in r.stdout.splitlines() if l.startswith("loaded ")]
+    refused = [l for l in r.stdout.splitlines() if l.startswith("refused ")]
+    assert len(loaded) + len(refused) == len(files)
+    return loaded, refused
+
+
+def sample_files(tmp):
+    """Small well-formed files: JPEG baseline / progressive / restart intervals / grey / 4:2:0 / 4:4:4 / odd sizes, PNG
+    grey / RGB / RGBA / palette / 16-bit / interlaced."""
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:67, 0:93]
+    rgb = np.stack([(xx * 2.5) % 256, (yy * 3.1) % 256, (xx + yy) % 256], -1).astype(np.uint8)
+    rgb = np.clip(rgb.astype(np.int32) + rng.integers(-12, 12, rgb.shape), 0, 255).astype(np.uint8)
+    files = []
+
+    def jpeg(name, arr, **kw):
+        p = tmp / name
+        PIL.fromarray(arr).save(p, "JPEG", **kw)
+        files.append(p)
+
+    jpeg("base_420.jpg", rgb, quality=85, subsampling=2)
+    jpeg("base_444.jpg", rgb, quality=92, subsampling=0)
+    jpeg("base_422.jpg", rgb, quality=70, subsampling=1)
+    jpeg("prog_420.jpg", rgb, quality=80, subsampling=2, progressive=True)
+    jpeg("prog_444.jpg", rgb, quality=95, subsampling=0, progressive=True)
+    jpeg("grey.jpg", rgb[:, :, 0], quality=88)
+    jpeg("grey_prog.jpg", rgb[:, :, 1], quality=60, progressive=True)
+    jpeg("restart.jpg", rgb, quality=85, subsampling=2, restart_marker_blocks=3)
+    jpeg("tiny.jpg", rgb[:5, :7], quality=90)
+
+    def png(name, img, **kw):
+        p = tmp / name
+        img.save(p, "PNG", **kw)
+        files.append(p)
+
+    png("rgb.png", PIL.fromarray(rgb))
+    png("rgba.png", PIL.fromarray(np.dstack([rgb, 255 - rgb[:, :, 0]])))
+    png("grey.png", PIL.fromarray(rgb[:, :, 2]))
+    png("palette.png", PIL.fromarray(rgb).convert("P"))
+    png("grey16.png", PIL.fromarray((rgb[:, :, 0].astype(np.uint16) * 257)))
+    return files
+
+
+def test_well_formed_files_load_clean(harness, tmp_path):
+    files = sample_files(tmp_path) + [ROOT / "tests" / "golden" / "truck.jpg"]
+    loaded, refused = run(harness, files)
+    assert len(loaded) >= len(files) - 2, refused       # (16-bit / palette PNG flavours may be refused by design)
+    for line in refused:
+        assert "grey16.png" in line or "palette.png" in line, line
+
+
+def test_damaged_files_never_trip_a_sanitizer(harness, tmp_path):
+    rng = np.random.default_rng(99)
+    originals = sample_files(tmp_path)
+    truck = (ROOT / "tests" / "golden" / "truck.jpg").read_bytes()
+    blobs = [(p.name, p.read_bytes()) for p in originals] + [("truck.jpg", truck[:60000])]
+    damaged = []
+    for name, data in blobs:
+        n = len(data)
+        stem, ext = name.rsplit(".", 1)
+        variants = []
+        for cut in sorted(set(int(c) for c in np.concatenate([np.arange(0, min(n, 40)), rng.integers(0, n, 25)]))):
+            variants.append(data[:cut])                                     # truncated anywhere, header included
+        for _ in range(40):                                                 # a few bytes flipped
+            b = bytearray(data)
+            for pos in rng.integers(0, n, int(rng.integers(1, 6))):
+                b[pos] = int(rng.integers(0, 256))
+            variants.append(bytes(b))
+        for _ in range(20):                                                 # a run of bytes replaced by 0xFF / 0x00 / noise
+            b = bytearray(data)
+            pos = int(rng.integers(0, n))
+            run_len = int(rng.integers(1, 64))
+            fill = [b"\xff", b"\x00", None][int(rng.integers(0, 3))]
+            b[pos:pos + run_len] = (fill * run_len) if fill else bytes(rng.integers(0, 256, run_len, dtype=np.uint8))
+            variants.append(bytes(b[:n]))
+        if ext == "jpg":                                                    # segment lengths and dimensions overwritten
+            for marker in (b"\xff\xc0", b"\xff\xc2", b"\xff\xc4", b"\xff\xdb", b"\xff\xda", b"\xff\xdd"):
+                at = data.find(marker)
+                if at < 0:
+                    continue
+                for value in (0, 1, 2, 3, 0x7fff, 0xffff):
+                    b = bytearray(data)
+                    b[at + 2:at + 4] = value.to_bytes(2, "big")
+                    variants.append(bytes(b))
+                for off in (5, 7):                                          # height / width of a frame header
+                    for value in (0, 1, 0xffff):
+                        b = bytearray(data)
+                        b[at + off:at + off + 2] = value.to_bytes(2, "big")
+                        variants.append(bytes(b))
+        else:                                                               # PNG: chunk lengths and IHDR fields, CRCs left stale
+            for at in (8, 33):
+                for value in (0, 1, 0x7fffffff, 0xffffffff):
+                    b = bytearray(data)
+                    b[at:at + 4] = value.to_bytes(4, "big")
+                    variants.append(bytes(b))
+            for field in (16, 20):                                          # width / height
+                for value in (0, 1, 1 << 24, 0xffffffff):
+                    b = bytearray(data)
+                    b[field:field + 4] = value.to_bytes(4, "big")
+                    variants.append(bytes(b))
+        for i, v in enumerate(variants):
+            p = tmp_path / f"{stem}_{i:03d}.{ext}"
+            p.write_bytes(v)
+            damaged.append(p)
+    loaded, refused = run(harness, damaged)
+    assert len(refused) > len(damaged) // 4          # most damage is noticed; what still loads is only required to be memory-safe
