@@ -150,46 +150,6 @@ EnvironmentImpl::EnvironmentImpl(dlimg_Options const& options) : backend(options
     }
 }
 
-LaneWorker::LaneWorker() : thread_([this] { run(); }) {}
-
-LaneWorker::~LaneWorker() {
-    {
-        std::lock_guard<std::mutex> lock(mutex_);
-        stop_ = true;
-    }
-    wake_.notify_all();
-    if (thread_.joinable()) thread_.join();
-}
-
-void LaneWorker::post(std::function<void()> task) {
-    {
-        std::lock_guard<std::mutex> lock(mutex_);
-        tasks_.push_back(std::move(task));
-    }
-    wake_.notify_one();
-}
-
-void LaneWorker::drain() {
-    std::unique_lock<std::mutex> lock(mutex_);
-    idle_.wait(lock, [&] { return tasks_.empty() && !running_; });
-}
-
-void LaneWorker::run() {
-    std::unique_lock<std::mutex> lock(mutex_);
-    for (;;) {
-        wake_.wait(lock, [&] { return stop_ || !tasks_.empty(); });
-        if (tasks_.empty()) return;                    // stop_ and nothing left
-        std::function<void()> task = std::move(tasks_.front());
-        tasks_.pop_front();
-        running_ = true;
-        lock.unlock();
-        task();                                        // tasks report their own failures (they must not throw)
-        lock.lock();
-        running_ = false;
-        if (tasks_.empty()) idle_.notify_all();
-    }
-}
-
 LaneWorker& EnvironmentImpl::lane_worker(int replica, int lane) {
     std::lock_guard<std::mutex> lock(workers_mutex_);
     if ((int)workers_.size() < replica_count()) workers_.resize(replica_count());

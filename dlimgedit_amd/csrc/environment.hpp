@@ -12,6 +12,7 @@
 
 #include "common.hpp"
 #include "sam_model.hpp"
+#include "lane_worker.hpp"
 
 #include <dlimgedit/dlimgedit.h>
 
@@ -44,29 +45,6 @@ class EmbeddingPool {
     int device_;
     std::mutex mutex_;
     std::vector<float*> free_;
-};
-
-// A host thread that enqueues the passes of ONE execution lane (the device-step queue below): a pass is ~95 kernel
-// launches = 0.3-0.6 ms of host time, and a caller that feeds four lanes from one thread gives the fourth lane its first
-// kernel 1.3-1.7 ms after the first (measured, tools/enqueue_time.py) -- every burst starts with most of the chip idle.
-// With a worker per lane the caller only plans and hands over; the lanes' launch streams are written in parallel.
-// Tasks run in the order they were posted; the destructor finishes what is queued and joins.
-class LaneWorker {
-  public:
-    LaneWorker();
-    ~LaneWorker();
-    LaneWorker(LaneWorker const&) = delete;
-    LaneWorker& operator=(LaneWorker const&) = delete;
-    void post(std::function<void()> task);
-    void drain();                          // returns when nothing is queued and nothing is running
-
-  private:
-    void run();
-    std::mutex mutex_;
-    std::condition_variable wake_, idle_;
-    std::deque<std::function<void()>> tasks_;
-    bool running_ = false, stop_ = false;
-    std::thread thread_;
 };
 
 class EnvironmentImpl {

@@ -220,14 +220,17 @@ void SegmentationImpl::process_batch(EnvironmentImpl& env, SegmentationImpl* con
                 // which one thread would spend lane after lane while the later lanes' part of the chip waits (8 images
                 // from one thread: 718 -> 734 images/s).  With several callers the lanes are fed in parallel anyway and
                 // the hand-over only costs (two threads x 8 images: 846 without, 824 with)
-                struct Handed { SamModel* model; std::promise<hipEvent_t> result; };
-                std::vector<std::unique_ptr<Handed>> handed;
+                // (the promise is shared with the task: it must outlive the task's set_value call, which may still be
+                // returning when this thread has its answer)
+                struct Handed { SamModel* model; std::promise<hipEvent_t> result; std::future<hipEvent_t> answer; };
+                std::vector<std::shared_ptr<Handed>> handed;
                 for (size_t base = 0; base < mine.size(); base += chunk) {
                     const int n = (int)std::min<size_t>(chunk, mine.size() - base);
                     SamModel& model = env.next_lane(replica);
-                    handed.push_back(std::make_unique<Handed>());
-                    Handed* h = handed.back().get();
+                    auto h = std::make_shared<Handed>();
                     h->model = &model;
+                    h->answer = h->result.get_future();
+                    handed.push_back(h);
                     env.lane_worker(replica, model.lane_index()).post([h, &run_chunk, base, n] {
                         try {
                             h->result.set_value(run_chunk(*h->model, base, n));
@@ -239,7 +242,7 @@ void SegmentationImpl::process_batch(EnvironmentImpl& env, SegmentationImpl* con
                 std::exception_ptr first;
                 for (auto& h : handed) {             // every task is waited for: they refer to this frame
                     try {
-                        waiting.push_back(Waiting{h->model, h->result.get_future().get()});
+                        waiting.push_back(Waiting{h->model, h->answer.get()});
                     } catch (...) {
                         drain_lane(h->model);        // whatever the failed pass queued runs to completion first
                         if (!first) first = std::current_exception();

@@ -143,3 +143,34 @@ def test_damaged_files_never_trip_a_sanitizer(harness, tmp_path):
             damaged.append(p)
     loaded, refused = run(harness, damaged)
     assert len(refused) > len(damaged) // 4          # most damage is noticed; what still loads is only required to be memory-safe
+
+
+def _build(tmp, name, source, sanitize, extra=()):
+    if not CLANG.exists():
+        pytest.skip("ROCm clang not found")
+    out = tmp / name
+    cmd = [str(CLANG), "-std=c++17", "-O1", "-g", "-w", f"-fsanitize={sanitize}", "-fno-sanitize-recover=all",
+           f"-I{ROOT / 'dlimgedit_amd' / 'csrc'}", str(ROOT / "tests" / "sanitize" / source), "-pthread", *extra, "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 and "cannot find" in (r.stderr + r.stdout).lower():
+        pytest.skip("this clang has no runtime for -fsanitize=" + sanitize)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return out
+
+
+def test_lane_worker_and_its_hand_over_protocols_under_thread_sanitizer(tmp_path):
+    """csrc/lane_worker.hpp (the lanes' enqueue threads) under ThreadSanitizer: posts from several threads beside drains,
+    the step queue's ticket protocol, the batch call's shared promise (tests/sanitize/lane_worker_tsan.cpp)."""
+    exe = _build(tmp_path, "lane_worker_tsan", "lane_worker_tsan.cpp", "thread")
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600, env={"TSAN_OPTIONS": "halt_on_error=1"})
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-1000:], r.stderr[-4000:])
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
+
+
+def test_planners_on_random_inputs_under_address_sanitizer(tmp_path):
+    """csrc/step_queue.hpp and csrc/mask_pieces.hpp on 220 000 random inputs with ASan + UBSan, every plan checked against
+    the invariants its caller relies on (tests/sanitize/planners_fuzz.cpp)."""
+    exe = _build(tmp_path, "planners_fuzz", "planners_fuzz.cpp", "address,undefined")
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-1000:], r.stderr[-4000:])
+    assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
