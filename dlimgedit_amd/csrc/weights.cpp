@@ -8,7 +8,7 @@ namespace dlimg {
 namespace {
 
 template <typename T> T read_at(std::vector<char> const& raw, size_t off) {
-    if (off + sizeof(T) > raw.size()) throw Exception("weight file truncated");
+    if (off > raw.size() || sizeof(T) > raw.size() - off) throw Exception("weight file truncated");
     T v;
     std::memcpy(&v, raw.data() + off, sizeof(T));
     return v;
@@ -37,9 +37,15 @@ WeightFile::WeightFile(std::string const& path) : path_(path) {
     geom_.num_heads = cfg[2];
     geom_.mlp_dim = cfg[3];
     int n_global = cfg[4];
-    if (geom_.embed_dim <= 0 || geom_.depth <= 0 || geom_.num_heads <= 0 || n_global < 0 || n_global > 8)
+    // (bounds generous enough for any SAM size; they keep every product of these numbers far inside 64 bits)
+    if (geom_.embed_dim <= 0 || geom_.embed_dim > (1 << 16) || geom_.depth <= 0 || geom_.depth > 1024 || geom_.num_heads <= 0 ||
+        geom_.num_heads > geom_.embed_dim || geom_.embed_dim % geom_.num_heads != 0 || geom_.mlp_dim <= 0 ||
+        geom_.mlp_dim > (1 << 20) || n_global < 0 || n_global > 8)
         throw Exception("'" + path + "': invalid model geometry in header");
-    for (int i = 0; i < n_global; ++i) geom_.global_attn_indexes.push_back(cfg[5 + i]);
+    for (int i = 0; i < n_global; ++i) {
+        if (cfg[5 + i] < 0 || cfg[5 + i] >= geom_.depth) throw Exception("'" + path + "': invalid model geometry in header");
+        geom_.global_attn_indexes.push_back(cfg[5 + i]);
+    }
 
     constexpr size_t entry = 64 + 4 + 4 + 32 + 8 + 8;
     size_t pos = 80;
@@ -51,10 +57,18 @@ WeightFile::WeightFile(std::string const& path) : path_(path) {
         uint32_t ndim = read_at<uint32_t>(raw_, pos + 68);
         if (dtype != 0 || ndim < 1 || ndim > 4) throw Exception("'" + path + "': unsupported tensor '" + name + "'");
         HostTensor t;
-        for (uint32_t d = 0; d < ndim; ++d) t.dims.push_back((int64_t)read_at<uint64_t>(raw_, pos + 72 + 8 * d));
+        uint64_t numel = 1;
+        for (uint32_t d = 0; d < ndim; ++d) {
+            const uint64_t dim = read_at<uint64_t>(raw_, pos + 72 + 8 * d);
+            // no dimension and no product of dimensions beyond what the file itself could hold (no wrap-around either)
+            if (dim == 0 || dim > raw_.size() || numel > raw_.size() / dim)
+                throw Exception("'" + path + "': tensor '" + name + "' out of bounds");
+            numel *= dim;
+            t.dims.push_back((int64_t)dim);
+        }
         uint64_t off = read_at<uint64_t>(raw_, pos + 104);
         uint64_t nbytes = read_at<uint64_t>(raw_, pos + 112);
-        if (nbytes != t.numel() * 4 || off % 4 || off + nbytes > raw_.size())
+        if (numel > raw_.size() / 4 || nbytes != numel * 4 || off % 4 || off > raw_.size() || nbytes > raw_.size() - off)
             throw Exception("'" + path + "': tensor '" + name + "' out of bounds");
         t.data = reinterpret_cast<const float*>(raw_.data() + off);
         tensors_.emplace(name, std::move(t));

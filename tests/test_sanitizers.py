@@ -33,7 +33,7 @@ def harness(tmp_path_factory):
 
 
 def run(harness, files):
-    r = subprocess.run([str(harness), *map(str, files)], capture_output=True, text=True, timeout=600,
+    r = subprocess.run([str(harness), *map(str, files)], capture_output=True, text=True, errors="replace", timeout=600,
                        env={"ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0", "UBSAN_OPTIONS": "print_stacktrace=1"})
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-4000:])
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
@@ -162,7 +162,7 @@ def test_lane_worker_and_its_hand_over_protocols_under_thread_sanitizer(tmp_path
     """csrc/lane_worker.hpp (the lanes' enqueue threads) under ThreadSanitizer: posts from several threads beside drains,
     the step queue's ticket protocol, the batch call's shared promise (tests/sanitize/lane_worker_tsan.cpp)."""
     exe = _build(tmp_path, "lane_worker_tsan", "lane_worker_tsan.cpp", "thread")
-    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600, env={"TSAN_OPTIONS": "halt_on_error=1"})
+    r = subprocess.run([str(exe)], capture_output=True, text=True, errors="replace", timeout=600, env={"TSAN_OPTIONS": "halt_on_error=1"})
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-1000:], r.stderr[-4000:])
     assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
 
@@ -171,6 +171,87 @@ def test_planners_on_random_inputs_under_address_sanitizer(tmp_path):
     """csrc/step_queue.hpp and csrc/mask_pieces.hpp on 220 000 random inputs with ASan + UBSan, every plan checked against
     the invariants its caller relies on (tests/sanitize/planners_fuzz.cpp)."""
     exe = _build(tmp_path, "planners_fuzz", "planners_fuzz.cpp", "address,undefined")
-    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, errors="replace", timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-1000:], r.stderr[-4000:])
     assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+
+
+def test_damaged_weight_files_never_trip_a_sanitizer(tmp_path):
+    """csrc/weights.cpp (the DLW parser: model files come from outside the library) under ASan + UBSan: an intact file of
+    the reduced variant loads with every tensor readable end to end; files with the header, the geometry, the tensor
+    table (dimensions, offsets, sizes -- including values whose sums or products wrap around 64 bits) or the tail damaged
+    are refused or loaded, never a report."""
+    import struct
+    from dlimgedit_amd import weights as W
+    from dlimgedit_amd.sam_config import get_config
+    exe = _build(tmp_path, "weights_harness", "weights_harness.cpp", "address,undefined",
+                 extra=["-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", f"-I{ROOT / 'include'}",
+                        str(ROOT / "dlimgedit_amd" / "csrc" / "weights.cpp")])
+    cfg = get_config("vit_test")
+    params = W.synthetic_weights(cfg, 3)
+    full = tmp_path / "full.dlw"
+    W.save_weights(full, cfg, params)
+    whole = full.read_bytes()
+    # a small file in the same format for the damaged variants: header and geometry of the real one, its first tensors of
+    # modest size with their table entries re-pointed (entry: name[64], dtype, ndim, dims[4], offset, bytes)
+    n_all = struct.unpack_from("<I", whole, 12)[0]
+    picked = []
+    for i in range(n_all):
+        e = whole[80 + 120 * i: 80 + 120 * (i + 1)]
+        off, nbytes = struct.unpack_from("<QQ", e, 104)
+        if nbytes <= 32768 and len(picked) < 12:
+            picked.append((e, whole[off:off + nbytes]))
+    table, payload, at = b"", b"", 80 + 120 * len(picked)
+    for e, blob in picked:
+        table += e[:104] + struct.pack("<QQ", at + len(payload), len(blob))
+        payload += blob
+    data = whole[:12] + struct.pack("<I", len(picked)) + whole[16:80] + table + payload
+    good = tmp_path / "good.dlw"
+    good.write_bytes(data)
+    count = len(picked)
+    names = [data[80 + 120 * i: 80 + 120 * i + 64].split(b"\0")[0].decode() for i in range(count)]
+    (tmp_path / "names.txt").write_text("\n".join(names) + "\n")
+    rng = np.random.default_rng(17)
+    files = [good]
+
+    def add(blob):
+        p = tmp_path / f"w_{len(files):04d}.dlw"
+        p.write_bytes(blob)
+        files.append(p)
+
+    for cut in list(range(0, 90)) + [int(c) for c in rng.integers(90, len(data), 40)]:
+        add(data[:cut])
+    wild = [0, 1, 3, 4, 0x7fffffff, 0xffffffff, 1 << 32, (1 << 62), (1 << 63), (1 << 64) - 4, (1 << 64) - 1]
+    for field in range(8, 80, 4):                           # version, count, geometry words
+        for v in (0, 1, 0x7fffffff, 0xffffffff, 0x80000000):
+            b = bytearray(data)
+            struct.pack_into("<I", b, field, v)
+            add(bytes(b))
+    for entry in (0, 1, count // 2, count - 1):             # tensor table: dtype, ndim, dims, offset, size
+        base = 80 + 120 * entry
+        for off, fmt in ((64, "<I"), (68, "<I")):
+            for v in (0, 1, 4, 5, 0xffffffff):
+                b = bytearray(data)
+                struct.pack_into(fmt, b, base + off, v)
+                add(bytes(b))
+        for off in (72, 80, 88, 96, 104, 112):
+            for v in wild:
+                b = bytearray(data)
+                struct.pack_into("<Q", b, base + off, v)
+                add(bytes(b))
+        b = bytearray(data)                                 # dimensions whose product wraps to the true element count
+        struct.pack_into("<QQ", b, base + 72, 1 << 63, 2)
+        add(bytes(b))
+    for _ in range(150):                                    # bytes flipped anywhere in header and table
+        b = bytearray(data)
+        for pos in rng.integers(0, 80 + 120 * count, int(rng.integers(1, 8))):
+            b[pos] = int(rng.integers(0, 256))
+        add(bytes(b))
+    r = subprocess.run([str(exe), str(tmp_path / "names.txt"), *map(str, files)], capture_output=True, text=True, errors="replace", timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-4000:])
+    assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+    lines = r.stdout.splitlines()
+    assert lines[0].startswith(f"loaded {good}") and f": {count} tensors" in lines[0], lines[0]
+    whole_run = subprocess.run([str(exe), str(tmp_path / "names.txt"), str(full)], capture_output=True, text=True, errors="replace", timeout=600)
+    assert whole_run.returncode == 0 and whole_run.stdout.startswith(f"loaded {full}"), (whole_run.stdout[-500:], whole_run.stderr[-2000:])
+    assert sum(l.startswith("refused ") for l in lines) > len(files) // 2
