@@ -1,10 +1,13 @@
 // ASan + UBSan harness for the pure host planners (tests/test_sanitizers.py): csrc/step_queue.hpp (which lane takes which
-// requests) and csrc/mask_pieces.hpp (how a batch of masks is cut into transfer pieces) on a few hundred thousand random
-// inputs, with the invariants the callers rely on checked on every one.
+// requests), csrc/mask_pieces.hpp (how a batch of masks is cut into transfer pieces) and csrc/resize_tables.cpp (the
+// contributor tables the resize kernels index with) on a few hundred thousand random inputs, with the invariants the
+// callers rely on checked on every one.
 #include "mask_pieces.hpp"
+#include "resize_tables.hpp"
 #include "step_queue.hpp"
 
 #include <cstdint>
+#include <cmath>
 #include <cstdio>
 #include <numeric>
 
@@ -63,6 +66,29 @@ int main() {
         }
         for (int i = 0; i < count; ++i)
             if (copied[i] != sizes[i]) { std::printf("mask %d: %zu of %zu bytes copied\n", i, copied[i], sizes[i]); return 1; }
+    }
+    // resize tables: any axis from 1 pixel to far beyond what an image has, both filters; the kernels read coef[o * taps + k]
+    // for k < count[o] and clamp first[o] + k into the source
+    for (int iter = 0; iter < 1500; ++iter) {
+        const int shape = (int)rnd(12);
+        const int in_size = shape == 0 ? 1 + (int)rnd(4) : shape == 1 ? 20000 + (int)rnd(20000) : 1 + (int)rnd(4000);
+        const int out_size = shape == 2 ? 1 + (int)rnd(4) : shape == 3 ? 1024 : 1 + (int)rnd(2048);
+        const ResizeFilter filter = rnd(2) ? ResizeFilter::default_ : ResizeFilter::box;
+        const AxisTable t = make_axis_table(in_size, out_size, filter);
+        if (t.in_size != in_size || t.out_size != out_size || t.taps <= 0 || (int)t.first.size() != out_size ||
+            (int)t.count.size() != out_size || t.coef.size() != (size_t)out_size * t.taps) { std::printf("table shape %d -> %d\n", in_size, out_size); return 1; }
+        for (int o = 0; o < out_size; ++o) {
+            if (t.count[o] <= 0 || t.count[o] > t.taps) { std::printf("count %d -> %d at %d\n", in_size, out_size, o); return 1; }
+            // a contributor may lie outside the source (edge clamp), but never further than the filter reaches
+            if (t.first[o] < -t.taps || t.first[o] + t.count[o] > in_size + t.taps) { std::printf("first %d -> %d at %d\n", in_size, out_size, o); return 1; }
+            double sum = 0;
+            for (int k = 0; k < t.taps; ++k) {
+                const float c = t.coef[(size_t)o * t.taps + k];
+                if (!std::isfinite(c) || (k >= t.count[o] && c != 0.0f)) { std::printf("coef %d -> %d at %d\n", in_size, out_size, o); return 1; }
+                sum += c;
+            }
+            if (std::fabs(sum - 1.0) > 1e-3) { std::printf("weights of %d -> %d at %d sum to %g\n", in_size, out_size, o, sum); return 1; }
+        }
     }
     std::printf("ok\n");
     return 0;

@@ -168,9 +168,11 @@ def test_lane_worker_and_its_hand_over_protocols_under_thread_sanitizer(tmp_path
 
 
 def test_planners_on_random_inputs_under_address_sanitizer(tmp_path):
-    """csrc/step_queue.hpp and csrc/mask_pieces.hpp on 220 000 random inputs with ASan + UBSan, every plan checked against
-    the invariants its caller relies on (tests/sanitize/planners_fuzz.cpp)."""
-    exe = _build(tmp_path, "planners_fuzz", "planners_fuzz.cpp", "address,undefined")
+    """csrc/step_queue.hpp and csrc/mask_pieces.hpp on 220 000 random inputs and csrc/resize_tables.cpp on 1 500 axis pairs
+    (1 pixel to 40 000, both filters) with ASan + UBSan, every result checked against the invariants its caller relies on
+    (tests/sanitize/planners_fuzz.cpp)."""
+    exe = _build(tmp_path, "planners_fuzz", "planners_fuzz.cpp", "address,undefined",
+                 extra=["-ffp-contract=off", str(ROOT / "dlimgedit_amd" / "csrc" / "resize_tables.cpp")])
     r = subprocess.run([str(exe)], capture_output=True, text=True, errors="replace", timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-1000:], r.stderr[-4000:])
     assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
