@@ -973,6 +973,32 @@ void SamModel::enqueue_masks(MaskSlot& slot, k::PostJob const* jobs, int count, 
     std::vector<k::PostJob> dev_jobs(jobs, jobs + count);
     size_t off = 0;
     double bytes = 0;
+    // One mask (a single-mask query): the post-processing kernel writes it straight into the pinned host staging memory
+    // instead of a device buffer that a copy command then moves -- the copy's start-up and the 1 MiB transfer behind the
+    // kernel become stores that leave while the kernel runs (0.330 -> 0.309 ms per compute_mask call on a cached
+    // embedding, 3 A/B pairs).  Several masks keep the device buffer and the piecewise copy: their transfer overlaps the
+    // host's copy-out piece by piece, which one kernel writing everything cannot.  DLIMGEDIT_DIRECT_MASKS=0: measurement aid.
+    static const bool direct_allowed = [] { const char* e = std::getenv("DLIMGEDIT_DIRECT_MASKS"); return !e || std::atoi(e) != 0; }();
+    const bool direct = direct_allowed && count == 1;
+    if (direct) {
+        dev_jobs[0].dst = static_cast<uint8_t*>(slot.pin.get());
+        bytes = (double)kLowRes * kLowRes * 4 + (double)jobs[0].out_w * jobs[0].out_h;
+        timed(ST_POST, bytes, [&] { k::postprocess_masks(dev_jobs.data(), count, stream_); });
+        if (iou_count > 0)
+            HIP_CHECK(hipMemcpyAsync(static_cast<uint8_t*>(slot.pin.get()) + total, iou_.get(), (size_t)iou_count * sizeof(float),
+                                     hipMemcpyDeviceToHost, stream_));
+        slot.piece_end = mask_piece_ends(with_iou);
+        if (slot.piece_done.empty()) {
+            hipEvent_t e = nullptr;
+            HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            slot.piece_done.push_back(e);
+        }
+        slot.piece_end.assign(1, with_iou);
+        HIP_CHECK(hipEventRecord(slot.piece_done[0], stream_));
+        HIP_CHECK(hipEventRecord(slot.done, stream_));
+        mark_activity();
+        return;
+    }
     for (int i = 0; i < count; ++i) {
         dev_jobs[i].dst = slot.dev.get() + off;
         off += mask_bytes(jobs[i]);
