@@ -781,12 +781,22 @@ DLIMG_API int dlimg_amd_test_attention(int global, uint16_t const* qkv, float co
         thread_local OwnStream own;
         if (!own.s) HIP_CHECK(hipStreamCreateWithFlags(&own.s, hipStreamNonBlocking));
         if (global) {
+            // the kernel's contract (kernels.hpp): q columns and rel-pos tables arrive pre-scaled -- here on the host, as
+            // SamModel does with the weights that produce them
             const size_t n = (size_t)(2 * span - 1) * hd;
-            DeviceBuffer<half_t> dh16(n), dw16(n);
-            k::cast_f16(dh.get(), dh16.get(), n, own.s);
-            k::cast_f16(dw.get(), dw16.get(), n, own.s);
-            k::attention_global(dq.get(), dh16.get(), dw16.get(), o.get(), batch, heads, hd, own.s);
-            HIP_CHECK(hipStreamSynchronize(own.s));      // dh16 / dw16 go out of scope below
+            const float qs = k::attention_global_q_scale(hd), rs = k::attention_global_rel_scale(hd);
+            std::vector<half_t> hq(reinterpret_cast<half_t const*>(qkv), reinterpret_cast<half_t const*>(qkv) + rows * 3 * D);
+            for (size_t r = 0; r < rows; ++r)
+                for (int c = 0; c < D; ++c) hq[r * 3 * D + c] = (half_t)((float)hq[r * 3 * D + c] * qs);
+            std::vector<half_t> hh(n), hw(n);
+            for (size_t i = 0; i < n; ++i) {
+                hh[i] = (half_t)(rel_h[i] * rs);
+                hw[i] = (half_t)(rel_w[i] * rs);
+            }
+            Upload<half_t> dqs(hq.data(), hq.size()), dh16(hh.data(), n), dw16(hw.data(), n);
+            HIP_CHECK(hipDeviceSynchronize());
+            k::attention_global(dqs.get(), dh16.get(), dw16.get(), o.get(), batch, heads, hd, own.s);
+            HIP_CHECK(hipStreamSynchronize(own.s));      // the uploads go out of scope below
         } else {
             DLIMG_ASSERT(qkv_bias != nullptr);
             k::attention_window(dq.get(), db.get(), dh.get(), dw.get(), o.get(), batch, heads, hd, own.s);

@@ -126,6 +126,12 @@ void cast_f16(const float* in, half_t* out, size_t n, hipStream_t);
 // rel_h/rel_w: [2*S-1, hd] with S = 14 (windowed, f32) or 64 (global, f16: converted once when the weights are loaded).
 void attention_window(const half_t* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w,
                       half_t* out, int B, int heads, int hd, hipStream_t);
+// attention_global works in units of log2 and leaves the scaling to whoever produces its operands: the q columns of qkv
+// must arrive multiplied by attention_global_q_scale(hd) = log2(e) / sqrt(hd) and both rel-pos tables by
+// attention_global_rel_scale(hd) = sqrt(hd), so that q'.k is the scaled score and q'.R' the bias q.R, both times
+// log2(e).  SamModel folds the factors into the qkv weights / bias and the tables of the global blocks when it loads them.
+float attention_global_q_scale(int hd);
+float attention_global_rel_scale(int hd);
 void attention_global(const half_t* qkv, const half_t* rel_h, const half_t* rel_w, half_t* out, int B,
                       int heads, int hd, hipStream_t);
 

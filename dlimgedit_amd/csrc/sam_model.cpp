@@ -37,33 +37,50 @@ struct Loader {
         k::cast_f16(staging.get(), dst.get(), n, stream);
         HIP_CHECK(hipStreamSynchronize(stream));
     }
-    void linear_h(std::string const& prefix, int out, int in, bool bias, LinearH& l) {
+    // head_rows / head_scale: the first head_rows output rows (weight rows and bias entries) are multiplied by head_scale
+    // before anything else happens to them -- the q rows of a global-attention block's qkv (kernels.hpp, attention_global)
+    void linear_h(std::string const& prefix, int out, int in, bool bias, LinearH& l, int head_rows = 0, float head_scale = 1.f) {
         HostTensor const& w = file.get(prefix + ".w", {out, in});
-        f16_host(w.data, w.numel(), l.w);
+        if (head_rows > 0) {
+            std::vector<float> ws(w.data, w.data + w.numel());
+            for (size_t i = 0; i < (size_t)head_rows * in; ++i) ws[i] *= head_scale;
+            f16_host(ws.data(), ws.size(), l.w);
+        } else {
+            f16_host(w.data, w.numel(), l.w);
+        }
         l.out = out;
         l.in = in;
         l.has_bias = bias;
-        if (bias) f32(prefix + ".b", {out}, l.b);
+        if (bias && head_rows > 0) {
+            HostTensor const& b = file.get(prefix + ".b", {out});
+            std::vector<float> bs(b.data, b.data + out);
+            for (int i = 0; i < head_rows; ++i) bs[i] *= head_scale;
+            f32_host(bs, l.b);
+        } else if (bias) {
+            f32(prefix + ".b", {out}, l.b);
+        }
     }
     // Linear layer behind a LayerNorm, with the norm folded in: y = W (g*(x-mu)*rstd + beta) + b
     //   = rstd * ((W g) x - mu * rowsum(W g)) + (b + W beta).  The GEMM multiplies the raw x by W g and applies
     // the rest per output element; rowsum is taken over the f16 values the GEMM really multiplies with.
-    void linear_ln_h(std::string const& prefix, std::string const& norm, int out, int in, LinearH& l) {
+    void linear_ln_h(std::string const& prefix, std::string const& norm, int out, int in, LinearH& l, int head_rows = 0,
+                     float head_scale = 1.f) {
         HostTensor const& w = file.get(prefix + ".w", {out, in});
         HostTensor const& b = file.get(prefix + ".b", {out});
         HostTensor const& gamma = file.get(norm + ".w", {in});
         HostTensor const& beta = file.get(norm + ".b", {in});
         std::vector<float> wg((size_t)out * in), colsum(out), bias(out);
         for (int n = 0; n < out; ++n) {
+            const float rs = n < head_rows ? head_scale : 1.f;      // see linear_h
             double sum = 0, shift = 0;
             for (int i = 0; i < in; ++i) {
-                const float v = w.data[(size_t)n * in + i] * gamma.data[i];
+                const float v = rs * w.data[(size_t)n * in + i] * gamma.data[i];
                 wg[(size_t)n * in + i] = v;
                 sum += (double)(float)(half_t)v;
-                shift += (double)w.data[(size_t)n * in + i] * beta.data[i];
+                shift += (double)rs * w.data[(size_t)n * in + i] * beta.data[i];
             }
             colsum[n] = (float)sum;
-            bias[n] = (float)(b.data[n] + shift);
+            bias[n] = (float)((double)rs * b.data[n] + shift);
         }
         f16_host(wg.data(), wg.size(), l.w);
         f32_host(bias, l.b);
@@ -158,20 +175,29 @@ SamWeights::SamWeights(std::string const& weight_path, int device_index) : devic
         L.global = geom_.is_global(i);
         const int span = L.global ? 64 : 14;
         ld.f32(p + ".qkv.b", {3 * D}, L.qkv_pad);
+        // a global block's attention kernel works in units of log2 on pre-scaled operands (kernels.hpp): q rows of the
+        // qkv weight and bias times log2(e) / sqrt(hd), rel-pos tables times sqrt(hd); L.qkv_pad (the windowed
+        // kernel's padding bias) is not used by global blocks
+        const int q_rows = L.global ? D : 0;
+        const float q_scale = L.global ? k::attention_global_q_scale(hd) : 1.f;
         if (fused_ln_) {
-            ld.linear_ln_h(p + ".qkv", p + ".ln1", 3 * D, D, L.qkv);
+            ld.linear_ln_h(p + ".qkv", p + ".ln1", 3 * D, D, L.qkv, q_rows, q_scale);
             ld.linear_ln_h(p + ".fc1", p + ".ln2", geom_.mlp_dim, D, L.fc1);
         } else {
             ld.norm(p + ".ln1", D, L.ln1);
             ld.norm(p + ".ln2", D, L.ln2);
-            ld.linear_h(p + ".qkv", 3 * D, D, true, L.qkv);
+            ld.linear_h(p + ".qkv", 3 * D, D, true, L.qkv, q_rows, q_scale);
             ld.linear_h(p + ".fc1", geom_.mlp_dim, D, true, L.fc1);
         }
         if (L.global) {
             HostTensor const& rh = file.get(p + ".rel_h", {2 * span - 1, hd});
             HostTensor const& rw = file.get(p + ".rel_w", {2 * span - 1, hd});
-            ld.f16_host(rh.data, rh.numel(), L.rel_h16);
-            ld.f16_host(rw.data, rw.numel(), L.rel_w16);
+            std::vector<float> rhs(rh.data, rh.data + rh.numel()), rws(rw.data, rw.data + rw.numel());
+            const float rel_scale = k::attention_global_rel_scale(hd);
+            for (auto& v : rhs) v *= rel_scale;
+            for (auto& v : rws) v *= rel_scale;
+            ld.f16_host(rhs.data(), rhs.size(), L.rel_h16);
+            ld.f16_host(rws.data(), rws.size(), L.rel_w16);
         } else {
             ld.f32(p + ".rel_h", {2 * span - 1, hd}, L.rel_h);
             ld.f32(p + ".rel_w", {2 * span - 1, hd}, L.rel_w);

@@ -1,5 +1,5 @@
 """Kernel time of the attention kernels alone (dlimg_amd_bench_attention): python tools/attn_variants.py [global|window] [heads] [hd] [batch]
-With DLIMGEDIT_TUNING_LIB=1 and DLIMGEDIT_ATTN_VAR=n the tuning build's variants of the global kernel are timed."""
+With DLIMGEDIT_TUNING_LIB=1 and DLIMGEDIT_ATTN_ABLATE=n the tuning build's ablated variants of the global kernel are timed (wrong results)."""
 import os
 import sys
 from pathlib import Path
@@ -11,7 +11,7 @@ heads = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 hd = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 batch = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 ms = [api.ext.bench_attention(kind == "global", heads, hd, batch, iters=100) for _ in range(3)]
-print(f"{kind} heads {heads} hd {hd} batch {batch} var {os.environ.get('DLIMGEDIT_ATTN_VAR', '-')}: "
+print(f"{kind} heads {heads} hd {hd} batch {batch} var {os.environ.get('DLIMGEDIT_ATTN_ABLATE', '-')}: "
       + " ".join(f"{m * 1e3:7.1f}" for m in ms) + " us per launch", flush=True)
 
 if kind == "global" and os.environ.get("DLIMGEDIT_ATTN_CHECK"):
