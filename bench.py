@@ -30,6 +30,14 @@ Besides the contract fields the JSON line carries
   stages        per-stage breakdown of the profiled repeat (profile_mode says how it was taken)
   rccl          N > 1: ranks counted by an all-reduce of ones, and the optional gather of the finished masks to
                 every rank (RCCL all_gather over xGMI, after the timed region: no collective is on the data path)
+  inproc_replicas  N > 1: the same node driven the way a host of the reference would drive it -- ONE process, ONE
+                Environment over all N GPUs (DLIMGEDIT_DEVICES), 8 images per GPU per call through slots 13 / 14 of the
+                drop-in table, masks gathered into one buffer on GPU 0 by the library (peer copies over xGMI)
+
+Launching: `python bench.py --gpus N` from a bare shell starts its own N ranks (a parent that never touches the GPU runs
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child and relays its output); under a launcher that
+has already set WORLD_SIZE the ranks run directly.  `--stub-device` replaces the device by a host stand-in so the N > 1
+orchestration (barriers, max over ranks, rank count, gather, the line's assembly) runs on CPU (tests/test_bench_cpu.py).
 """
 from __future__ import annotations
 
@@ -73,6 +81,88 @@ def synthetic_image(seed: int, size: int = 1024) -> np.ndarray:
     return img
 
 
+def spawn_ranks(n: int, argv: list) -> int:
+    """--gpus N from a bare shell: this process has imported neither torch nor the library and has made no GPU call; it starts
+    the N ranks as CHILD processes through torch.distributed.run, relays what they print and returns their exit code.
+    (Replacing a process that has initialised the GPU by another program takes the machine down on this pool: never exec.)"""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+class StubEngine:
+    """Host stand-in for the device (--stub-device): a step writes a rank- and step-dependent pattern into this rank's
+    mask tensor.  Only the orchestration around it is exercised; no number it produces means anything."""
+
+    def __init__(self, torch, rank: int, batch: int):
+        self.torch, self.rank, self.calls = torch, rank, 0
+        self.local_masks = torch.zeros((batch, 1024, 1024), dtype=torch.uint8)
+
+    def step(self):
+        self.calls += 1
+        for i in range(self.local_masks.shape[0]):
+            self.local_masks[i, :8, :] = (self.rank * 16 + i + 1) & 0xFF
+            self.local_masks[i, 8, 0] = self.calls & 0xFF
+
+    def synchronize(self):
+        pass
+
+
+def inproc_replicas(api, ext, synthetic, model_dir: str, devices: list, images_per_gpu: int, steps: int, rehearsal: bool) -> dict:
+    """north_star's own multi-GPU form: the existing C-ABI host, ONE Environment whose replicas sit on `devices`
+    (DLIMGEDIT_DEVICES), images dealt one per GPU in turn by slot 13, one prompt each through the device-output form of
+    slot 14 (dlimg_amd_get_segmentation_masks_device): every mask is produced on the GPU that holds its embedding and lands
+    in ONE buffer on devices[0] (hipMemcpyPeerAsync over xGMI between GPUs).  Host pixels in (PCIe inclusive), masks stay in
+    HBM.  Checked against slot 14's host masks, bit for bit, before it is timed."""
+    os.environ["DLIMGEDIT_DEVICES"] = ",".join(str(d) for d in devices)
+    env = api.Environment(api.Options(api.Backend.gpu, model_dir))
+    del os.environ["DLIMGEDIT_DEVICES"]
+    try:
+        n = images_per_gpu * len(devices)
+        imgs = [synthetic(500 + i) for i in range(n)]
+        views = [api.ImageView(im, api.Channels.rgba) for im in imgs]
+        pts = [api.Point(512, 512)] * n
+        out = ext.device_alloc(env, n * 1024 * 1024)
+        segs = api.Segmentation.process_batch(views, env)
+        placement = [ext.segmentation_device(sg)[0] for sg in segs]
+        want = api.Segmentation.compute_mask_batch(segs, points=pts)
+        offsets = ext.compute_mask_batch_device(segs, out, points=pts, root_device=devices[0])
+        got = np.empty(n * 1024 * 1024, np.uint8)
+        ext.copy_to_host(env, got, out)
+        equal = all(np.array_equal(got[offsets[i]:offsets[i] + 1024 * 1024].reshape(1024, 1024), want[i]) for i in range(n))
+        for sg in segs:
+            sg.close()
+
+        def one_call():
+            sg_ = api.Segmentation.process_batch(views, env)
+            ext.compute_mask_batch_device(sg_, out, points=pts, root_device=devices[0])
+            for x in sg_:
+                x.close()
+
+        one_call()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_call()
+        dt = time.perf_counter() - t0
+        ext.device_free(env, out)
+        return {"value": n * steps / dt, "unit": "images/s", "devices": devices, "replicas": ext.replica_count(env),
+                "images_per_call": n, "calls": steps, "images_per_replica": [placement.count(r) for r in range(len(devices))],
+                "gathered_masks_equal_slot_14": bool(equal),
+                "note": ("one-GPU REHEARSAL (the same GPU listed %d times), not a result" % len(devices)) if rehearsal else
+                        "one process, one Environment over all GPUs: host pixels in through slot 13, masks gathered into one "
+                        "buffer on devices[0] by dlimg_amd_get_segmentation_masks_device (peer copies over xGMI); one host "
+                        "thread, PCIe inclusive"}
+    finally:
+        env.close()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,39 +178,54 @@ def main() -> None:
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="one-GPU rehearsal of the N > 1 code path: every rank uses GPU 0 and the collectives run on gloo / CPU "
                          "tensors (RCCL refuses two ranks on one device); the line is marked as a rehearsal, never a result")
+    ap.add_argument("--stub-device", action="store_true",
+                    help="no GPU at all: a host stand-in takes the device's place so that the N > 1 orchestration runs on "
+                         "CPU (gloo); the line is marked, its numbers mean nothing (tests/test_bench_cpu.py)")
+    ap.add_argument("--inproc-images-per-gpu", type=int, default=8, help="images per GPU per call of the inproc_replicas leg")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))      # before anything here has touched the GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
-    dev_index = 0 if args.rehearse_gloo else local_rank
-    coll_dev = "cpu" if args.rehearse_gloo else "cuda"
+    stub = args.stub_device
+    host_collectives = args.rehearse_gloo or stub
+    dev_index = 0 if host_collectives else local_rank
+    coll_dev = "cpu" if host_collectives else "cuda"
     os.environ["DLIMGEDIT_DEVICE"] = str(dev_index)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import torch
     import torch.distributed as dist
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device is visible")
-    torch.cuda.set_device(dev_index)
+    if not stub:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: no HIP device is visible")
+        torch.cuda.set_device(dev_index)
     if world > 1:
-        if args.rehearse_gloo:
+        if host_collectives:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    # a host-side group for waiting: a rank parked in an RCCL barrier keeps a polling kernel on its GPU
+    host_group = dist.new_group(backend="gloo") if world > 1 and not host_collectives else None
 
-    from dlimgedit_amd import api, sharding, weights as W
+    def device_synchronize():
+        if not stub:
+            torch.cuda.synchronize()
+
+    from dlimgedit_amd import sharding
     from dlimgedit_amd.sam_config import get_config
+    if not stub:
+        from dlimgedit_amd import api, weights as W
 
     cfg = get_config(args.model)
     # ---- model directory: rank 0 of the node writes seeded synthetic weights, the others wait
     model_dir = args.model_dir
     params = None
-    if model_dir is None:
+    if model_dir is None and not stub:
         model_dir = os.path.join(tempfile.gettempdir(), f"dlimgedit_bench_{args.model}_{args.seed}_{os.getuid()}")
         target = Path(model_dir) / "segmentation" / W.weight_file_name(cfg)
         if local_rank == 0 and not target.exists():
@@ -132,29 +237,38 @@ def main() -> None:
         dist.barrier()
     os.environ["DLIMGEDIT_SAM_MODEL"] = args.model
 
-    env = api.Environment(api.Options(api.Backend.gpu, model_dir))
-    ext = api.ext
     B = args.batch
-    # ---- inputs resident in HBM before the timed region
-    imgs = [synthetic_image(rank * B + i) for i in range(B)]
     img_ptrs, mask_ptrs = [], []
-    # N > 1: the masks live in ONE torch tensor per rank, so the RCCL gather below reads them where the kernels wrote them
-    # (no host round trip); N = 1 keeps torch off the data path altogether
-    local_masks = torch.zeros((B, 1024, 1024), dtype=torch.uint8, device="cuda") if world > 1 else None
-    for i, im in enumerate(imgs):
-        p = ext.device_alloc(env, im.nbytes)
-        ext.copy_to_device(env, p, im)
-        img_ptrs.append(p)
-        mask_ptrs.append(local_masks[i].data_ptr() if world > 1 else ext.device_alloc(env, 1024 * 1024))
-    views = ext.device_views(img_ptrs, 1024, 1024)
-    points = [api.Point(512, 512)] * B
+    if stub:
+        env = ext = None
+        engine = StubEngine(torch, rank, B)
+        local_masks = engine.local_masks
+        step, engine_sync = engine.step, engine.synchronize
+    else:
+        env = api.Environment(api.Options(api.Backend.gpu, model_dir))
+        ext = api.ext
+        # ---- inputs resident in HBM before the timed region
+        imgs = [synthetic_image(rank * B + i) for i in range(B)]
+        # N > 1: the masks live in ONE torch tensor per rank, so the RCCL gather below reads them where the kernels wrote
+        # them (no host round trip); N = 1 keeps torch off the data path altogether
+        local_masks = torch.zeros((B, 1024, 1024), dtype=torch.uint8, device="cuda") if world > 1 else None
+        for i, im in enumerate(imgs):
+            p = ext.device_alloc(env, im.nbytes)
+            ext.copy_to_device(env, p, im)
+            img_ptrs.append(p)
+            mask_ptrs.append(local_masks[i].data_ptr() if world > 1 else ext.device_alloc(env, 1024 * 1024))
+        views = ext.device_views(img_ptrs, 1024, 1024)
+        points = [api.Point(512, 512)] * B
 
-    def step():
-        ext.encode_and_mask(env, views, points, mask_ptrs)
+        def step():
+            ext.encode_and_mask(env, views, points, mask_ptrs)
+
+        def engine_sync():
+            ext.synchronize(env)
 
     def sync_all():
-        ext.synchronize(env)
-        torch.cuda.synchronize()
+        engine_sync()
+        device_synchronize()
         if world > 1:
             dist.barrier()
 
@@ -167,8 +281,8 @@ def main() -> None:
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
-        ext.synchronize(env)
-        torch.cuda.synchronize()                 # ... and behind them
+        engine_sync()
+        device_synchronize()                     # ... and behind them
         repeat_s.append(sharding.max_over_ranks(time.perf_counter() - t0, device=coll_dev))
         if world > 1:
             dist.barrier()
@@ -192,30 +306,36 @@ def main() -> None:
             "dtype": "f16",
             "data": "synthetic",
             "config": {"workload": f"SAM {args.model} encoder + 1 point prompt, {B} image(s)/GPU/step, 1024x1024 RGBA, "
-                                   "inputs and masks resident in HBM", "images_per_gpu_per_step": B, "lanes_per_gpu": ext.lane_count(env),
-                       # what the library's step queue really uses (it clamps the variables and has its own defaults)
-                       "requests_coalesced_per_pass": ext.queue_config(env)["coalesce"],
-                       "passes_queued_per_lane": ext.queue_config(env)["step_depth"],
+                                   "inputs and masks resident in HBM; timed through the extension entry point "
+                                   "dlimg_amd_encode_and_mask (device pointers in and out) -- the drop-in table itself, host "
+                                   "buffers in and out, is `abi_path`", "images_per_gpu_per_step": B,
                        "weights": "seeded synthetic" if args.model_dir is None else "from --model-dir"},
             "repeats": len(repeat_s),
             "timed_total_s": float(sum(repeat_s)),
             "repeat_ms": [round(1e3 * t, 3) for t in repeat_s],
             "value_min_max": [images / max(repeat_s), images / min(repeat_s)],
         }
+        if stub:
+            result["stub_device"] = "no GPU: a host stand-in took the device's place (orchestration rehearsal); the numbers mean nothing"
+            result["data"] = "none (stub device)"
+        else:
+            # what the library's step queue really uses (it clamps the variables and has its own defaults)
+            result["config"].update({"lanes_per_gpu": ext.lane_count(env), "requests_coalesced_per_pass": ext.queue_config(env)["coalesce"],
+                                     "passes_queued_per_lane": ext.queue_config(env)["step_depth"]})
 
     # ---- N > 1: the ranks that really take part, and the optional gather of the masks (after the timed region)
     if world > 1:
         ranks = sharding.count_ranks(device=coll_dev)
-        ext.synchronize(env)                     # the masks of the last timed step are in local_masks (device memory)
-        torch.cuda.synchronize()
+        engine_sync()                            # the masks of the last timed step are in local_masks (device memory)
+        device_synchronize()
         foreground = float((local_masks > 0).float().mean().item())
-        src = local_masks.cpu() if args.rehearse_gloo else local_masks
+        src = local_masks.cpu() if host_collectives else local_masks
         sharding.gather_device_masks(src, world * B)                     # first call: communicator set-up, not timed
-        torch.cuda.synchronize()
+        device_synchronize()
         dist.barrier()
         t0 = time.perf_counter()
         gathered = sharding.gather_device_masks(src, world * B)
-        torch.cuda.synchronize()
+        device_synchronize()
         t_gather = sharding.max_over_ranks(time.perf_counter() - t0, device=coll_dev)
         ok = bool(torch.equal(gathered[rank::world][:B], src))             # item i = b * world + rank
         all_ok = sharding.max_over_ranks(0.0 if ok else 1.0, device=coll_dev) == 0.0
@@ -227,7 +347,8 @@ def main() -> None:
             dist.destroy_process_group()
             raise SystemExit(3)
         if rank == 0:
-            result["rccl"] = {"rccl_ranks": ranks, "backend": "gloo (one-GPU REHEARSAL, not a result)" if args.rehearse_gloo else "nccl (RCCL)",
+            result["rccl"] = {"rccl_ranks": ranks, "backend": "gloo (no device: orchestration REHEARSAL on CPU, not a result)" if stub else
+                              "gloo (one-GPU REHEARSAL, not a result)" if args.rehearse_gloo else "nccl (RCCL)",
                               "gather": {"masks": int(gathered.shape[0]), "bytes": int(gathered.numel()), "ms": 1e3 * t_gather,
                                          "gbs": gathered.numel() / t_gather / 1e9, "own_share_intact": ok,
                                          "own_share_foreground": foreground,
@@ -237,10 +358,21 @@ def main() -> None:
     elif rank == 0:
         result["rccl"] = {"rccl_ranks": 1, "gather": None}
 
+    # ---- N > 1: the node driven from ONE process through the drop-in table (rank 0; the other ranks wait on the HOST)
+    if world > 1 and not stub:
+        if rank == 0:
+            devices = [0] * world if args.rehearse_gloo else list(range(world))
+            try:
+                result["inproc_replicas"] = inproc_replicas(api, ext, synthetic_image, model_dir, devices, args.inproc_images_per_gpu,
+                                                            max(2, min(args.steps, 10)), args.rehearse_gloo)
+            except Exception as e:                       # the torchrun figure above stands on its own
+                result["inproc_replicas"] = {"error": str(e)}
+        dist.barrier(group=host_group) if host_group is not None else dist.barrier()
+
     # ---- profiled repeats of the same steps: HIP events attached to every GEMM dispatch, on the stream it is launched on.
     # First in the regime `value` is measured in (all lanes, requests coalesced as in the timed region), then with every
     # request on lane 0 (each kernel alone on the chip).
-    if rank == 0:
+    if rank == 0 and not stub:
         def profiled(mode):
             ext.set_profiling(env, mode)
             ext.take_stage_stats(env)
@@ -351,7 +483,7 @@ def main() -> None:
                              if enc_ms > 0 else 0.0}
 
     # ---- per-stage rates SURVEY.md section 8d asks for next to the metric: encoder alone (device resident, all lanes)
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not stub:
         for _ in range(2):
             ext.encode_only(env, views)
         ext.synchronize(env)
@@ -365,7 +497,7 @@ def main() -> None:
     # ---- the two pixel kernels against the HBM rate (north_star: "HBM GB/s for the pre/post kernels"): one image per
     # launch sits on the launch floor (`stages` above), so they are also clocked with 16 images / masks per launch.
     # Launches rotate over 768 MB of distinct inputs and outputs (3 x the 256 MB Infinity Cache): what moves is HBM traffic.
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not stub:
         pre_b, post_b = 4 * 1024 * 1024 + 4096 * 768 * 2, 256 * 256 * 4 + 1024 * 1024      # algorithmic bytes per image / mask
         hk = {"unit": "GB/s", "peak": HBM_PEAK_GBS, "achievable": HBM_COPY_GBS,
               "achievable_note": "float4 copy kernel, HBM to HBM (MI355X_MICROARCH.md)",
@@ -383,7 +515,7 @@ def main() -> None:
         result["hbm_kernels"] = hk
 
     # ---- the drop-in ABI itself: host buffers in and out (PCIe inclusive), rank 0, N = 1 only
-    if rank == 0 and world == 1 and not args.no_abi_path:
+    if rank == 0 and world == 1 and not stub and not args.no_abi_path:
         import threading
         view = api.ImageView(imgs[0], api.Channels.rgba)
 
@@ -446,7 +578,7 @@ def main() -> None:
         }
 
     # ---- CPU baseline (oracle port) + mask IoU, rank 0, N = 1 only
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not stub and not args.no_cpu_baseline:
         from oracle import sam_oracle as O
         if params is None:
             params = W.load_weights(Path(model_dir) / "segmentation" / W.weight_file_name(cfg))[1] \
@@ -493,10 +625,11 @@ def main() -> None:
         result["mask_iou_checks"] = checks
 
     if rank == 0:
-        print(json.dumps(result))
-    for p in img_ptrs + (mask_ptrs if world == 1 else []):
-        ext.device_free(env, p)
-    env.close()
+        print(json.dumps(result), flush=True)
+    if not stub:
+        for p in img_ptrs + (mask_ptrs if world == 1 else []):
+            ext.device_free(env, p)
+        env.close()
     if world > 1:
         dist.destroy_process_group()
 
