@@ -512,9 +512,16 @@ DLIMG_API int dlimg_amd_synchronize(dlimg_Environment env) {
             e.drain_step_workers();                 // (the workers never take pending_mutex)
         }
         for_each_lane(e, [](SamModel& m) { m.synchronize(); });
+        // an encoder pass whose activations left the f16 range says so (SamModel::last_pass_flag); the asynchronous entry
+        // point learns it here, like every other failure of a queued pass
+        bool overflow = false;
+        for_each_lane(e, [&](SamModel& m) { overflow = m.any_pass_flag_set_and_clear() || overflow; });
         std::lock_guard<std::mutex> lock(e.pending_mutex);
         retire_device_steps(e);
         std::lock_guard<std::mutex> errors(e.step_error_mutex);
+        if (overflow && e.step_error.empty())
+            throw Exception("dlimg_amd_encode_and_mask: an image encoder pass produced non-finite values (an activation left "
+                            "the f16 range); the masks of the requests queued since the last synchronize are not valid");
         if (!e.step_error.empty()) {
             const std::string msg = "dlimg_amd_encode_and_mask: " + std::to_string(e.dropped_steps) +
                                     " queued request(s) were dropped because their pass failed: " + e.step_error;

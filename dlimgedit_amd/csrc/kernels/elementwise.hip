@@ -145,7 +145,7 @@ constexpr int LN_MAX_VEC = 5;         // D <= 1280
 template <int ACT>
 __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ b, float eps, int rows, int D,
-                                                            float* out_f32, half_t* out_h) {
+                                                            float* out_f32, half_t* out_h, int* nonfinite) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = lane_id();
@@ -169,6 +169,10 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
         }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+    // a row that holds an infinity or a NaN has no finite statistics: reported (one store per such row into host-visible
+    // memory) where the caller asked for it -- SamModel::encode on the last LayerNorm of the neck, whose input has seen
+    // every activation of the image
+    if (nonfinite && lane == 0 && !(fabsf(mean) < INFINITY && fabsf(rstd) < INFINITY)) *nonfinite = 1;
 #pragma unroll
     for (int i = 0; i < LN_MAX_VEC; ++i) {
         if (i < nv) {
@@ -262,18 +266,19 @@ void preprocess(const uint8_t* img, int w, int h, int stride, int channels, half
 }
 
 void layernorm(const float* x, const float* w, const float* b, float eps, int rows, int D, int act, float* out_f32,
-               half_t* out_h, hipStream_t s) {
+               half_t* out_h, hipStream_t s, int* nonfinite) {
     if (rows <= 0) return;
     if (D <= 0 || D > LN_MAX_PER_LANE * 64) throw_error("layernorm: row length must be in 1..1280");
     dim3 grid((rows + 3) / 4);
     const bool aligned = !(((uintptr_t)x | (uintptr_t)w | (uintptr_t)b | (uintptr_t)out_f32) & 15) && !((uintptr_t)out_h & 7);
     if (D % 256 == 0 && aligned) {
         if (act == ACT_GELU)
-            hipLaunchKernelGGL(layernorm_vec_kernel<ACT_GELU>, grid, dim3(256), 0, s, x, w, b, eps, rows, D, out_f32, out_h);
+            hipLaunchKernelGGL(layernorm_vec_kernel<ACT_GELU>, grid, dim3(256), 0, s, x, w, b, eps, rows, D, out_f32, out_h, nonfinite);
         else
-            hipLaunchKernelGGL(layernorm_vec_kernel<ACT_NONE>, grid, dim3(256), 0, s, x, w, b, eps, rows, D, out_f32, out_h);
+            hipLaunchKernelGGL(layernorm_vec_kernel<ACT_NONE>, grid, dim3(256), 0, s, x, w, b, eps, rows, D, out_f32, out_h, nonfinite);
         return;
     }
+    if (nonfinite) throw_error("layernorm: the non-finite report needs rows that are a multiple of 256 long");
     if (act == ACT_GELU)
         hipLaunchKernelGGL(layernorm_kernel<ACT_GELU>, grid, dim3(256), 0, s, x, w, b, eps, rows, D, out_f32, out_h);
     else

@@ -93,9 +93,10 @@ void gemm(const GemmArgs&, hipStream_t, hipEvent_t start = nullptr, hipEvent_t s
 
 // ---- row LayerNorm ---------------------------------------------------------------------------
 // y = (x-mean)/sqrt(var+eps)*w+b over rows of length D (<= 1280); optional GELU; f32 and/or f16 out.
-// x and out_f32 may alias.
+// x and out_f32 may alias.  nonfinite (optional, D a multiple of 256): an int in memory the kernel can write (pinned host
+// memory) that is set to 1 when a row holds an infinity or a NaN.
 void layernorm(const float* x, const float* w, const float* b, float eps, int rows, int D, int act,
-               float* out_f32, half_t* out_h, hipStream_t);
+               float* out_f32, half_t* out_h, hipStream_t, int* nonfinite = nullptr);
 
 // ---- pixel pre-processing (K1) ---------------------------------------------------------------
 // u8 image [h,w,C] (row stride `stride` bytes; dlimg::Channels code `channels`) -> f16 patch-major

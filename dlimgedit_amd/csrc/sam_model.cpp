@@ -30,7 +30,14 @@ struct Loader {
         dst.reserve(v.size());
         HIP_CHECK(hipMemcpy(dst.get(), v.data(), v.size() * 4, hipMemcpyHostToDevice));
     }
-    void f16_host(float const* src, size_t n, DeviceBuffer<half_t>& dst) {
+    // Everything that becomes an f16 MFMA operand passes here: a value beyond the f16 range would be an infinity on the
+    // device and every mask a NaN pattern, silently -- refused when the model is loaded instead (what: the tensor's name,
+    // or what it was folded from)
+    void f16_host(float const* src, size_t n, DeviceBuffer<half_t>& dst, std::string const& what) {
+        for (size_t i = 0; i < n; ++i)
+            if (!(std::fabs(src[i]) <= 65504.0f))
+                throw Exception("'" + file.path() + "': " + what + " holds " + std::to_string(src[i]) + " (element " +
+                                std::to_string(i) + "), outside the f16 range of this build's MFMA operands");
         staging.reserve(n);
         dst.reserve(n);
         HIP_CHECK(hipMemcpy(staging.get(), src, n * 4, hipMemcpyHostToDevice));
@@ -44,9 +51,9 @@ struct Loader {
         if (head_rows > 0) {
             std::vector<float> ws(w.data, w.data + w.numel());
             for (size_t i = 0; i < (size_t)head_rows * in; ++i) ws[i] *= head_scale;
-            f16_host(ws.data(), ws.size(), l.w);
+            f16_host(ws.data(), ws.size(), l.w, prefix + ".w");
         } else {
-            f16_host(w.data, w.numel(), l.w);
+            f16_host(w.data, w.numel(), l.w, prefix + ".w");
         }
         l.out = out;
         l.in = in;
@@ -82,7 +89,7 @@ struct Loader {
             colsum[n] = (float)sum;
             bias[n] = (float)((double)rs * b.data[n] + shift);
         }
-        f16_host(wg.data(), wg.size(), l.w);
+        f16_host(wg.data(), wg.size(), l.w, prefix + ".w scaled by " + norm + ".w");
         f32_host(bias, l.b);
         f32_host(colsum, l.colsum);
         l.out = out;
@@ -123,7 +130,7 @@ struct Loader {
             std::memcpy(w.data() + i * wi.numel(), wi.data, wi.numel() * 4);
             std::memcpy(b.data() + i * out_each, bi.data, bi.numel() * 4);
         }
-        f16_host(w.data(), w.size(), l.w);
+        f16_host(w.data(), w.size(), l.w, parts[0] + ".w (fused with its siblings)");
         f32_host(b, l.b);
         l.out = int(n) * out_each;
         l.in = in;
@@ -140,7 +147,7 @@ struct Loader {
                 for (int ci = 0; ci < ci_n; ++ci)
                     g[((size_t)s * co_n + co) * ci_n + ci] = w.data[((size_t)ci * co_n + co) * 4 + s];
             }
-        f16_host(g.data(), g.size(), l.w);
+        f16_host(g.data(), g.size(), l.w, prefix + ".w");
         f32_host(gb, l.b);
         l.out = 4 * co_n;
         l.in = ci_n;
@@ -196,8 +203,8 @@ SamWeights::SamWeights(std::string const& weight_path, int device_index) : devic
             const float rel_scale = k::attention_global_rel_scale(hd);
             for (auto& v : rhs) v *= rel_scale;
             for (auto& v : rws) v *= rel_scale;
-            ld.f16_host(rhs.data(), rhs.size(), L.rel_h16);
-            ld.f16_host(rws.data(), rws.size(), L.rel_w16);
+            ld.f16_host(rhs.data(), rhs.size(), L.rel_h16, p + ".rel_h");
+            ld.f16_host(rws.data(), rws.size(), L.rel_w16, p + ".rel_w");
         } else {
             ld.f32(p + ".rel_h", {2 * span - 1, hd}, L.rel_h);
             ld.f32(p + ".rel_w", {2 * span - 1, hd}, L.rel_w);
@@ -214,7 +221,7 @@ SamWeights::SamWeights(std::string const& weight_path, int device_index) : devic
             for (int ci = 0; ci < kEmbedDim; ++ci)
                 for (int t = 0; t < 9; ++t)
                     g[((size_t)co * 9 + t) * kEmbedDim + ci] = w.data[((size_t)co * kEmbedDim + ci) * 9 + t];
-        ld.f16_host(g.data(), g.size(), neck2_.w);
+        ld.f16_host(g.data(), g.size(), neck2_.w, "enc.neck.conv2.w");
         neck2_.out = kEmbedDim;
         neck2_.in = 9 * kEmbedDim;
     }
@@ -238,7 +245,7 @@ SamWeights::SamWeights(std::string const& weight_path, int device_index) : devic
                     row[128 + kf] = std::cos(v);
                 }
             }
-        ld.f16_host(pe.data(), pe.size(), pe_h);
+        ld.f16_host(pe.data(), pe.size(), pe_h, "the dense positional encoding");
     }
     // (keys + pos) W = keys W + pos W: the second term is a constant of the model, computed here once (same GEMM
     // kernel, f16 pos like the sum it replaces) and added by the image-side projections as an fp32 addend.  Columns
@@ -383,6 +390,7 @@ SamModel::~SamModel() {
         for (auto e : m->piece_done) (void)hipEventDestroy(e);
     }
     if (stream_) (void)hipStreamDestroy(stream_);
+    if (pass_flags_) (void)hipHostFree(pass_flags_);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -484,6 +492,15 @@ void SamModel::wait_and_recycle(hipEvent_t e) {
         done_pool_.push_back(e);
     }
     HIP_CHECK(err);
+}
+
+bool SamModel::any_pass_flag_set_and_clear() {
+    bool any = false;
+    for (int i = 0; pass_flags_ && i < kPassFlags; ++i) {
+        any = any || pass_flags_[i] != 0;
+        pass_flags_[i] = 0;
+    }
+    return any;
 }
 
 bool SamModel::poll_and_recycle(hipEvent_t e) {
@@ -777,9 +794,18 @@ void SamModel::encode(int batch, float* const* emb_dst) {
     gemm(g);
     // the embedding goes straight into the handle's storage when there is one image; a batch is copied out per image
     float* direct = (emb_dst && batch == 1 && emb_dst[0]) ? emb_dst[0] : nullptr;
+    // f16 operands and the f16 residual pair overflow to infinity beyond 65504; an infinity anywhere in an image turns
+    // into NaNs that reach this LayerNorm's input, which reports it (last_pass_flag) so that the caller refuses the
+    // embedding instead of decoding masks from it
+    if (!pass_flags_) {
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&pass_flags_), kPassFlags * sizeof(int), hipHostMallocDefault));
+        std::memset(pass_flags_, 0, kPassFlags * sizeof(int));
+    }
+    pass_flag_ = pass_flags_ + (pass_counter_++ % kPassFlags);
+    *pass_flag_ = 0;
     timed(ST_LAYERNORM, (double)M * kEmbedDim * 8, [&] {
         k::layernorm(neck_f32_.get(), W.neck_ln2_.w.get(), W.neck_ln2_.b.get(), kLnEps, M, kEmbedDim, k::ACT_NONE,
-                     direct ? direct : emb_.get(), nullptr, stream_);
+                     direct ? direct : emb_.get(), nullptr, stream_, pass_flag_);
     });
     if (emb_dst && !direct) {
         const size_t n = (size_t)kTokens * kEmbedDim;

@@ -222,6 +222,13 @@ class SamModel {
     void synchronize();
     // Event recorded behind everything enqueued so far; wait for it WITHOUT mutex(), then give it back.
     hipEvent_t completion();
+    // Overflow report of the encoder pass enqueued last (valid under mutex(), right after encode()): an int in pinned host
+    // memory that the pass sets to 1 when an activation left the f16 range somewhere in the image (an infinity or a NaN
+    // reached the last LayerNorm of the neck).  Read it after the pass's completion event; slots are reused after
+    // kPassFlags further passes of this lane.
+    static constexpr int kPassFlags = 64;
+    const volatile int* last_pass_flag() const { return pass_flag_; }
+    bool any_pass_flag_set_and_clear();
     void wait_and_recycle(hipEvent_t e);      // no mutex needed
     bool poll_and_recycle(hipEvent_t e);      // no mutex needed: true (and the event is taken back) once it has completed
 
@@ -296,6 +303,9 @@ class SamModel {
     std::vector<hipEvent_t> event_pool_;
     StageStats stats_;
     std::mutex done_mutex_;
+    int* pass_flags_ = nullptr;          // [kPassFlags] pinned, host-visible; pass_flag_ = the slot of the pass enqueued last
+    int* pass_flag_ = nullptr;
+    unsigned pass_counter_ = 0;
     std::vector<hipEvent_t> done_pool_;   // completion() events, guarded by done_mutex_ (taken without mutex_)
 };
 

@@ -107,7 +107,12 @@ template <typename F> void for_each_replica(std::vector<int> const& used, F&& bo
         if (e) std::rethrow_exception(e);
 }
 
-struct Waiting { SamModel* model; hipEvent_t done; };
+// overflow: the pass's report (SamModel::last_pass_flag), read once its event has been waited for
+struct Waiting { SamModel* model; hipEvent_t done; const volatile int* overflow; };
+
+constexpr const char* kOverflowMessage =
+    "the image encoder produced non-finite values: an activation left the f16 range (65504) of this build's MFMA operands "
+    "and residual stream -- the embedding is refused (no masks are computed from it)";
 
 // Error paths: a request that threw half-way may have queued kernels or copies that still write into buffers the
 // caller is about to hand back (pooled embedding buffers, mask staging slots).  Everything queued on that lane runs
@@ -127,6 +132,10 @@ void wait_all(std::vector<Waiting>& waiting) {
     for (auto& w : waiting) {
         try {
             w.model->wait_and_recycle(w.done);
+            if (w.overflow && *w.overflow) {
+                *const_cast<volatile int*>(w.overflow) = 0;      // reported here, once
+                throw Exception(kOverflowMessage);
+            }
         } catch (...) {
             if (!first) first = std::current_exception();
         }
@@ -194,6 +203,7 @@ void SegmentationImpl::process_batch(EnvironmentImpl& env, SegmentationImpl* con
                                  : alone      ? std::min<size_t>(4, spread)
                                               : std::min<size_t>(4, std::max(spread, (mine.size() + 1) / 2));
             // One pass: the chunk's images staged (host copy + upload) and encoded on `model`; returns the event behind it.
+            struct Queued { hipEvent_t done; const volatile int* overflow; };
             auto run_chunk = [&](SamModel& model, size_t base, int n) {
                 std::vector<float*> emb(n);
                 for (int j = 0; j < n; ++j) emb[j] = segs[mine[base + j]]->embedding_storage(replica);
@@ -211,7 +221,8 @@ void SegmentationImpl::process_batch(EnvironmentImpl& env, SegmentationImpl* con
                     roctx::Range r("dlimg.encode");
                     model.encode(n, emb.data());
                 }
-                return model.completion();
+                const volatile int* overflow = model.last_pass_flag();
+                return Queued{model.completion(), overflow};
             };
             const size_t chunks = (mine.size() + chunk - 1) / chunk;
             if (chunks > 1 && alone && env.use_step_workers) {
@@ -222,7 +233,7 @@ void SegmentationImpl::process_batch(EnvironmentImpl& env, SegmentationImpl* con
                 // the hand-over only costs (two threads x 8 images: 846 without, 824 with)
                 // (the promise is shared with the task: it must outlive the task's set_value call, which may still be
                 // returning when this thread has its answer)
-                struct Handed { SamModel* model; std::promise<hipEvent_t> result; std::future<hipEvent_t> answer; };
+                struct Handed { SamModel* model; std::promise<Queued> result; std::future<Queued> answer; };
                 std::vector<std::shared_ptr<Handed>> handed;
                 for (size_t base = 0; base < mine.size(); base += chunk) {
                     const int n = (int)std::min<size_t>(chunk, mine.size() - base);
@@ -242,7 +253,8 @@ void SegmentationImpl::process_batch(EnvironmentImpl& env, SegmentationImpl* con
                 std::exception_ptr first;
                 for (auto& h : handed) {             // every task is waited for: they refer to this frame
                     try {
-                        waiting.push_back(Waiting{h->model, h->answer.get()});
+                        const Queued q = h->answer.get();
+                        waiting.push_back(Waiting{h->model, q.done, q.overflow});
                     } catch (...) {
                         drain_lane(h->model);        // whatever the failed pass queued runs to completion first
                         if (!first) first = std::current_exception();
@@ -254,7 +266,8 @@ void SegmentationImpl::process_batch(EnvironmentImpl& env, SegmentationImpl* con
                     const int n = (int)std::min<size_t>(chunk, mine.size() - base);
                     SamModel& model = env.next_lane(replica);
                     enqueueing = &model;
-                    waiting.push_back(Waiting{&model, run_chunk(model, base, n)});
+                    const Queued q = run_chunk(model, base, n);
+                    waiting.push_back(Waiting{&model, q.done, q.overflow});
                     enqueueing = nullptr;
                 }
             }

@@ -44,6 +44,7 @@ class WeightFile {
     HostTensor const& get(std::string const& name) const;
     HostTensor const& get(std::string const& name, std::vector<int64_t> const& expect_dims) const;
     bool has(std::string const& name) const { return tensors_.count(name) != 0; }
+    std::string const& path() const { return path_; }
 
   private:
     std::string path_;

@@ -198,9 +198,38 @@ def weight_file_name(cfg: SamConfig) -> str:
     return f"sam_{cfg.name}.dlw"
 
 
-def save_weights(path, cfg: SamConfig, params: Dict[str, np.ndarray]) -> Path:
+F16_MAX = 65504.0
+
+
+def f16_operand(name: str) -> bool:
+    """Tensors the device converts to f16 MFMA operands as they are (LayerNorm scales are folded into some of them at load
+    time, which the C++ loader checks again after folding): the encoder's GEMM weights and rel-pos tables of the global
+    blocks' kind, the neck convolutions, the decoder's image-side projections and up-scaling convolutions."""
+    if name.endswith(".b"):
+        return False
+    if name.startswith("enc."):
+        return name.endswith(".w") and ".ln" not in name or name.endswith((".rel_h", ".rel_w"))
+    return name.endswith(".w") and any(t in name for t in (".k.w", ".v.w", ".q.w", "upscale", "conv"))
+
+
+def check_f16_range(params: Dict[str, np.ndarray], allow_out_of_range: bool = False) -> None:
+    """Real checkpoints are not guaranteed to fit this build's arithmetic: f16 MFMA operands overflow to infinity beyond
+    65504, and an infinity turns every mask into a NaN pattern without any error.  Refuses non-finite values anywhere and
+    out-of-range values in tensors that become f16 operands (`allow_out_of_range`: the writer's escape hatch for tests
+    that plant such values to exercise the C++ loader, which refuses them again when the model is loaded)."""
+    for name, arr in params.items():
+        a = np.asarray(arr)
+        if not np.isfinite(a).all():
+            raise ValueError(f"{name}: holds non-finite values")
+        if not allow_out_of_range and f16_operand(name) and a.size and float(np.abs(a).max()) > F16_MAX:
+            raise ValueError(f"{name}: |value| up to {float(np.abs(a).max()):.6g} is outside the f16 range (65504) of the "
+                             "MFMA operands this tensor becomes")
+
+
+def save_weights(path, cfg: SamConfig, params: Dict[str, np.ndarray], allow_out_of_range: bool = False) -> Path:
     """Write `params` (must cover param_specs(cfg) exactly) to `path` in DLW v1."""
     path = Path(path)
+    check_f16_range({s[0]: params[s[0]] for s in param_specs(cfg) if s[0] in params}, allow_out_of_range)
     specs = param_specs(cfg)
     names = [s[0] for s in specs]
     missing = [n for n in names if n not in params]

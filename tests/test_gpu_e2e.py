@@ -410,3 +410,43 @@ def test_the_reference_s_truck_case_on_its_own_photograph(api, session):
         if (want > 0).mean() >= 0.02:
             at_least(f"e2e.truck.{name}.mask_iou", iou(got, want), IOU_BAR)
     seg.close()
+
+
+def test_values_beyond_the_f16_range_are_reported_not_decoded(api, model_dirs, tmp_path):
+    """No real checkpoint has run on this build, and its MFMA operands and residual stream are f16 (65504): a weight
+    beyond that is refused by name when the model is loaded; an ACTIVATION beyond it -- here a positional-embedding channel
+    at 1e5, far inside fp32 -- turns into an infinity somewhere in the encoder, and process() says so instead of handing
+    out an embedding whose masks would be NaN patterns.  The environment keeps working afterwards."""
+    from dlimgedit_amd import weights as W
+    _, params, cfg = model_dirs("vit_test")
+    img = api.ImageView(synthetic_image(0), api.Channels.rgba)
+
+    heavy = dict(params)
+    heavy["enc.L0.fc2.w"] = params["enc.L0.fc2.w"].copy()
+    heavy["enc.L0.fc2.w"][3, 5] = 7.0e4
+    d1 = tmp_path / "heavy"
+    W.save_weights(d1 / "segmentation" / W.weight_file_name(cfg), cfg, heavy, allow_out_of_range=True)
+    env = api.Environment(api.Options(api.Backend.gpu, str(d1)))
+    with pytest.raises(api.Error, match=r"enc\.L0\.fc2\.w holds 70000.* outside the f16 range"):
+        api.Segmentation.process(img, env)
+    env.close()
+
+    hot = dict(params)
+    hot["enc.pos"] = params["enc.pos"].copy()
+    hot["enc.pos"][:, 0] = 1.0e5
+    d2 = tmp_path / "hot"
+    W.save_weights(d2 / "segmentation" / W.weight_file_name(cfg), cfg, hot)
+    env = api.Environment(api.Options(api.Backend.gpu, str(d2)))
+    with pytest.raises(api.Error, match="non-finite values: an activation left the f16 range"):
+        api.Segmentation.process(img, env)
+    with pytest.raises(api.Error, match="non-finite values"):
+        api.Segmentation.process_batch([img, img, img], env)
+    env.close()
+
+    # the same images on the unmodified weights still work in this process (nothing sticky, no poisoned buffers)
+    mdir, _, _ = model_dirs("vit_test")
+    env = api.Environment(api.Options(api.Backend.gpu, mdir))
+    seg = api.Segmentation.process(img, env)
+    assert np.isfinite(api.ext.get_embedding(seg)).all()
+    seg.close()
+    env.close()

@@ -111,3 +111,26 @@ def test_convert_checkpoint_tool(tmp_path, fmt):
     assert cfg2["embed_dim"] == cfg.embed_dim and cfg2["depth"] == cfg.depth
     for name, value in params.items():
         assert np.array_equal(back[name], value), name
+
+
+def test_values_outside_the_f16_range_are_refused_when_a_model_is_written(tmp_path):
+    """No real checkpoint has run here, and f16 operands overflow silently on the device (65504): the writer -- which
+    tools/convert_checkpoint.py goes through -- refuses what cannot be represented, by tensor name."""
+    cfg = get_config("vit_test")
+    params = W.synthetic_weights(cfg, 3)
+    bad = dict(params)
+    bad["enc.L0.fc2.w"] = params["enc.L0.fc2.w"].copy()
+    bad["enc.L0.fc2.w"][3, 5] = 7.0e4
+    with pytest.raises(ValueError, match=r"enc\.L0\.fc2\.w.*f16 range"):
+        W.save_weights(tmp_path / "a.dlw", cfg, bad)
+    W.save_weights(tmp_path / "a2.dlw", cfg, bad, allow_out_of_range=True)      # the tests' way to reach the C++ loader
+    bad = dict(params)
+    bad["enc.L1.ln1.b"] = params["enc.L1.ln1.b"].copy()
+    bad["enc.L1.ln1.b"][0] = np.nan
+    with pytest.raises(ValueError, match="non-finite"):
+        W.save_weights(tmp_path / "b.dlw", cfg, bad, allow_out_of_range=True)
+    # fp32-only tensors may be large: the residual stream and the token side of the decoder are not f16 operands
+    ok = dict(params)
+    ok["enc.L0.fc2.b"] = params["enc.L0.fc2.b"] + 1.0e5
+    W.save_weights(tmp_path / "c.dlw", cfg, ok)
+    assert W.f16_operand("enc.L0.qkv.w") and W.f16_operand("enc.L1.rel_h") and not W.f16_operand("enc.L0.ln1.w")
