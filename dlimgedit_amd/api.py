@@ -392,6 +392,7 @@ class ext:
                 "dlimg_amd_take_stage_stats": ([vp, vp, vp, vp], ci),
                 "dlimg_amd_test_preprocess": ([vp, ci, ci, ci, ci, vp], ci),
                 "dlimg_amd_test_postprocess": ([vp, ci, vp, ci, ci, vp], ci),
+                "dlimg_amd_test_postprocess_batch": ([vp, ci, ci, ci, vp], ci),
                 "dlimg_amd_test_force_gemm_tile": ([ci], ci),
                 "dlimg_amd_test_force_gemm_consumer_tile": ([ci], ci),
                 "dlimg_amd_test_gemm": ([ci, ci, ci, vp, vp, vp, vp, ci, ci, vp, vp], ci),
@@ -424,7 +425,7 @@ class ext:
                "dlimg_amd_encode_and_mask", "dlimg_amd_encode_only", "dlimg_amd_synchronize", "dlimg_amd_lane_count",
                "dlimg_amd_queue_config", "dlimg_amd_replica_count", "dlimg_amd_segmentation_device", "dlimg_amd_get_segmentation_masks_device",
                "dlimg_amd_set_profiling",
-               "dlimg_amd_take_stage_stats", "dlimg_amd_test_preprocess", "dlimg_amd_test_postprocess",
+               "dlimg_amd_take_stage_stats", "dlimg_amd_test_preprocess", "dlimg_amd_test_postprocess", "dlimg_amd_test_postprocess_batch",
                "dlimg_amd_test_force_gemm_tile", "dlimg_amd_test_force_gemm_consumer_tile", "dlimg_amd_test_gemm", "dlimg_amd_test_gemm_ln", "dlimg_amd_test_gemm_stream", "dlimg_amd_test_layernorm", "dlimg_amd_test_attention", "dlimg_amd_test_resize",
                "dlimg_amd_birefnet_prepare_image", "dlimg_amd_birefnet_process_mask", "dlimg_amd_resize_mask",
                "dlimg_amd_bench_attention", "dlimg_amd_bench_prepost", "dlimg_amd_bench_gemm", "dlimg_amd_bench_gemm_streams", "dlimg_amd_bench_gemm_stamps")
@@ -611,6 +612,14 @@ class ext:
         iou = None if iou is None else np.ascontiguousarray(iou, dtype=np.float32)
         _check(cls._l().dlimg_amd_test_postprocess(planes.ctypes.data, planes.shape[0], cls._ptr(iou), out_w, out_h,
                                                    out.ctypes.data))
+        return out
+
+    @classmethod
+    def test_postprocess_batch(cls, planes: np.ndarray, out_w: int, out_h: int) -> np.ndarray:
+        """One launch for all planes (one mask each): the batched form of the post-processing kernel."""
+        planes = np.ascontiguousarray(planes, dtype=np.float32).reshape(-1, 256, 256)
+        out = np.empty((planes.shape[0], out_h, out_w), dtype=np.uint8)
+        _check(cls._l().dlimg_amd_test_postprocess_batch(planes.ctypes.data, planes.shape[0], out_w, out_h, out.ctypes.data))
         return out
 
     @classmethod

@@ -635,6 +635,26 @@ DLIMG_API int dlimg_amd_test_postprocess(float const* planes, int n_planes, floa
     });
 }
 
+DLIMG_API int dlimg_amd_test_postprocess_batch(float const* planes, int n_masks, int out_w, int out_h, uint8_t* out_masks) {
+    return guarded([&] {
+        require_gpu();
+        DLIMG_ASSERT(planes != nullptr && out_masks != nullptr && n_masks >= 1 && n_masks <= 16 && out_w > 0 && out_h > 0);
+        const size_t px = (size_t)out_w * out_h;
+        Upload<float> src(planes, (size_t)n_masks * kLowRes * kLowRes);
+        DeviceBuffer<uint8_t> dst(px * n_masks);
+        HIP_CHECK(hipMemset(dst.get(), 0x5a, px * n_masks));                  // nothing but what the kernel writes counts
+        ResizeLongestSide rs;
+        rs.set(Extent{out_w, out_h});
+        std::vector<k::PostJob> jobs;
+        for (int i = 0; i < n_masks; ++i)
+            jobs.push_back(k::PostJob{src.get() + (size_t)i * kLowRes * kLowRes, nullptr, dst.get() + i * px, out_w, out_h,
+                                      rs.resized.width, rs.resized.height});
+        k::postprocess_masks(jobs.data(), n_masks, nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+        download(out_masks, dst.get(), px * n_masks);
+    });
+}
+
 DLIMG_API int dlimg_amd_test_force_gemm_tile(int tile) {
     g_forced_test_tile.store(tile < 0 ? -1 : tile, std::memory_order_relaxed);
     g_forced_consumer_tile.store(-1, std::memory_order_relaxed);

@@ -58,15 +58,26 @@ DLIMG_DEVICE float stage1(const float* __restrict__ low, int Y, int X) {
 }
 
 // Fast form for masks whose second stage is the identity (longest side 1024: BASELINE configs 1-4).  The first stage is an
-// exact 4x up-sampling, so inside the plane the taps of output pixel 4j + p are the same for every j: columns (j-1, j)
-// with weights (0.375, 0.625) and (0.125, 0.875) for p = 0, 1, columns (j, j+1) with (0.875, 0.125) and (0.625, 0.375) for
-// p = 2, 3 -- the values make_tap computes (0.25 * (x + 0.5) - 0.5 is exact in fp32), rows alike.  A thread therefore
-// produces a 4 x 4 block of the mask from a 3 x 3 neighbourhood of logits: 9 loads and ~110 rounded operations for 16
-// pixels (the per-pixel form: 64 loads, ~350), the same multiplications and additions in the same order, so the mask
-// is bit-identical.  Blocks on the border of the logit plane (clamped taps) and ragged right / bottom edges take the
-// per-pixel path.  16 masks per launch: 38 us (0.55 TB/s, VALU- and L1-bound) -> 17 us (1.2 TB/s, latency-bound).
-__global__ __launch_bounds__(256) void postprocess_identity_kernel(JobPack pack) {
-    const k::PostJob job = pack.j[blockIdx.y];
+// exact 4x up-sampling, so the taps of output pixel 4j + p are the same for every j: columns (j-1, j) with weights
+// (0.375, 0.625) and (0.125, 0.875) for p = 0, 1, columns (j, j+1) with (0.875, 0.125) and (0.625, 0.375) for p = 2, 3 --
+// the values make_tap computes (0.25 * (x + 0.5) - 0.5 is exact in fp32), rows alike; at the right / bottom border the
+// clamped index gives the same sum of two products, at the left / top border (pixels 0, 1) make_tap clamps the
+// COORDINATE: taps (0, 1) with weights (1, 0), which the first lane / first row band select.  Same multiplications and
+// additions in the same order as the per-pixel form, so the mask is bit-identical (tests: test_postprocess_bit_exact).
+//
+// Against the HBM roofline (r05): a lane owns 16 consecutive pixels of 8 rows.  It reads four logits per logit row as ONE
+// 16-byte load -- a wave reads whole 1 KB logit rows -- and gets its two neighbours from the adjacent lanes; it writes
+// 16 bytes per pixel row, so a wave-instruction stores one whole 1 KB row of the mask (r04: 4 bytes per lane, 256 B per
+// instruction, three scalar loads per row, 0.10 of the HBM peak at 16 masks per launch).  A workgroup = 4 waves = 32
+// consecutive pixel rows; the workgroups of a mask are consecutive ids of ONE XCD (xcd_remap), whose L2 serves the two
+// logit rows neighbouring bands share.  Ragged extents (W < 1024 or H not a multiple of 8) compute the same values and
+// only store what is inside.
+constexpr int ID_ROWS = 8;                       // pixel rows per lane (two logit rows + one above, one below)
+__global__ __launch_bounds__(256) void postprocess_identity_kernel(JobPack pack, int bands_per_mask) {
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const k::PostJob job = pack.j[logical / bands_per_mask];
+    const int band = (logical % bands_per_mask) * 4 + (threadIdx.x >> 6);      // band of ID_ROWS pixel rows
+    const int lane = lane_id();
     const float* low = job.src;
     if (job.select_iou) {
         float best = __fadd_rn(job.select_iou[0], __fmul_rn(-0.5f, 1000.0f));
@@ -77,82 +88,53 @@ __global__ __launch_bounds__(256) void postprocess_identity_kernel(JobPack pack)
         low += (size_t)bi * LOW * LOW;
     }
     const int W = job.out_w, H = job.out_h;
-    const int bw = (W + 3) >> 2, bh = (H + 3) >> 2;
-    // a thread takes FOUR vertically adjacent 4 x 4 blocks (16 rows x 4 columns of the mask): a quarter of the waves, and the
-    // 18 logits of its 6 x 3 neighbourhood are requested together instead of 9 per wave (r04: 16 masks per launch, inputs
-    // and outputs rotating through 768 MB so that they come from HBM: 21.5 us -> see DESIGN section 6)
-    const int bh4 = (bh + 3) >> 2;
-    const long total = (long)bw * bh4;
+    const int oy0 = band * ID_ROWS, ox0 = lane * 16;
+    if (oy0 >= H) return;                        // (wave-uniform)
+    constexpr int LR = ID_ROWS / 4;              // logit rows of the band
+    const int ly0 = band * LR;
+    // horizontal pass: hz[r][x] = value of logit row ly0 - 1 + r at the lane's 16 pixel columns
     const float wa[4] = {0.375f, 0.125f, 0.875f, 0.625f};      // weight of the first tap for p = 0..3
     const float wb[4] = {0.625f, 0.875f, 0.125f, 0.375f};      // weight of the second tap
-    for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long)gridDim.x * 256) {
-        const int by4 = (int)(g / bw), bx = (int)(g % bw);
-        const int ox0 = bx * 4;
-        const bool cols_inside = bx >= 1 && bx <= LOW - 2 && ox0 + 4 <= W && (W & 3) == 0 && (((uintptr_t)job.dst) & 3) == 0;
-        const bool all_interior = cols_inside && by4 >= 1 && by4 * 4 + 3 <= LOW - 2 && by4 * 16 + 16 <= H;
-        if (all_interior) {
-            // logit rows by0 - 1 .. by0 + 4 (six), columns bx - 1 .. bx + 1: horizontal interpolation once per row
-            const int by0 = by4 * 4;
-            float hz[6][4];
+    const bool first = lane == 0, last = lane == 63;
+    float hz[LR + 2][16];
 #pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                const float* row = low + (by0 - 1 + r) * LOW + (bx - 1);
-                const float v0 = row[0], v1 = row[1], v2 = row[2];
+    for (int r = 0; r < LR + 2; ++r) {
+        int ly = ly0 - 1 + r;
+        ly = ly < 0 ? 0 : (ly > LOW - 1 ? LOW - 1 : ly);
+        const float4_t c = *reinterpret_cast<const float4_t*>(low + ly * LOW + lane * 4);
+        float left = __shfl_up(c[3], 1, 64), right = __shfl_down(c[0], 1, 64);
+        if (last) right = c[3];                  // clamped index 256 -> 255
+        const float v[6] = {left, c[0], c[1], c[2], c[3], right};
 #pragma unroll
-                for (int p = 0; p < 4; ++p) hz[r][p] = __fadd_rn(__fmul_rn(p < 2 ? v0 : v1, wa[p]), __fmul_rn(p < 2 ? v1 : v2, wb[p]));
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float a = v[j + (p < 2 ? 0 : 1)], bq = v[j + (p < 2 ? 1 : 2)], fa = wa[p], fb = wb[p];
+                if (j == 0 && p < 2 && first) { a = c[0]; bq = c[1]; fa = 1.0f; fb = 0.0f; }     // pixels 0, 1: taps (0, 1), weights (1, 0)
+                hz[r][j * 4 + p] = __fadd_rn(__fmul_rn(a, fa), __fmul_rn(bq, fb));
             }
-            uint8_t* dst = job.dst + (size_t)(by0 * 4) * W + ox0;
+    }
+    const bool wide = (W & 15) == 0 && (((uintptr_t)job.dst) & 15) == 0 && ox0 + 16 <= W;
 #pragma unroll
-            for (int sub = 0; sub < 4; ++sub)
+    for (int y = 0; y < ID_ROWS; ++y) {
+        const int oy = oy0 + y;
+        if (oy >= H) break;
+        const int q = y & 3, r0 = (y >> 2) + (q < 2 ? 0 : 1);      // rows (ly - 1, ly) for q = 0, 1, (ly, ly + 1) for q = 2, 3
+        // pixel rows 0, 1 (first band only; y < 2 is a compile-time fact in the unrolled loop): taps (0, 1), weights (1, 0)
+        const bool top_rows = y < 2 && band == 0;
+        const float fa = top_rows ? 1.0f : wa[q], fb = top_rows ? 0.0f : wb[q];
+        uint32_t packed[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int r0 = sub + (q < 2 ? 0 : 1);
-                    uint32_t packed = 0;
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        const float val = __fadd_rn(__fmul_rn(wa[q], hz[r0][p]), __fmul_rn(wb[q], hz[r0 + 1][p]));
-                        if (val > 0.f) packed |= 0xffu << (8 * p);
-                    }
-                    *reinterpret_cast<uint32_t*>(dst + (size_t)(sub * 4 + q) * W) = packed;
-                }
-            continue;
+        for (int x = 0; x < 16; ++x) {
+            const float top = top_rows ? hz[1][x] : hz[r0][x], bot = top_rows ? hz[2][x] : hz[r0 + 1][x];
+            const float val = __fadd_rn(__fmul_rn(fa, top), __fmul_rn(fb, bot));
+            if (val > 0.f) packed[x >> 2] |= 0xffu << (8 * (x & 3));
         }
-        for (int sub = 0; sub < 4; ++sub) {
-            const int by = by4 * 4 + sub;
-            if (by >= bh) break;
-            const int oy0 = by * 4;
-            uint8_t* dst = job.dst + (size_t)oy0 * W + ox0;
-            const bool interior = by >= 1 && by <= LOW - 2 && bx >= 1 && bx <= LOW - 2 && oy0 + 4 <= H && ox0 + 4 <= W &&
-                                  (((uintptr_t)dst | (uintptr_t)W) & 3) == 0;
-            if (interior) {
-                float v[3][3];
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) v[r][c] = low[(by - 1 + r) * LOW + (bx - 1 + c)];
-                float hz[3][4];                  // horizontal interpolation of the three rows at the four x positions
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        const int c0 = p < 2 ? 0 : 1;
-                        hz[r][p] = __fadd_rn(__fmul_rn(v[r][c0], wa[p]), __fmul_rn(v[r][c0 + 1], wb[p]));
-                    }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int r0 = q < 2 ? 0 : 1;
-                    uint32_t packed = 0;
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        const float val = __fadd_rn(__fmul_rn(wa[q], hz[r0][p]), __fmul_rn(wb[q], hz[r0 + 1][p]));
-                        if (val > 0.f) packed |= 0xffu << (8 * p);
-                    }
-                    *reinterpret_cast<uint32_t*>(dst + (size_t)q * W) = packed;
-                }
-            } else {
-                for (int q = 0; q < 4 && oy0 + q < H; ++q)
-                    for (int p = 0; p < 4 && ox0 + p < W; ++p) dst[(size_t)q * W + p] = stage1(low, oy0 + q, ox0 + p) > 0.f ? 255 : 0;
-            }
+        uint8_t* dst = job.dst + (size_t)oy * W + ox0;
+        if (wide) {
+            *reinterpret_cast<uint4_t*>(dst) = uint4_t{packed[0], packed[1], packed[2], packed[3]};
+        } else {
+            for (int x = 0; x < 16 && ox0 + x < W; ++x) dst[x] = (uint8_t)(packed[x >> 2] >> (8 * (x & 3)));
         }
     }
 }
@@ -211,7 +193,7 @@ void postprocess_masks(const PostJob* jobs, int count, hipStream_t s) {
     for (int base = 0; base < count; base += MAX_JOBS) {
         const int n = count - base < MAX_JOBS ? count - base : MAX_JOBS;
         JobPack pack{};
-        long max_groups = 1, max_blocks16 = 1;
+        long max_groups = 1;
         bool all_identity = true;
         for (int i = 0; i < n; ++i) {
             const PostJob& j = jobs[base + i];
@@ -221,17 +203,16 @@ void postprocess_masks(const PostJob* jobs, int count, hipStream_t s) {
             pack.j[i] = j;
             long g = (long)j.out_h * ((j.out_w + 3) / 4);
             if (g > max_groups) max_groups = g;
-            long b16 = (long)((((j.out_h + 3) / 4) + 3) / 4) * ((j.out_w + 3) / 4);      // 16 x 4 pixels per thread
-            if (b16 > max_blocks16) max_blocks16 = b16;
             all_identity = all_identity && j.pre_w == j.out_w && j.pre_h == j.out_h;
         }
-        // second stage = identity for every job of the launch: 4 x 4 pixels per thread.  Only for launches of several
-        // masks: with one or two masks the 65 536 threads per mask of that form do not fill the chip and the launch takes
-        // 5.4 us instead of 3.9; at 16 masks 17 us instead of 38.
-        if (all_identity && n >= 4) {
-            long blocks = (max_blocks16 + 255) / 256;
-            if (blocks > 4096) blocks = 4096;
-            hipLaunchKernelGGL(postprocess_identity_kernel, dim3((unsigned)blocks, n), dim3(256), 0, s, pack);
+        // second stage = identity for every job of the launch: the exact-4x form, 16 x 8 pixels per lane.  From three masks
+        // per launch on (MI355X, us per launch for 1 / 2 / 3 / 4 / 8 / 16 masks: per-pixel form 4.1 / 5.8 / 8.1 / 9.8 / 17.7 /
+        // 34.8, this form 6.0 / 6.4 / 6.5 / 7.0 / 8.0 / 11.7: it has the longer dependent chain and the higher floor)
+        if (all_identity && n >= 3) {
+            int max_h = 1;
+            for (int i = 0; i < n; ++i) max_h = jobs[base + i].out_h > max_h ? jobs[base + i].out_h : max_h;
+            const int bands = ((max_h + ID_ROWS - 1) / ID_ROWS + 3) / 4;          // workgroups (4 bands each) per mask
+            hipLaunchKernelGGL(postprocess_identity_kernel, dim3((unsigned)(bands * n)), dim3(256), 0, s, pack, bands);
             continue;
         }
         long blocks = (max_groups + 255) / 256;

@@ -128,6 +128,8 @@ DLIMG_API int dlimg_amd_test_preprocess(uint8_t const* pixels, int width, int he
  * decoder does, otherwise plane 0 is used.  out_mask: out_w*out_h bytes. */
 DLIMG_API int dlimg_amd_test_postprocess(float const* planes, int n_planes, float const* iou, int out_w, int out_h,
                                          uint8_t* out_mask);
+/* K16, several masks in ONE launch (the form slot 14 uses for a chunk of prompts): plane i -> out_masks + i * out_w * out_h. */
+DLIMG_API int dlimg_amd_test_postprocess_batch(float const* planes, int n_masks, int out_w, int out_h, uint8_t* out_masks);
 /* Forces tile configuration `tile` (index into kernels/gemm.hip's table; < 0: off) in the GEMM test hooks below wherever it
  * fits the problem.  Affects only dlimg_amd_test_gemm / dlimg_amd_test_gemm_ln / the bench hooks, never the product path. */
 DLIMG_API int dlimg_amd_test_force_gemm_tile(int tile);

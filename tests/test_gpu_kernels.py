@@ -96,6 +96,26 @@ def test_postprocess_bit_exact(ext, w, h):
     assert set(np.unique(got)) <= {0, 255}
 
 
+@pytest.mark.parametrize("w,h", [(1024, 1024), (1024, 683), (681, 1024), (1024, 2), (1022, 1024), (1024, 1021), (600, 1024)])
+def test_postprocess_batched_identity_form_bit_exact(ext, w, h):
+    """Launches of three or more masks whose second stage is the identity take the exact-4x form (16 x 8 pixels per lane,
+    16-byte loads and stores; kernels/postprocess.hip): against the oracle, bit for bit, including the first two pixel
+    rows / columns (clamped coordinate), the last ones (clamped index), extents that are not multiples of 16 or 8, and
+    extreme logits at the borders of the plane."""
+    O = _oracle()
+    planes = _planes(w * 3 + h, 5)
+    planes[1, 0, :] = 50.0
+    planes[1, :, 0] = -50.0
+    planes[2, 255, :] = np.linspace(-1e-3, 1e-3, 256, dtype=np.float32)
+    planes[2, :, 255] = np.linspace(1e-3, -1e-3, 256, dtype=np.float32)
+    planes[3] *= 1e-4
+    got = ext.test_postprocess_batch(planes, w, h)
+    for i in range(planes.shape[0]):
+        want = O.write_mask_image(O.postprocess_logits(planes[i], (h, w))[None, None], 0, (w, h))
+        assert np.array_equal(got[i], want), i
+    assert set(np.unique(got)) <= {0, 255}
+
+
 def test_postprocess_write_mask_kat(ext):
     """reference test_segmentation.cpp:85-99: strict > 0 (0.0 stays 0)."""
     planes = np.zeros((1, 256, 256), np.float32)
