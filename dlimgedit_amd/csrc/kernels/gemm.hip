@@ -665,23 +665,31 @@ DLIMG_DEVICE void pp_epilogue(const k::GemmArgs& a, float4v (&acc)[NI][4], char*
         auto fp32_bands = [&](auto resid_tag, auto h_tag) {
             constexpr int RESID = decltype(resid_tag)::value;        // 0 none, 1 fp32, 2 f16 pair (hi + lo)
             constexpr int OUT = decltype(h_tag)::value;              // 0 fp32, 1 fp32 + f16 copy, 2 f16 pair
-            constexpr bool HAS_RESID = RESID != 0;
             constexpr bool HAS_H = OUT == 1;
-            // ---- fp32 rows of 64 floats: 16-byte slot (j*4 + quad) ^ (row & 7)
-            const int rd_row = lane >> 4, rd_slot = lane & 15;
-            // the band's residual in whole lines, requested one band ahead of its use (its latency would otherwise be
-            // paid once per band: 3.5 k cycles per band measured)
+            // ---- fp32 rows of 64 floats: 16-byte slot (j*4 + quad) ^ (row & 7).  Read back EIGHT columns per lane (two
+            // slots), 8 lanes per row, 8 rows per pass, two passes per band: every global access of the band is then a
+            // 16-byte one -- the f16 pair's hi and lo halves of 8 columns are 16 bytes each (r05; four columns per lane
+            // made them 8-byte accesses, twice as many instructions through the CU's memory pipe, which is what bounds
+            // this epilogue).  A row's 64 columns sit in 8 adjacent lanes for the statistics.
+            const int rd_row = lane >> 3, rd_col = (lane & 7) * 8;
+            // the band's residual, requested one band ahead of its use (its latency would otherwise be paid once per
+            // band: 3.5 k cycles per band measured).  Per pass two 16-byte registers: fp32 columns 0-3 / 4-7, or hi / lo.
             float4_t rv[2][4];
             auto request_residual = [&](int i, float4_t (&dst)[4]) {
     #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    dst[kk] = float4_t{0.f, 0.f, 0.f, 0.f};
-                    const int r = kk * 4 + rd_row;
-                    if (RESID == 1 && !kNoResidRead)
-                        dst[kk] = *reinterpret_cast<const float4_t*>(a.resid + (size_t)(resid_row0 + row_base + i * 16 + r) * a.ldr +
-                                                                     n0 + wc * 64 + rd_slot * 4);
-                    if (RESID == 2)
-                        dst[kk] = hilo_load(a.resid_h, a.resid_l, (size_t)(resid_row0 + row_base + i * 16 + r) * a.ldrs + n0 + wc * 64 + rd_slot * 4);
+                for (int kk = 0; kk < 2; ++kk) {
+                    dst[kk * 2] = dst[kk * 2 + 1] = float4_t{0.f, 0.f, 0.f, 0.f};
+                    const int r = kk * 8 + rd_row;
+                    if (RESID == 1 && !kNoResidRead) {
+                        const float* src = a.resid + (size_t)(resid_row0 + row_base + i * 16 + r) * a.ldr + n0 + wc * 64 + rd_col;
+                        dst[kk * 2] = *reinterpret_cast<const float4_t*>(src);
+                        dst[kk * 2 + 1] = *reinterpret_cast<const float4_t*>(src + 4);
+                    }
+                    if (RESID == 2) {
+                        const size_t off = (size_t)(resid_row0 + row_base + i * 16 + r) * a.ldrs + n0 + wc * 64 + rd_col;
+                        dst[kk * 2] = *reinterpret_cast<const float4_t*>(a.resid_h + off);
+                        dst[kk * 2 + 1] = *reinterpret_cast<const float4_t*>(a.resid_l + off);
+                    }
                 }
             };
             if (!PRE) request_residual(0, rv[0]);
@@ -701,42 +709,51 @@ DLIMG_DEVICE void pp_epilogue(const k::GemmArgs& a, float4v (&acc)[NI][4], char*
                 if (!PRE && i + 1 < NI) request_residual(i + 1, rv[(i + 1) & 1]);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int r = kk * 4 + rd_row;
-                    float4_t v = *reinterpret_cast<const float4_t*>(sl + r * 256 + ((rd_slot ^ (r & 7)) << 4));
-                    const float4_t rr = PRE ? pre[i][kk] : rv[i & 1][kk];
-                    v += RESID == 2 ? hilo_value(rr) : rr;
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int r = kk * 8 + rd_row;
+                    const int slot = (lane & 7) * 2;
+                    float4_t v0 = *reinterpret_cast<const float4_t*>(sl + r * 256 + ((slot ^ (r & 7)) << 4));
+                    float4_t v1 = *reinterpret_cast<const float4_t*>(sl + r * 256 + (((slot + 1) ^ (r & 7)) << 4));
+                    const float4_t ra = PRE ? pre[i][kk * 2] : rv[i & 1][kk * 2], rb = PRE ? pre[i][kk * 2 + 1] : rv[i & 1][kk * 2 + 1];
+                    if (RESID == 1) {
+                        v0 += ra;
+                        v1 += rb;
+                    } else if (RESID == 2) {
+                        // ra = hi of the 8 columns, rb = lo: (h01, h23, l01, l23) per group of four
+                        const uint4_t xa = __builtin_bit_cast(uint4_t, ra), xb = __builtin_bit_cast(uint4_t, rb);
+                        v0 += hilo_value(__builtin_bit_cast(float4_t, uint4_t{xa[0], xa[1], xb[0], xb[1]}));
+                        v1 += hilo_value(__builtin_bit_cast(float4_t, uint4_t{xa[2], xa[3], xb[2], xb[3]}));
+                    }
                     const size_t m = (size_t)(m0 + row_base + i * 16 + r);
-                    const int col = n0 + wc * 64 + rd_slot * 4;
+                    const int col = n0 + wc * 64 + rd_col;
                     if (OUT == 2) {
-                        const HiLo4 p = hilo_split(v);
-                        *reinterpret_cast<half4_t*>(a.out_h + m * a.ldc16 + col) = p.h;
-                        *reinterpret_cast<half4_t*>(a.out_l + m * a.ldc16 + col) = p.l;
+                        const HiLo4 p0 = hilo_split(v0), p1 = hilo_split(v1);
+                        const uint2_t h0 = __builtin_bit_cast(uint2_t, p0.h), h1 = __builtin_bit_cast(uint2_t, p1.h);
+                        const uint2_t l0 = __builtin_bit_cast(uint2_t, p0.l), l1 = __builtin_bit_cast(uint2_t, p1.l);
+                        *reinterpret_cast<uint4_t*>(a.out_h + m * a.ldc16 + col) = uint4_t{h0[0], h0[1], h1[0], h1[1]};
+                        *reinterpret_cast<uint4_t*>(a.out_l + m * a.ldc16 + col) = uint4_t{l0[0], l0[1], l1[0], l1[1]};
                     } else {
-                        *reinterpret_cast<float4_t*>(a.out_f32 + m * a.ldc32 + col) = v;
+                        *reinterpret_cast<float4_t*>(a.out_f32 + m * a.ldc32 + col) = v0;
+                        *reinterpret_cast<float4_t*>(a.out_f32 + m * a.ldc32 + col + 4) = v1;
                     }
                     if (HAS_H && !kNoCopyWrite) {
-                        const half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                        *reinterpret_cast<half4_t*>(a.out_h + m * a.ldc16 + col) = h;
+                        const half8_t h = {(half_t)v0[0], (half_t)v0[1], (half_t)v0[2], (half_t)v0[3],
+                                           (half_t)v1[0], (half_t)v1[1], (half_t)v1[2], (half_t)v1[3]};
+                        *reinterpret_cast<half8_t*>(a.out_h + m * a.ldc16 + col) = h;
                     }
                     if (EPI == EPI_STATS) {
-                        // the row's 64 columns of this wave are in the 16 lanes of one DPP row: (sum, squared deviations)
-                        float s1 = (v[0] + v[1]) + (v[2] + v[3]);
-                        s1 += dpp_move<0xB1>(s1);        // quad_perm [1,0,3,2]
-                        s1 += dpp_move<0x4E>(s1);        // quad_perm [2,3,0,1]
-                        s1 += dpp_move<0x141>(s1);       // row_half_mirror
-                        s1 += dpp_move<0x140>(s1);       // row_mirror
-                        const float4_t d = v - s1 * (1.0f / 64.0f);
-                        float m2 = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
-                        m2 += dpp_move<0xB1>(m2);
-                        m2 += dpp_move<0x4E>(m2);
-                        m2 += dpp_move<0x141>(m2);
-                        m2 += dpp_move<0x140>(m2);
-                        if (rd_slot == 0) rowpart[(row_base + i * 16 + r) * 4 + wc] = float2_t{s1, m2};
+                        // the row's 64 columns of this wave are in 8 adjacent lanes: (sum, squared deviations)
+                        float s1 = ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
+                        s1 = sum_over_8_lanes(s1);
+                        const float4_t d0 = v0 - s1 * (1.0f / 64.0f), d1 = v1 - s1 * (1.0f / 64.0f);
+                        float m2 = ((d0[0] * d0[0] + d0[1] * d0[1]) + (d0[2] * d0[2] + d0[3] * d0[3])) +
+                                   ((d1[0] * d1[0] + d1[1] * d1[1]) + (d1[2] * d1[2] + d1[3] * d1[3]));
+                        m2 = sum_over_8_lanes(m2);
+                        if ((lane & 7) == 0) rowpart[(row_base + i * 16 + r) * 4 + wc] = float2_t{s1, m2};
                     }
                 }
             }
-    
+
         };
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
@@ -1041,22 +1058,27 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(k::GemmArgs a) {
         for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) rpre[i][kk] = float4_t{0.f, 0.f, 0.f, 0.f};
+        // (lane mapping of pp_epilogue's read-back: 8 lanes per row, 8 columns each, 8 rows per pass)
         if (a.resid && !kNoResidRead) {          // one uniform branch around all the requests
             const int resid_row0 = m0 % a.resid_mod;
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-                    rpre[i][kk] = *reinterpret_cast<const float4_t*>(
-                        a.resid + (size_t)(resid_row0 + wr * (BM / 2) + i * 16 + kk * 4 + (lane >> 4)) * a.ldr + n0 + wc * 64 + (lane & 15) * 4);
-        } else if (a.resid_h) {                  // the residual as an f16 pair: the same 16 bytes per lane and request
+                for (int kk = 0; kk < 2; ++kk) {
+                    const float* src = a.resid + (size_t)(resid_row0 + wr * (BM / 2) + i * 16 + kk * 8 + (lane >> 3)) * a.ldr + n0 + wc * 64 + (lane & 7) * 8;
+                    rpre[i][kk * 2] = *reinterpret_cast<const float4_t*>(src);
+                    rpre[i][kk * 2 + 1] = *reinterpret_cast<const float4_t*>(src + 4);
+                }
+        } else if (a.resid_h) {                  // the residual as an f16 pair: hi and lo of 8 columns, 16 bytes each
             const int resid_row0 = m0 % a.resid_mod;
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-                    rpre[i][kk] = hilo_load(a.resid_h, a.resid_l,
-                                            (size_t)(resid_row0 + wr * (BM / 2) + i * 16 + kk * 4 + (lane >> 4)) * a.ldrs + n0 + wc * 64 + (lane & 15) * 4);
+                for (int kk = 0; kk < 2; ++kk) {
+                    const size_t off = (size_t)(resid_row0 + wr * (BM / 2) + i * 16 + kk * 8 + (lane >> 3)) * a.ldrs + n0 + wc * 64 + (lane & 7) * 8;
+                    rpre[i][kk * 2] = *reinterpret_cast<const float4_t*>(a.resid_h + off);
+                    rpre[i][kk * 2 + 1] = *reinterpret_cast<const float4_t*>(a.resid_l + off);
+                }
         }
     }
     pp_barrier();
