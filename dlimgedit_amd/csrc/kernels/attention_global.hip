@@ -171,10 +171,12 @@ __global__ __launch_bounds__(512, 2) void attention_global_kernel(const half_t* 
     // relw[i][kx] = q_i . rel_w[qx_i - kx + 63] in accumulator layout (the C operand of the bias MFMA).  The MFMA gives,
     // for query i (a lane), the products with rows d = 0..95 of rel_w[qx0 + d] in accumulator-ROW order; what the lane
     // needs is row d = i - kx + 63 for each of its kx: a per-lane selection of registers, done through LDS.  Each wave
-    // uses its own 8 KB of the relh table (filled afterwards) as [query][kx]: product (d, i) goes to kx = i + 63 - d
-    // -- every d = 32..63 lands inside 0..63, and of d and d + 64 exactly one does, so 32 unconditional stores per lane
-    // -- and comes back as eight 16-byte reads; 16-byte chunks XOR-swizzled by the query: both directions conflict-free.
-    float* gw = reinterpret_cast<float*>(relh_pk) + wave * 64 * RELH_STRIDE;
+    // uses its own 8 KB of the relh table (filled afterwards) as [kx][query]: product (d, i) goes to kx = i + 63 - d
+    // -- every d = 32..63 lands inside 0..63, and of d and d + 64 exactly one does (kx mod 64), so 32 unconditional
+    // stores per lane -- and comes back in accumulator order.  Lanes of a wave-instruction hit consecutive words both
+    // ways (conflict-free), and every address is one register plus an immediate (the prologue is straight-line code
+    // that runs once per workgroup, from a cold instruction cache: its length is its cost).
+    char* const gwb = reinterpret_cast<char*>(relh_pk) + wave * (64 * RELH_STRIDE * 4);
     float16_t relw[2];
     const unsigned long long p2 = pstamp();
     {
@@ -186,39 +188,41 @@ __global__ __launch_bounds__(512, 2) void attention_global_kernel(const half_t* 
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) racc[t] = mfma32(row_ok ? rwf[t][ks] : zero_h8(), qf[ks], racc[t]);
         }
-        auto slot = [&](int kx) { return 64 * l31 + (((kx >> 2) ^ (l31 & 15)) << 2) + (kx & 3); };
+        // byte address of (kx, query i) = 128 * kx + 4 * i.  acc_row(r, hi) = e_r + 4 * hi with e_r a compile-time constant.
+        const int d31 = l31 - 4 * hi;                       // i - 4 * hi
+        char* const mid = gwb + 132 * l31 - 512 * hi + 128 * (31 - 27);      // d = 32 + rr: kx = i + 31 - rr, + 128 * (27 - e_r)
+        const uint32_t wrap = (uint32_t)(128 * (d31 + 63) + 4 * l31);      // d = rr or rr + 64: kx = (i + 63 - rr) mod 64
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int rr = acc_row(r, hi);
-            gw[slot(l31 + 31 - rr)] = racc[1][r];
-            const bool low = l31 <= rr;                      // d = rr (kx = i + 63 - rr) or d = rr + 64 (kx = i - 1 - rr)
-            gw[slot(low ? l31 + 63 - rr : l31 - 1 - rr)] = low ? racc[0][r] : racc[2][r];
+            const int e_r = (r & 3) + 8 * (r >> 2);
+            *reinterpret_cast<float*>(mid + 128 * (27 - e_r)) = racc[1][r];
+            *reinterpret_cast<float*>(gwb + ((wrap - 128u * (uint32_t)e_r) & 8191u)) = d31 <= e_r ? racc[0][r] : racc[2][r];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's own stores have landed (LDS is in order per wave)
+        const char* const back = gwb + 4 * l31 + 512 * hi;
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const float4_t v = *reinterpret_cast<const float4_t*>(gw + 64 * l31 + (((jt * 8 + 2 * g4 + hi) ^ (l31 & 15)) << 2));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) relw[jt][g4 * 4 + e] = v[e];
-            }
+            for (int r = 0; r < 16; ++r)
+                relw[jt][r] = *reinterpret_cast<const float*>(back + 128 * (jt * 32 + (r & 3) + 8 * (r >> 2)));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // read before the relh rows below overwrite the scratch
         __builtin_amdgcn_sched_barrier(0);
     }
     // relh[i][ky] = q_i . rel_h[qy - ky + 63]: rows rr = 0..63 <-> rel_h[qy + rr], ky = 63 - rr; kept in LDS as an
     // (hi, lo) f16 pair per (key row, query): that IS the B operand of the bias MFMA
+    {
+        char* const top = gwb + 4 * l31 - 512 * hi;          // (ky, i) at 128 * ky + 4 * i, ky = 63 - 32 t - e_r - 4 hi
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        float16_t acc = zero16();
+        for (int t = 0; t < 2; ++t) {
+            float16_t acc = zero16();
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) acc = mfma32(rhf[t][ks], qf[ks], acc);
+            for (int ks = 0; ks < KS; ++ks) acc = mfma32(rhf[t][ks], qf[ks], acc);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ky = 63 - (t * 32 + acc_row(r, hi));
-            const float v = acc[r];
-            const half_t vh = (half_t)v;
-            relh_pk[(wave * 64 + ky) * RELH_STRIDE + l31] = pack2(vh, (half_t)(v - (float)vh));
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[r];
+                const half_t vh = (half_t)v;
+                *reinterpret_cast<uint32_t*>(top + 128 * (63 - 32 * t - ((r & 3) + 8 * (r >> 2)))) = pack2(vh, (half_t)(v - (float)vh));
+            }
         }
     }
     const unsigned long long p3 = pstamp();
