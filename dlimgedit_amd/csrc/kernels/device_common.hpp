@@ -57,7 +57,7 @@ DLIMG_DEVICE float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071
 // v_pk_mul_f32): fc1's epilogue is VALU-bound (12.6 M outputs on the CUs its tiles occupy; the 7.1.26 form with
 // exp2 + rcp on single values cost 6.7 k of the tile's 11 k epilogue cycles).  Against the fp64 erf form the fp32
 // evaluation is within 7.1e-7 absolute over |x| <= 12; P^16 overflowing to inf for |x| > ~25 gives q = 0, the limit.
-DLIMG_DEVICE float2_t gelu_pair(float2_t x) {
+DLIMG_DEVICE float2_t gelu_pair_erf(float2_t x) {
     const float2_t ax = {fabsf(x[0]), fabsf(x[1])};
     float2_t p = ax * 5.38297500e-6f + 4.88906359e-5f;       // a6 / 8, a5 / (4 sqrt 2)
     p = p * ax + 3.80035750e-5f;                               // a4 / 4
@@ -72,6 +72,24 @@ DLIMG_DEVICE float2_t gelu_pair(float2_t x) {
     const float2_t q = {__builtin_amdgcn_rcpf(p[0]), __builtin_amdgcn_rcpf(p[1])};       // 1 ulp is plenty
     const float2_t pos = {fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f)};
     return pos - (ax * 0.5f) * q;
+}
+// The fc1 epilogue's form (r05): GELU(x) = x * Phi(x) with Phi(x) ~ sigmoid(x (a + b x^2 + c x^4)), the three constants
+// fitted to the exact erf form (max |error| 2.5e-5 over all x, at |x| ~ 2-3; the result is rounded to f16 right after,
+// whose spacing at those values is 1e-3).  x is clamped to +-8 inside the polynomial (c < 0: the argument would turn
+// round beyond |x| ~ 11; at 8 the sigmoid is 1 - 1e-12 / e^-27 already); the final product takes the unclamped x.
+// Per value 3.5 packed instructions + v_exp_f32 + v_rcp_f32 against 8.5 + v_rcp_f32 above.
+DLIMG_DEVICE float2_t gelu_pair(float2_t x) {
+#if defined(DLIMG_GELU_ERF)
+    return gelu_pair_erf(x);
+#endif
+    constexpr float L2E = 1.44269504088896341f;
+    const float2_t xc = {fminf(fmaxf(x[0], -8.0f), 8.0f), fminf(fmaxf(x[1], -8.0f), 8.0f)};
+    const float2_t x2 = xc * xc;
+    float2_t p = x2 * (0.0007030335806902641f * L2E) + (-0.07401129206536386f * L2E);       // -(c x^2 + b) log2(e)
+    p = p * x2 + (-1.5950157685363155f * L2E);                                              // -(... + a) log2(e)
+    const float2_t u = xc * p;                                                              // -x (a + b x^2 + c x^4) log2(e)
+    const float2_t d = float2_t{__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])} + 1.0f;
+    return x * float2_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
 }
 DLIMG_DEVICE float4_t gelu4(float4_t v) {
 #if defined(DLIMG_TUNING) && defined(DLIMG_NO_GELU)      // upper bound of what a cheaper GELU could return (WRONG results)
