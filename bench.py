@@ -411,14 +411,19 @@ def main() -> None:
         achieved_alone = rate(g)
         # HBM-side bytes per GEMM launch are NOT measured in this run: they come from separate rocprofv3 --pmc passes of
         # this command (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE), kept under profiles/
-        traffic_static = None
-        for tfile in (ROOT / "profiles" / "r04_hbm_traffic_pmc.json", ROOT / "profiles" / "r03_hbm_traffic_pmc.json"):
-            if tfile.exists() and args.model == "vit_b" and B == 1:
-                t = json.loads(tfile.read_text())["per_kernel"].get("gemm_pp")
-                if t:
-                    traffic_static = {"value": t["fetch_bytes_per_launch_corrected_x2"] + t["write_bytes_per_launch"],
-                                      "source": f"profiles/{tfile.name} (static: separate --pmc passes, not measured in this run)"}
-                    break
+        traffic, traffic_source = None, None
+        newest = sorted((ROOT / "profiles").glob("r*_hbm_traffic_pmc.json"))
+        if newest and args.model == "vit_b" and B == 1 and dominant:
+            doc = json.loads(newest[-1].read_text())
+            # the dominant flavour's launches of the timed region: the row of its kernel at the grid it runs with there
+            tag = {"gemm_stats": ("gemm_pp_kernel<0, 2>", "gemm_pp_kernel<0,2>"), "gemm_norm": ("gemm_pp_kernel<0, 1>", "gemm_pp_kernel<0,1>"),
+                   "gemm_norm_gelu": ("gemm_pp_kernel<1, 1>", "gemm_pp_kernel<1,1>")}.get(dominant, ())
+            rows = [(k, v) for k, v in doc.get("by_kernel_and_grid", {}).items() if any(k.startswith(t) for t in tag)]
+            if rows:
+                k, v = max(rows, key=lambda kv: kv[1]["launches_in_run"])
+                traffic = v["fetch_bytes_per_launch_corrected_x2"] + v["write_bytes_per_launch"]
+                traffic_source = (f"profiles/{newest[-1].name}, row '{k}': FETCH_SIZE (doubled, gfx950) + WRITE_SIZE per launch from "
+                                  "separate rocprofv3 --pmc passes of this command -- counters cannot be read inside the timed run")
         step_flops = B * (cfg.encoder_flops() + decoder_flops)
         chip_tflops = step_flops / (result["ms_per_step"] * 1e-3) / 1e12          # per GPU (every rank runs the same step)
         lanes_wall_ms = result["ms_per_step"] * args.steps
@@ -428,7 +433,7 @@ def main() -> None:
             # per-kernel rocprofv3 table reproduces (profiles/*_kernel_stats_single_lane_by_grid.txt).
             "kernel": dom["kernel"], "kernel_key": dominant,
             "bound": "mfma", "achieved": dom["tflops"], "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": dom["frac"], "traffic": None, "traffic_static": traffic_static,
+            "frac": dom["frac"], "traffic": traffic, "traffic_source": traffic_source,
             "mode": "single lane: every request on lane 0, each kernel alone on the chip; two-image passes as in the timed region",
             "avg_launch_us": dom["avg_launch_us"], "gflop_per_launch": dom["gflop_per_launch"],
             "per_kernel": per_kernel,

@@ -1033,7 +1033,11 @@ DLIMG_API int dlimg_amd_bench_gemm_stamps(int M, int N, int K, int act, int flav
         std::vector<half_t> ha((size_t)M * K), hw((size_t)N * K);
         uint32_t seed = 12345u;
         auto rnd = [&] { seed = seed * 1664525u + 1013904223u; return ((seed >> 8) & 0xffff) / 32768.0f - 1.0f; };
-        const bool zeros = std::getenv("DLIMGEDIT_BENCH_ZERO") != nullptr;     // clock experiment: all-zero operands
+#ifdef DLIMG_TUNING
+        const bool zeros = std::getenv("DLIMGEDIT_BENCH_ZERO") != nullptr;     // clock experiment (tuning build): all-zero operands
+#else
+        const bool zeros = false;
+#endif
         for (auto& v : ha) v = zeros ? (half_t)0.f : (half_t)rnd();
         for (auto& v : hw) v = zeros ? (half_t)0.f : (half_t)(rnd() * 0.05f);
         Upload<half_t> a(ha.data(), ha.size()), w(hw.data(), hw.size());

@@ -11,8 +11,8 @@
  *   - dlimg_gpu means "HIP device (MI355X)"; dlimg_cpu is reported as unsupported: this build has
  *     no CPU execution path (the onnxruntime CPU provider is not reproduced).
  *   - last_error() is per calling thread (the reference's global string is unsynchronised).
- *   - segment_objects returns dlimg_error (the BiRefNet graph is not part of this build); load_image /
- *     save_image work for PNG files on the host, JPEG input is refused with an explicit message.
+ *   - segment_objects returns dlimg_error (the BiRefNet graph is not part of this build); load_image reads PNG and
+ *     JPEG files on the host, save_image writes PNG.
  *   - unlike the reference header this file is valid C (the struct tag is typedef'ed).
  */
 #ifndef DLIMGEDIT_H_

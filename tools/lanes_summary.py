@@ -57,7 +57,14 @@ timed = [b for b in cand if describe(b)[1] <= 1.3 * med]
 print(f"{len(blocks)} blocks of kernels in the trace; {len(cand)} look like timed repeats ({images_per_block} images on >= 3 lanes), "
       f"{len(timed)} of them within 1.3 x the median wall time are used")
 if not timed:
-    raise SystemExit("no timed block found: run with --blocks to see what the trace holds")
+    # what the trace does hold, as a statement (under rocprofv3 the lanes' passes run one after another on this pool: a
+    # "timed repeat" spread over >= 3 lanes may simply not exist in the profiler's regime)
+    print("no block of this trace looks like a timed repeat on >= 3 lanes: the per-kernel table below covers ALL kernels of the "
+          "trace, and the wall-time lines are omitted")
+    timed = [b for b in blocks if describe(b)[0] > 0]
+    if not timed:
+        print("the trace holds no kernels at all")
+        raise SystemExit(0)
 
 def short(name):
     name = name.replace("_ZN5dlimg12_GLOBAL__N_1", "").replace(".kd", "")

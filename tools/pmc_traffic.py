@@ -24,18 +24,32 @@ def group_of(name):
     return "other"
 
 
-def collect(db_path, counter):
+def short(name):
+    """kernel name with its template arguments, without the namespace prefix and the argument list"""
+    import re
+    name = name.split("(")[0]
+    m = re.search(r"(\w+_kernel)(<[^>]*>)?", name)
+    return (m.group(1) + (m.group(2) or "")) if m else name[:48]
+
+
+def collect(db_path, counter, by_grid=None):
     db = sqlite3.connect(db_path)
     out = {}
-    for name, value in db.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
+    for name, value, grid, wg in db.execute("select kernel_name, value, grid_size, workgroup_size from counters_collection "
+                                            "where counter_name = ?", (counter,)):
         g = out.setdefault(group_of(name), [0, 0.0])
         g[0] += 1
         g[1] += value
+        if by_grid is not None:
+            e = by_grid.setdefault(f"{short(name)} wgs={int(grid // max(wg, 1))}", [0, 0.0])
+            e[0] += 1
+            e[1] += value
     return out
 
 
 def main():
-    fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+    fetch_grid, write_grid = {}, {}
+    fetch, write = collect(sys.argv[1], "FETCH_SIZE", fetch_grid), collect(sys.argv[2], "WRITE_SIZE", write_grid)
     per_kernel = {}
     for g in sorted(set(fetch) | set(write)):
         n_f, kb_f = fetch.get(g, [0, 0.0])
@@ -53,6 +67,13 @@ def main():
                 "counters are in KB; includes Infinity-Cache hits",
         "per_kernel": per_kernel,
     }
+    # the same per (kernel with its template arguments, workgroups of the launch): launches of different batch sizes and
+    # shapes are different rows, so a row's bytes can be set against the algorithmic bytes of exactly that launch
+    doc["by_kernel_and_grid"] = {
+        k: {"launches_in_run": fetch_grid.get(k, [0, 0.0])[0],
+            "fetch_bytes_per_launch_corrected_x2": 2.0 * 1024.0 * fetch_grid.get(k, [0, 0.0])[1] / max(fetch_grid.get(k, [0, 0.0])[0], 1),
+            "write_bytes_per_launch": 1024.0 * write_grid.get(k, [0, 0.0])[1] / max(write_grid.get(k, [0, 0.0])[0], 1)}
+        for k in sorted(set(fetch_grid) | set(write_grid))}
     doc.update(per_kernel.get("gemm_pp", {}))
     with open(sys.argv[3], "w") as f:
         json.dump(doc, f, indent=1)
