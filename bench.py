@@ -320,7 +320,8 @@ def main() -> None:
             result["data"] = "none (stub device)"
         else:
             # what the library's step queue really uses (it clamps the variables and has its own defaults)
-            result["config"].update({"lanes_per_gpu": ext.lane_count(env), "requests_coalesced_per_pass": ext.queue_config(env)["coalesce"],
+            result["config"].update({"lanes_per_gpu": ext.lane_count(env), "lanes_fed_by_the_step_queue": ext.queue_config(env)["lanes_in_use"],
+                                     "requests_coalesced_per_pass": ext.queue_config(env)["coalesce"],
                                      "passes_queued_per_lane": ext.queue_config(env)["step_depth"]})
 
     # ---- N > 1: the ranks that really take part, and the optional gather of the masks (after the timed region)
@@ -434,7 +435,7 @@ def main() -> None:
             "kernel": dom["kernel"], "kernel_key": dominant,
             "bound": "mfma", "achieved": dom["tflops"], "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": dom["frac"], "traffic": traffic, "traffic_source": traffic_source,
-            "mode": "single lane: every request on lane 0, each kernel alone on the chip; two-image passes as in the timed region",
+            "mode": "single lane: every request on lane 0, each kernel alone on the chip; passes of as many images as in the timed region",
             "avg_launch_us": dom["avg_launch_us"], "gflop_per_launch": dom["gflop_per_launch"],
             "per_kernel": per_kernel,
             "all_gemm_launches": {"achieved_single_lane": achieved_alone, "frac_single_lane": achieved_alone / MFMA_F16_PEAK_TFLOPS,

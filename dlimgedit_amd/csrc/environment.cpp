@@ -133,6 +133,10 @@ EnvironmentImpl::EnvironmentImpl(dlimg_Options const& options) : backend(options
         const int v = std::atoi(e);
         coalesce = v < 1 ? 1 : (v > 8 ? 8 : v);
     }
+    if (const char* e = std::getenv("DLIMGEDIT_STEP_LANES")) {
+        const int v = std::atoi(e);
+        step_lanes = v < 0 ? 0 : (v > 8 ? 8 : v);
+    }
     if (const char* e = std::getenv("DLIMGEDIT_STEP_WORKERS")) use_step_workers = std::atoi(e) != 0;
     if (const char* e = std::getenv("DLIMGEDIT_STEP_DEPTH")) {
         const int v = std::atoi(e);

@@ -106,7 +106,14 @@ class EnvironmentImpl {
     std::mutex pending_mutex;
     std::vector<PendingStep> pending;
     std::vector<std::deque<StepPass>> step_passes;     // per lane of replica 0, oldest first (pending_mutex)
-    int coalesce = 2;
+    // Defaults (r05, MI355X, ViT-B, bursts of 8-100 requests): passes of FOUR images on THREE of the lanes.  A four-image
+    // pass fills the chip by itself where a two-image pass does not (768 workgroups of global attention = three full
+    // rounds of the 256 CUs instead of 1.5; 192-tile stream writers), so fewer passes have to share the chip to fill
+    // it: 4 lanes x 2 images 866-886 images/s, 3 x 4 882-902 on the same boxes, 4 x 4 851-867 (five passes of a 20-request
+    // block over four lanes end 2 / 1 / 1 / 1).  The larger models are not sensitive (ViT-H 167-168 either way) and keep
+    // two images per pass.  step_lanes = 0: every lane.  DLIMGEDIT_COALESCE / DLIMGEDIT_STEP_LANES / DLIMGEDIT_STEP_DEPTH.
+    int coalesce = 0;                                  // 0 = chosen from the model when its lanes are created
+    int step_lanes = -1;                               // -1 = likewise
     int step_depth = 2;
     int step_cursor = 0;                               // lane after the one used last (pending_mutex)
     // The passes are enqueued by the lanes' own host threads (lane_worker below);

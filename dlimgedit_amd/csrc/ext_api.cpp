@@ -287,8 +287,21 @@ void run_device_steps(EnvironmentImpl& env, int lane, EnvironmentImpl::PendingSt
 }
 
 // Forgets the passes that have finished and returns the lanes requests are spread over.
-int retire_device_steps(EnvironmentImpl& env) {
+// lanes the step queue deals its passes to, and its pass width: the environment's settings, or the model's defaults
+// (environment.hpp: ViT-B four images per pass on three lanes, larger models two images on every lane)
+int step_queue_lanes(EnvironmentImpl& env) {
     const int lanes = std::max(1, env.effective_lane_count(0));
+    int want = env.step_lanes;
+    if (want < 0) want = env.lane(0, 0).geometry().embed_dim <= 768 ? 3 : 0;
+    return want > 0 ? std::min(lanes, want) : lanes;
+}
+int step_queue_width(EnvironmentImpl& env) {
+    if (env.coalesce > 0) return env.coalesce;
+    return env.lane(0, 0).geometry().embed_dim <= 768 ? 4 : 2;
+}
+
+int retire_device_steps(EnvironmentImpl& env) {
+    const int lanes = step_queue_lanes(env);
     if ((int)env.step_passes.size() < env.lane_count(0)) env.step_passes.resize(env.lane_count(0));
     for (size_t l = 0; l < env.step_passes.size(); ++l) {
         auto& q = env.step_passes[l];
@@ -324,7 +337,7 @@ void flush_device_steps(EnvironmentImpl& env, bool all) {
     const int lanes = retire_device_steps(env);
     StepQueueState st;
     queue_state(env, lanes, st);
-    const std::vector<StepPlanPass> plan = plan_device_steps(st, (int)env.pending.size(), env.coalesce, env.step_depth, all);
+    const std::vector<StepPlanPass> plan = plan_device_steps(st, (int)env.pending.size(), step_queue_width(env), env.step_depth, all);
     env.step_cursor = st.cursor;
     // A pass that fails to enqueue takes only ITS OWN requests with it (note_failed_pass): the passes launched before it
     // stay launched, the requests behind it stay queued for the next call.  With enqueue threads nothing fails here.
@@ -467,7 +480,7 @@ DLIMG_API int dlimg_amd_encode_and_mask(dlimg_Environment env, dlimg_ImageView c
                 throw Exception("device-resident images must have their longest side at 1024 pixels");
         }
         std::lock_guard<std::mutex> lock(e.pending_mutex);
-        if (count >= e.coalesce) {
+        if (count >= step_queue_width(e)) {
             // a call that is a batch already runs as it is (behind whatever single requests were waiting)
             flush_device_steps(e, true);
             std::vector<EnvironmentImpl::PendingStep> steps(count);
@@ -536,10 +549,10 @@ DLIMG_API int dlimg_amd_queue_config(dlimg_Environment env, int* out) {
     return guarded([&] {
         DLIMG_ASSERT(out != nullptr);
         EnvironmentImpl& e = impl(env);
-        out[0] = e.coalesce;
+        out[0] = step_queue_width(e);
         out[1] = e.step_depth;
         out[2] = e.lane_count(0);
-        out[3] = std::max(1, e.effective_lane_count(0));
+        out[3] = step_queue_lanes(e);
         LaneBoard const* board = e.lane(0, 0).board();
         out[4] = board ? (int)std::min<long>(board->passes(), 0x7fffffff) : 0;
         out[5] = board ? (int)std::min<long>(board->alone_passes(), 0x7fffffff) : 0;

@@ -273,7 +273,7 @@ def test_a_synchronous_caller_is_recognised_as_alone_and_concurrent_callers_are_
 @pytest.mark.parametrize("workers", ["1", "0"])
 def test_step_queue_with_and_without_enqueue_threads(model_dirs, workers, monkeypatch):
     """dlimg_amd_encode_and_mask with the lanes' own enqueue threads (default) and with the caller enqueueing
-    (DLIMGEDIT_STEP_WORKERS=0): three bursts of single requests (coalesced into passes of two, the odd one dealt out by
+    (DLIMGEDIT_STEP_WORKERS=0): three bursts of single requests (coalesced into passes of the queue's width, the rest dealt out by
     synchronize) and one call that is a batch already; every mask equal to the ABI path's.  A request that is refused up
     front (NULL mask pointer) leaves nothing behind for synchronize to report."""
     from dlimgedit_amd import api
