@@ -417,8 +417,8 @@ def main() -> None:
         if newest and args.model == "vit_b" and B == 1 and dominant:
             doc = json.loads(newest[-1].read_text())
             # the dominant flavour's launches of the timed region: the row of its kernel at the grid it runs with there
-            tag = {"gemm_stats": ("gemm_pp_kernel<0, 2>", "gemm_pp_kernel<0,2>"), "gemm_norm": ("gemm_pp_kernel<0, 1>", "gemm_pp_kernel<0,1>"),
-                   "gemm_norm_gelu": ("gemm_pp_kernel<1, 1>", "gemm_pp_kernel<1,1>")}.get(dominant, ())
+            tag = {"gemm_stats": ("gemm_pp_kernel<0,2>",), "gemm_norm": ("gemm_pp_kernel<0,1>",),
+                   "gemm_norm_gelu": ("gemm_pp_kernel<1,1>",)}.get(dominant, ())
             rows = [(k, v) for k, v in doc.get("by_kernel_and_grid", {}).items() if any(k.startswith(t) for t in tag)]
             if rows:
                 k, v = max(rows, key=lambda kv: kv[1]["launches_in_run"])

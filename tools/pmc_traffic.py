@@ -25,11 +25,17 @@ def group_of(name):
 
 
 def short(name):
-    """kernel name with its template arguments, without the namespace prefix and the argument list"""
+    """kernel name with its template arguments, whichever way the profiler spells it: demangled
+    ('void dlimg::(anonymous namespace)::gemm_pp_kernel<0, 2>(dlimg::k::GemmArgs)') or mangled ('..14gemm_pp_kernelILi0ELi2EEEv..')"""
     import re
-    name = name.split("(")[0]
-    m = re.search(r"(\w+_kernel)(<[^>]*>)?", name)
-    return (m.group(1) + (m.group(2) or "")) if m else name[:48]
+    m = re.search(r"(\w+_kernel)\s*(<[^>]*>)?", name.replace("(anonymous namespace)::", ""))
+    if m and not m.group(1).startswith("_Z"):
+        return m.group(1) + (m.group(2) or "").replace(" ", "")
+    m = re.search(r"N_1\d+([a-z]\w*?_kernel)(I(?:Li\d+E)+E)?", name) or re.search(r"\d+([a-z]\w*?_kernel)(I(?:Li\d+E)+E)?", name)
+    if m:
+        args = re.findall(r"Li(\d+)E", m.group(2) or "")
+        return m.group(1) + ("<" + ",".join(args) + ">" if args else "")
+    return name[:48]
 
 
 def collect(db_path, counter, by_grid=None):
