@@ -552,8 +552,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm16_f16_kernel(k::Gem
 // slot 4t+4.
 constexpr int kPPHalfBytes = 128 * 128;
 constexpr int kPPBufBytes = 4 * kPPHalfBytes;
-constexpr int kPPAuxBytes = 256 * 8 + 2 * 256 * 4 + 256 * 4 * 8;      // rowstat, colvec[2], rowpart [256][4]
+// Auxiliary area behind the operand buffers: rowstat [BM] (mean, rstd), colvec [2][256] (bias, LayerNorm column sums), then
+// EITHER rowpart [BM][4] (EPI_STATS: the waves' 64-column partials) OR the raw row-statistic partials of an EPI_NORM tile as
+// the producer left them, [group][BM] (sum, M2), kPPStatGroups groups at most (ping-pong producers leave 3 / 4 / 5 for
+// ViT-B / L / H; the 128- and 96-column tiles of a pass without other lanes up to 10)
+constexpr int kPPStatGroups = 12;
+constexpr int pp_aux_bytes(int bm) { return bm * 8 + 2 * 256 * 4 + (bm * 4 * 8 > kPPStatGroups * bm * 8 ? bm * 4 * 8 : kPPStatGroups * bm * 8); }
+constexpr int kPPAuxBytes = pp_aux_bytes(256);
 constexpr int kPPLds = 2 * kPPBufBytes + kPPAuxBytes;
+static_assert(kPPLds <= 160 * 1024, "gemm_pp_kernel: LDS");
 
 // L segment's end: fragment reads of this wave have returned, then the workgroup barrier.  One statement with a memory
 // clobber: the compiler moves no LDS access across it.
@@ -603,6 +610,60 @@ DLIMG_DEVICE HiLo4 hilo_split(float4_t v) {
 DLIMG_DEVICE float4_t hilo_load(const half_t* hi, const half_t* lo, size_t offset) {
     return hilo_pack(*reinterpret_cast<const half4_t*>(hi + offset), *reinterpret_cast<const half4_t*>(lo + offset));
 }
+
+// Bias, LayerNorm column sums and the row-statistic partials of a ping-pong tile (r05).  They used to arrive through
+// registers (ColumnVectors / RowStats: loads ahead of the operand DMA, consumed behind it), and hipcc then waits with
+// vmcnt(0) in front of their first use -- register loads and LDS-DMA share the counter but may complete out of order with
+// each other, so it cannot count -- i.e. for EVERY operand request of the prologue, and the merge of the partials ran after
+// that: 5.4 k cycles of prologue against 2.9 k for the same GEMM without the folded LayerNorm, of a ~40 k cycle
+// workgroup.  Now they are DMA requests like the operands (the oldest ones of their wave, so every counted wait of the
+// prologue covers them), land in the auxiliary area as they lie in memory, and the partials are merged -- same
+// arithmetic, same order -- after the K loop, in front of the epilogue, which is the first to need (mean, rstd).
+template <int BM, int EPI>
+struct PPAux {
+    static constexpr int BN = 256;
+    static constexpr int TPR = 512 / BM;                 // threads that share a row in the merge (as RowStats)
+    // piece p of the tile's auxiliary data is requested by wave p % 8: 0 = bias, 1 = column sums, 2 + g * GP + h = rows
+    // 128 h .. of group g's partials (GP pieces of 1 KB per group; a 64-row tile has half a piece per group)
+    static constexpr int GP = BM * 8 > 1024 ? BM * 8 / 1024 : 1;
+    static DLIMG_DEVICE void issue(const k::GemmArgs& a, int m0, int n0, float* colvec, float2_t* raw, int wave, int lane) {
+        if (wave == 0) {
+            if (a.bias) glds16(a.bias + n0 + lane * 4, colvec);
+            else *reinterpret_cast<float4_t*>(colvec + lane * 4) = float4_t{0.f, 0.f, 0.f, 0.f};
+        }
+        if (EPI != EPI_NORM) return;
+        if (wave == 1) glds16(a.ln_colsum + n0 + lane * 4, colvec + BN);
+        const int pieces = a.ln_groups * GP;
+        for (int p = wave; p < pieces + 2; p += 8) {         // (wave-uniform trip count)
+            if (p < 2) continue;
+            const int g = (p - 2) / GP, h = (p - 2) % GP;
+            const float2_t* src = reinterpret_cast<const float2_t*>(a.ln_stats) + (size_t)g * a.M + m0 + h * 128 + lane * 2;
+            if (BM * 8 >= 1024 || lane < BM / 2) glds16(src, raw + g * BM + h * 128);
+        }
+    }
+    // after the K loop: (mean, rstd) of every row of the tile from its partials (Chan et al.; the arithmetic and the
+    // order of RowStats::finish: sums over the groups sub, sub + TPR, ... per thread, then over the TPR threads of a row)
+    static DLIMG_DEVICE void merge(const k::GemmArgs& a, const float2_t* raw, float* rowstat) {
+        if (EPI != EPI_NORM) return;
+        const int r = threadIdx.x / TPR, sub = threadIdx.x % TPR;
+        float s1 = 0.f;
+        for (int g = sub; g < a.ln_groups; g += TPR) s1 += raw[g * BM + r][0];
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) s1 += __shfl_xor(s1, o, 64);
+        const float n_g = (float)(a.K / a.ln_groups), inv_n_g = 1.0f / n_g;
+        const float mean = s1 / (float)a.K;
+        float m2 = 0.f;
+        for (int g = sub; g < a.ln_groups; g += TPR) {
+            const float2_t q = raw[g * BM + r];
+            const float dm = q[0] * inv_n_g - mean;
+            m2 += q[1] + n_g * dm * dm;
+        }
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) m2 += __shfl_xor(m2, o, 64);
+        if (sub == 0) reinterpret_cast<float2_t*>(rowstat)[r] = float2_t{mean, rsqrtf(m2 / (float)a.K + a.ln_eps)};
+        __syncthreads();
+    }
+};
 
 // Epilogue of the ping-pong kernels: the wave's (NI * 16) x 64 part of the tile, rows row_base .. of the workgroup's tile.
 // PRE: the residual of the whole wave tile was requested before the main loop (pre[band][kk]; only where the
@@ -856,14 +917,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(k::GemmArgs a) {
 
     const unsigned long long t_start = DLIMG_STAMPS(a) ? __builtin_amdgcn_s_memtime() : 0ull;
     const unsigned long long r_start = DLIMG_STAMPS(a) ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    ColumnVectors<BM, BN, 512, EPI> column_vectors;
-    RowStats<BM, 512, EPI> row_stats;
-    column_vectors.issue(a, n0);                 // ordinary loads first: they are the oldest entries of the vm counter
-    row_stats.issue(a, m0);
+    PPAux<BM, EPI>::issue(a, m0, n0, colvec, rowpart, wave, lane);      // the oldest requests of their wave
     stage(0, 0); stage(0, 1); stage(0, 2); stage(0, 3);
     if (nk > 1) { stage(1, 2); stage(1, 3); }
-    column_vectors.store(colvec);
-    row_stats.finish(a, rowstat);
     if (nk > 1) wait_dma<4>(); else wait_dma<0>();
     pp_barrier();                                // tile 0 is visible to every wave
     if (wr == 1) pp_barrier();                   // group 1 runs one slot behind group 0
@@ -942,6 +998,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(k::GemmArgs a) {
     const unsigned long long t_loop_end = DLIMG_STAMPS(a) ? __builtin_amdgcn_s_memtime() : 0ull;
     const unsigned long long r_loop_end = DLIMG_STAMPS(a) ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
+    PPAux<BM, EPI>::merge(a, rowpart, rowstat);
     pp_epilogue<8, ACT, EPI>(a, acc, smem, rowstat, colvec, rowpart, m0, n0, wr * 128, wc, wave, lane);
     if (DLIMG_STAMPS(a) && threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the wave's own stores have left
@@ -974,7 +1031,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(k::GemmArgs a) {
 constexpr int pp128_a_bytes(int bm) { return bm * 128; }                  // one A buffer: bm rows x 64 halves
 constexpr int pp128_w_base(int bm) { return 3 * pp128_a_bytes(bm); }      // A buffers first
 constexpr int pp128_operands(int bm) { return 3 * pp128_a_bytes(bm) + 3 * 2 * kPPHalfBytes; }   // 144 KB / 120 KB
-constexpr int pp128_lds(int bm) { return pp128_operands(bm) + bm * 8 + 2 * 256 * 4 + bm * 4 * 8; }
+constexpr int pp128_lds(int bm) { return pp128_operands(bm) + pp_aux_bytes(bm); }
+static_assert(pp128_lds(128) <= 160 * 1024 && pp128_lds(64) <= 160 * 1024, "gemm_pp128_kernel: LDS");
 
 template <int BM, int ACT, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(k::GemmArgs a) {
@@ -1038,15 +1096,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(k::GemmArgs a) {
     const char* w_base = smem + pp128_w_base(BM) + (wc >> 1) * kPPHalfBytes + (wc & 1) * 64 * 128;  // + W buffer + (nh*32 + j*16)*128
     auto frag = [&](const char* p) { return *reinterpret_cast<const half8_t*>(p); };
 
-    ColumnVectors<BM, BN, 512, EPI> column_vectors;
-    RowStats<BM, 512, EPI> row_stats;
-    column_vectors.issue(a, n0);
-    row_stats.issue(a, m0);
+    PPAux<BM, EPI>::issue(a, m0, n0, colvec, rowpart, wave, lane);      // the oldest requests of their wave
     // tiles 0 and 1 (tile t lives in A buffer and W buffer t % 3)
     stage_a(0, 0); stage_w(0, 0, 0); stage_w(0, 0, 1);
     if (nk > 1) { stage_a(1, 1); stage_w(1, 1, 0); stage_w(1, 1, 1); }
-    column_vectors.store(colvec);
-    row_stats.finish(a, rowstat);
     if (nk > 1) wait_dma<LOADS>(); else wait_dma<0>();
     // Stream writers: the residual of the wave's 64 x 64 part (64 registers, which this tile can afford) is requested
     // now and used in the epilogue.  These requests are younger than everything the main loop's counted waits must
@@ -1136,6 +1189,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp128_kernel(k::GemmArgs a) {
     const unsigned long long t_loop_end = DLIMG_STAMPS(a) ? __builtin_amdgcn_s_memtime() : 0ull;
     const unsigned long long r_loop_end = DLIMG_STAMPS(a) ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
+    PPAux<BM, EPI>::merge(a, rowpart, rowstat);
     pp_epilogue<NI, ACT, EPI, PRE>(a, acc, smem, rowstat, colvec, rowpart, m0, n0, wr * (BM / 2), wc, wave, lane, PRE ? rpre : nullptr);
     if (DLIMG_STAMPS(a) && threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1277,6 +1331,7 @@ bool gemm_tile_fits(const GemmArgs& a, int tile) {
     if (tile < 0 || tile >= kNumTiles) return false;
     const TileCfg& t = kTiles[tile];
     if ((a.out_l || a.resid_h) && !(tile >= 9 && tile <= 11)) return false;      // f16-pair stream: ping-pong epilogue only
+    if (tile >= 9 && tile <= 11 && a.ln_stats && a.ln_groups > kPPStatGroups) return false;   // room for the raw partials
     return a.M % t.bm == 0 && a.N % t.bn == 0 && !((a.resid || a.resid_h) && a.resid_mod % t.bm != 0);
 }
 
@@ -1328,7 +1383,7 @@ int gemm_pick_tile(const GemmArgs& a) {
     }
     for (int i = 0; i < kNumTiles; ++i) {
         const TileCfg& t = kTiles[i];
-        if (unit % t.bm || a.N % t.bn || wraps_inside(t.bm)) continue;
+        if (unit % t.bm || a.N % t.bn || wraps_inside(t.bm) || !gemm_tile_fits(a, i)) continue;
         if (i == forced) return i;
         if (shared && forced < 0) {
             // shared GPU: other lanes fill the CUs this launch leaves free, so the only question is operand
