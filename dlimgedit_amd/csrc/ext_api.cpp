@@ -839,7 +839,14 @@ DLIMG_API int dlimg_amd_test_attention(int global, uint16_t const* qkv, float co
             HIP_CHECK(hipStreamSynchronize(own.s));      // the uploads go out of scope below
         } else {
             DLIMG_ASSERT(qkv_bias != nullptr);
-            k::attention_window(dq.get(), db.get(), dh.get(), dw.get(), o.get(), batch, heads, hd, own.s);
+            // the kernel takes the padding values and the tables as f16, as SamModel converts them when it loads the weights
+            const size_t n = (size_t)(2 * span - 1) * hd;
+            DeviceBuffer<half_t> db16((size_t)3 * D), dh16(n), dw16(n);
+            k::cast_f16(db.get(), db16.get(), (size_t)3 * D, own.s);
+            k::cast_f16(dh.get(), dh16.get(), n, own.s);
+            k::cast_f16(dw.get(), dw16.get(), n, own.s);
+            k::attention_window(dq.get(), db16.get(), dh16.get(), dw16.get(), o.get(), batch, heads, hd, own.s);
+            HIP_CHECK(hipStreamSynchronize(own.s));
         }
         HIP_CHECK(hipStreamSynchronize(own.s));
         download(reinterpret_cast<half_t*>(out), o.get(), rows * D);
@@ -1003,14 +1010,15 @@ DLIMG_API int dlimg_amd_bench_attention(int global, int batch, int heads, int hd
         for (auto& v : hrel) v = rnd() * 0.3f;
         Upload<half_t> dq(hq.data(), hq.size());
         Upload<float> db(hb.data(), hb.size()), dh(hrel.data(), nrel), dw(hrel.data(), nrel);
-        DeviceBuffer<half_t> o(rows * D), dh16(nrel), dw16(nrel);
+        DeviceBuffer<half_t> o(rows * D), dh16(nrel), dw16(nrel), db16((size_t)3 * D);
         hipStream_t st;
         HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         k::cast_f16(dh.get(), dh16.get(), nrel, st);
         k::cast_f16(dw.get(), dw16.get(), nrel, st);
+        k::cast_f16(db.get(), db16.get(), (size_t)3 * D, st);
         auto launch = [&] {
             if (global) k::attention_global(dq.get(), dh16.get(), dw16.get(), o.get(), batch, heads, hd, st);
-            else k::attention_window(dq.get(), db.get(), dh.get(), dw.get(), o.get(), batch, heads, hd, st);
+            else k::attention_window(dq.get(), db16.get(), dh16.get(), dw16.get(), o.get(), batch, heads, hd, st);
         };
         for (int i = 0; i < 3; ++i) launch();
         hipEvent_t e0, e1;
@@ -1056,13 +1064,15 @@ DLIMG_API int dlimg_amd_bench_gemm_stamps(int M, int N, int K, int act, int flav
         Upload<half_t> a(ha.data(), ha.size()), w(hw.data(), hw.size());
         DeviceBuffer<half_t> o((size_t)M * N);
         DeviceBuffer<float> o32, colsum, bias, stats;
+        DeviceBuffer<half_t> pair_in, pair_out;
         k::GemmArgs g;
         g.A = a.get(); g.lda = K; g.W = w.get(); g.ldw = K; g.out_h = o.get(); g.ldc16 = N;
         g.M = M; g.N = N; g.K = K; g.act = act; g.tile = tile; g.shared_gpu = shared != 0;
         apply_forced_tile(g);
         // flavour 0: f16 output only; 1: LayerNorm folded in; 2: residual-stream writer (bias + fp32 residual in
-        // place); 3: the same plus the f16 copy of the stream and its row statistics; 4: f16 output with bias
-        DLIMG_ASSERT(flavour >= 0 && flavour <= 4);
+        // place); 3: the same plus the f16 copy of the stream and its row statistics; 4: f16 output with bias;
+        // 5: the encoder's stream writer (bias + the stream as an f16 pair in, pair out, row statistics); 6: 5 without statistics
+        DLIMG_ASSERT(flavour >= 0 && flavour <= 6);
         std::vector<float> cs(N, 0.5f);
         bias.reserve(N);
         HIP_CHECK(hipMemcpy(bias.get(), cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
@@ -1078,6 +1088,12 @@ DLIMG_API int dlimg_amd_bench_gemm_stamps(int M, int N, int K, int act, int flav
             g.bias = bias.get();
         } else if (flavour == 4) {
             g.bias = bias.get();
+        } else if (flavour >= 5) {
+            pair_in.reserve((size_t)M * N * 2); pair_out.reserve((size_t)M * N);
+            HIP_CHECK(hipMemset(pair_in.get(), 0, (size_t)M * N * 4));
+            g.bias = bias.get(); g.resid_h = pair_in.get(); g.resid_l = pair_in.get() + (size_t)M * N; g.ldrs = N; g.resid_mod = M;
+            g.out_l = pair_out.get();
+            if (flavour == 5) { stats.reserve((size_t)M * 24 * 2); g.stats_out = stats.get(); }
         } else if (flavour >= 2) {
             o32.reserve((size_t)M * N);
             HIP_CHECK(hipMemset(o32.get(), 0, (size_t)M * N * 4));

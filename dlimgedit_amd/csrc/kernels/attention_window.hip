@@ -53,9 +53,9 @@ DLIMG_DEVICE WinSlot win_slot(int slot, int wy, int wx) {
 // head dimension 80 needs 82 KB of LDS per workgroup, so one per CU whatever the registers.
 template <int HD>
 __global__ __launch_bounds__(448, HD == 64 ? 4 : 2) void attention_window_kernel(const half_t* __restrict__ qkv,
-                                                               const float* __restrict__ qkv_bias,
-                                                               const float* __restrict__ rel_h,
-                                                               const float* __restrict__ rel_w,
+                                                               const half_t* __restrict__ qkv_pad,
+                                                               const half_t* __restrict__ rel_h,
+                                                               const half_t* __restrict__ rel_w,
                                                                half_t* __restrict__ out, int heads) {
     constexpr int KS = HD / 16;                 // MFMA k-steps over the head dimension
     constexpr int DT = (HD + 31) / 32;          // 32-wide output tiles over the head dimension
@@ -80,86 +80,89 @@ __global__ __launch_bounds__(448, HD == 64 ? 4 : 2) void attention_window_kernel
     const int wave = wave_id();
     const int hi = lane >> 5, l31 = lane & 31;
 
+    // Every request of the prologue is UNCONDITIONAL (r05): a load under a per-lane condition sits in a branch, and the
+    // compiler drains the memory counter where the branch joins -- the old pad path (K / V of a zero-padding token = the
+    // qkv bias, fetched and converted per lane) did that once per K / V piece in the 9 of 25 windows that have padding,
+    // and the rel-pos tables, requested behind K / V, made the first MFMA wait for the whole window.  Now: a slot that is
+    // not a token reads token 0 of its window (a line the window needs anyway) and is replaced afterwards; the order is
+    // Q, tables, padding values, K / V, so the rel-pos prologue runs while K / V are still on their way.
+    const int token0 = wy * WS * GRID + wx * WS;                     // the window's first token: always real
     // ---- this wave's 32 queries as B-operand fragments ------------------------------------------
     const int qslot = wave * 32 + l31;
     const WinSlot qs = win_slot(qslot, wy, wx);
     const bool q_real = !qs.dummy && !qs.pad;
     half8_t qf[KS];
+    {
+        const half_t* qrow = base + (size_t)(q_real ? qs.token : token0) * ld + head * HD + hi * 8;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        qf[ks] = zero_h8();
-        if (q_real)
-            qf[ks] = *reinterpret_cast<const half8_t*>(base + (size_t)qs.token * ld + head * HD + ks * 16 + hi * 8);
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const half8_t*>(qrow + ks * 16);
     }
-
-    // ---- K and V of the window are requested now and parked in registers: their latency runs behind the
-    // rel-pos prologue below, whose LDS scratch aliases the K / V images.
-    // consecutive threads take consecutive 16-byte chunks of one slot: whole global lines per request
+    half8_t rfh[KS], rfw[KS];
+    {
+        const int rrow = l31 < 2 * WS - 1 ? l31 : 2 * WS - 2;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            rfh[ks] = *reinterpret_cast<const half8_t*>(rel_h + rrow * HD + ks * 16 + hi * 8);
+            rfw[ks] = *reinterpret_cast<const half8_t*>(rel_w + rrow * HD + ks * 16 + hi * 8);
+        }
+    }
+    // ---- K and V of the window: requested now, parked in registers; their latency runs behind the rel-pos prologue
+    // below, whose LDS scratch aliases the K / V images.  Consecutive threads take consecutive 16-byte chunks of one
+    // slot (whole global lines per request).  With head dimension 64 a thread's chunk index is the same for all its
+    // pieces (448 % CHUNKS == 0) and it needs ONE chunk of the padding token's k and v; with 80, one per piece.
     static_assert((SLOTS * CHUNKS) % 448 == 0, "K/V chunks split evenly over the workgroup");
     constexpr int KV_IT = SLOTS * CHUNKS / 448;
+    constexpr int PADS = 448 % CHUNKS == 0 ? 1 : KV_IT;
+    half8_t kpad[PADS], vpad[PADS];
+#pragma unroll
+    for (int it = 0; it < PADS; ++it) {
+        const int ch = (tid + it * 448) % CHUNKS;
+        kpad[it] = *reinterpret_cast<const half8_t*>(qkv_pad + D + head * HD + ch * 8);
+        vpad[it] = *reinterpret_cast<const half8_t*>(qkv_pad + 2 * D + head * HD + ch * 8);
+    }
     half8_t kreg[KV_IT], vreg[KV_IT];
 #pragma unroll
     for (int it = 0; it < KV_IT; ++it) {
         const int idx = tid + it * 448;
-        const int slot = idx / CHUNKS, ch = idx % CHUNKS;
-        const WinSlot ws = win_slot(slot, wy, wx);
-        kreg[it] = zero_h8();
-        vreg[it] = zero_h8();
-        if (!ws.dummy) {
-            if (ws.pad) {
+        const WinSlot ws = win_slot(idx / CHUNKS, wy, wx);
+        const half_t* row = base + (size_t)((ws.dummy || ws.pad) ? token0 : ws.token) * ld + head * HD + (idx % CHUNKS) * 8;
+        kreg[it] = *reinterpret_cast<const half8_t*>(row + D);
+        vreg[it] = *reinterpret_cast<const half8_t*>(row + 2 * D);
+    }
+    __builtin_amdgcn_sched_barrier(0);          // every request is out before the first wait (the scheduler otherwise
+                                                // puts the first table's MFMAs in front of the K / V requests)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    kreg[it][e] = (half_t)qkv_bias[D + head * HD + ch * 8 + e];
-                    vreg[it][e] = (half_t)qkv_bias[2 * D + head * HD + ch * 8 + e];
-                }
-            } else {
-                const half_t* row = base + (size_t)ws.token * ld + head * HD + ch * 8;
-                kreg[it] = *reinterpret_cast<const half8_t*>(row + D);
-                vreg[it] = *reinterpret_cast<const half8_t*>(row + 2 * D);
-            }
-        }
+    for (int ks = 0; ks < KS; ++ks) {
+        if (!q_real) qf[ks] = zero_h8();
+        if (l31 >= 2 * WS - 1) { rfh[ks] = zero_h8(); rfw[ks] = zero_h8(); }
     }
 
     // ---- decomposed rel-pos: G[r][i] = rel[r] . q_i  via MFMA, gathered into per-lane registers ----
+    // The scratch is private to the wave and a wave's LDS operations execute in order: no workgroup barrier between the
+    // scatter of one table's products and their gather, only before K / V are written over the scratch.
     float* g = lds_g + wave * 32 * G_STRIDE;
     const int ty_q = qslot >> 4, tx_q = qslot & 15;
     float bh[WS];       // bias / scale from the key's row, index = key ty
     float bw[8];        // bias / scale from the key's column, index e <-> tx = (e&3) + 8*(e>>2) + 4*hi
     {
-        // both tables' fragments are requested before the first MFMA: one memory latency, not two
-        half8_t rfh[KS], rfw[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            rfh[ks] = zero_h8();
-            rfw[ks] = zero_h8();
-            if (l31 < 2 * WS - 1) {
-                const float4_t* rh = reinterpret_cast<const float4_t*>(rel_h + l31 * HD + ks * 16 + hi * 8);
-                const float4_t* rw = reinterpret_cast<const float4_t*>(rel_w + l31 * HD + ks * 16 + hi * 8);
-                const float4_t h0 = rh[0], h1 = rh[1], w0 = rw[0], w1 = rw[1];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    rfh[ks][e] = (half_t)h0[e];
-                    rfh[ks][4 + e] = (half_t)h1[e];
-                    rfw[ks][e] = (half_t)w0[e];
-                    rfw[ks][4 + e] = (half_t)w1[e];
-                }
-            }
-        }
         float16_t acc = zero16();
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) acc = mfma32(rfh[ks], qf[ks], acc);
+        float16_t acc_w = zero16();
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc_w = mfma32(rfw[ks], qf[ks], acc_w);
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[l31 * G_STRIDE + acc_row(r, hi)] = acc[r];
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int ky = 0; ky < WS; ++ky) bh[ky] = g[l31 * G_STRIDE + ty_q + (WS - 1) - ky] * sqrtf((float)HD);
-        __syncthreads();
-        acc = zero16();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) acc = mfma32(rfw[ks], qf[ks], acc);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) g[l31 * G_STRIDE + acc_row(r, hi)] = acc[r];
-        __syncthreads();
+        for (int r = 0; r < 16; ++r) g[l31 * G_STRIDE + acc_row(r, hi)] = acc_w[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int tx = (e & 3) + 8 * (e >> 2) + 4 * hi;
@@ -174,8 +177,10 @@ __global__ __launch_bounds__(448, HD == 64 ? 4 : 2) void attention_window_kernel
     for (int it = 0; it < KV_IT; ++it) {
         const int idx = tid + it * 448;
         const int slot = idx / CHUNKS, ch = idx % CHUNKS;
-        *reinterpret_cast<half8_t*>(lds_k + slot * K_STRIDE + ch * 8) = kreg[it];
-        *reinterpret_cast<half8_t*>(lds_v + slot * V_STRIDE + ch * 8) = vreg[it];
+        const WinSlot ws = win_slot(slot, wy, wx);
+        const half8_t kp = kpad[PADS == 1 ? 0 : it], vp = vpad[PADS == 1 ? 0 : it];
+        *reinterpret_cast<half8_t*>(lds_k + slot * K_STRIDE + ch * 8) = ws.dummy ? zero_h8() : ws.pad ? kp : kreg[it];
+        *reinterpret_cast<half8_t*>(lds_v + slot * V_STRIDE + ch * 8) = ws.dummy ? zero_h8() : ws.pad ? vp : vreg[it];
     }
     if (DT * 32 > HD) {         // V columns beyond the head dimension must not hold NaN patterns
         constexpr int PADC = (DT * 32 - HD) / 8;
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(448, HD == 64 ? 4 : 2) void attention_window_kernel
 }
 
 template <int HD>
-void launch_window(const half_t* qkv, const float* bias, const float* rel_h, const float* rel_w, half_t* out, int B,
+void launch_window(const half_t* qkv, const half_t* bias, const half_t* rel_h, const half_t* rel_w, half_t* out, int B,
                    int heads, hipStream_t s) {
     const size_t images = (size_t)SLOTS * (HD + 8) * 2 + (size_t)SLOTS * V_STRIDE * 2;
     const size_t scratch = 7 * 32 * G_STRIDE * 4;
@@ -325,13 +330,14 @@ void launch_window(const half_t* qkv, const float* bias, const float* rel_h, con
 
 namespace k {
 
-void attention_window(const half_t* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w, half_t* out,
+void attention_window(const half_t* qkv, const half_t* qkv_pad, const half_t* rel_h, const half_t* rel_w, half_t* out,
                       int B, int heads, int hd, hipStream_t s) {
     if (B <= 0 || heads <= 0) throw_error("attention_window: empty problem");
-    if (((uintptr_t)qkv | (uintptr_t)out) & 15) throw_error("attention_window: buffers must be 16-byte aligned");
+    if (((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)qkv_pad | (uintptr_t)rel_h | (uintptr_t)rel_w) & 15)
+        throw_error("attention_window: buffers must be 16-byte aligned");
     switch (hd) {
-    case 64: return launch_window<64>(qkv, qkv_bias, rel_h, rel_w, out, B, heads, s);
-    case 80: return launch_window<80>(qkv, qkv_bias, rel_h, rel_w, out, B, heads, s);
+    case 64: return launch_window<64>(qkv, qkv_pad, rel_h, rel_w, out, B, heads, s);
+    case 80: return launch_window<80>(qkv, qkv_pad, rel_h, rel_w, out, B, heads, s);
     default: throw_error("attention_window: head dimension must be 64 or 80");
     }
 }

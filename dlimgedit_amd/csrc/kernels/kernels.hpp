@@ -123,9 +123,9 @@ void cast_f16(const float* in, half_t* out, size_t n, hipStream_t);
 
 // ---- encoder attention -----------------------------------------------------------------------
 // qkv: [B*4096, 3*D] f16 token-major (q | k | v, head-major inside each), out: [B*4096, D] f16.
-// qkv_bias: f32 [3*D] (keys/values of zero-padded window tokens equal the bias).
-// rel_h/rel_w: [2*S-1, hd] with S = 14 (windowed, f32) or 64 (global, f16: converted once when the weights are loaded).
-void attention_window(const half_t* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w,
+// qkv_pad: f16 [3*D], the qkv bias (keys / values of a window's zero-padding tokens equal it).
+// rel_h/rel_w: f16 [2*S-1, hd] with S = 14 (windowed) or 64 (global); converted once when the weights are loaded.
+void attention_window(const half_t* qkv, const half_t* qkv_pad, const half_t* rel_h, const half_t* rel_w,
                       half_t* out, int B, int heads, int hd, hipStream_t);
 // attention_global works in units of log2 and leaves the scaling to whoever produces its operands: the q columns of qkv
 // must arrive multiplied by attention_global_q_scale(hd) = log2(e) / sqrt(hd) and both rel-pos tables by

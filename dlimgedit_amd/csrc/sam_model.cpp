@@ -181,7 +181,10 @@ SamWeights::SamWeights(std::string const& weight_path, int device_index) : devic
         const std::string p = "enc.L" + std::to_string(i);
         L.global = geom_.is_global(i);
         const int span = L.global ? 64 : 14;
-        ld.f32(p + ".qkv.b", {3 * D}, L.qkv_pad);
+        if (!L.global) {
+            HostTensor const& qb = file.get(p + ".qkv.b", {3 * D});
+            ld.f16_host(qb.data, qb.numel(), L.qkv_pad, p + ".qkv.b");
+        }
         // a global block's attention kernel works in units of log2 on pre-scaled operands (kernels.hpp): q rows of the
         // qkv weight and bias times log2(e) / sqrt(hd), rel-pos tables times sqrt(hd); L.qkv_pad (the windowed
         // kernel's padding bias) is not used by global blocks
@@ -196,9 +199,9 @@ SamWeights::SamWeights(std::string const& weight_path, int device_index) : devic
             ld.linear_h(p + ".qkv", 3 * D, D, true, L.qkv, q_rows, q_scale);
             ld.linear_h(p + ".fc1", geom_.mlp_dim, D, true, L.fc1);
         }
+        HostTensor const& rh = file.get(p + ".rel_h", {2 * span - 1, hd});
+        HostTensor const& rw = file.get(p + ".rel_w", {2 * span - 1, hd});
         if (L.global) {
-            HostTensor const& rh = file.get(p + ".rel_h", {2 * span - 1, hd});
-            HostTensor const& rw = file.get(p + ".rel_w", {2 * span - 1, hd});
             std::vector<float> rhs(rh.data, rh.data + rh.numel()), rws(rw.data, rw.data + rw.numel());
             const float rel_scale = k::attention_global_rel_scale(hd);
             for (auto& v : rhs) v *= rel_scale;
@@ -206,8 +209,8 @@ SamWeights::SamWeights(std::string const& weight_path, int device_index) : devic
             ld.f16_host(rhs.data(), rhs.size(), L.rel_h16, p + ".rel_h");
             ld.f16_host(rws.data(), rws.size(), L.rel_w16, p + ".rel_w");
         } else {
-            ld.f32(p + ".rel_h", {2 * span - 1, hd}, L.rel_h);
-            ld.f32(p + ".rel_w", {2 * span - 1, hd}, L.rel_w);
+            ld.f16_host(rh.data, rh.numel(), L.rel_h16, p + ".rel_h");
+            ld.f16_host(rw.data, rw.numel(), L.rel_w16, p + ".rel_w");
         }
         ld.linear_h(p + ".proj", D, D, true, L.proj);
         ld.linear_h(p + ".fc2", D, geom_.mlp_dim, true, L.fc2);
@@ -751,7 +754,7 @@ void SamModel::encode(int batch, float* const* emb_dst) {
         } else {
             const double fl = (double)batch * 25.0 * (4.0 * 196.0 * 196.0 * D + 4.0 * 196.0 * 14.0 * hd * H);
             timed(ST_ATTN_WINDOW, fl, [&] {
-                k::attention_window(qkv_.get(), L.qkv_pad.get(), L.rel_h.get(), L.rel_w.get(), att_.get(), batch, H, hd,
+                k::attention_window(qkv_.get(), L.qkv_pad.get(), L.rel_h16.get(), L.rel_w16.get(), att_.get(), batch, H, hd,
                                     stream_);
             });
         }

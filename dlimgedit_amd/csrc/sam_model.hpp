@@ -49,9 +49,8 @@ struct EncoderLayer {
     bool global = false;
     NormW ln1, ln2;
     LinearH qkv, proj, fc1, fc2;
-    DeviceBuffer<float> qkv_pad;     // q|k|v of a window's zero-padding token = the plain qkv bias
-    DeviceBuffer<float> rel_h, rel_w;         // windowed layers
-    DeviceBuffer<half_t> rel_h16, rel_w16;    // global layers: the attention kernel takes the tables as f16
+    DeviceBuffer<half_t> qkv_pad;    // q|k|v of a window's zero-padding token = the plain qkv bias (windowed layers)
+    DeviceBuffer<half_t> rel_h16, rel_w16;    // the attention kernels take the tables as f16 (global layers: pre-scaled)
 };
 
 struct TokenAttention { LinearF q, k, v, o; };
