@@ -22,7 +22,12 @@
 #include "device_common.hpp"
 #include "kernels.hpp"
 
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <mutex>
+#include <string>
+#include <vector>
 
 namespace dlimg {
 namespace {
@@ -56,7 +61,16 @@ __global__ __launch_bounds__(448, HD == 64 ? 4 : 2) void attention_window_kernel
                                                                const half_t* __restrict__ qkv_pad,
                                                                const half_t* __restrict__ rel_h,
                                                                const half_t* __restrict__ rel_w,
-                                                               half_t* __restrict__ out, int heads) {
+                                                               half_t* __restrict__ out, int heads,
+                                                               unsigned long long* stamps_arg) {
+#ifdef DLIMG_TUNING      // tuning build: s_memtime at the phase boundaries of wave 0, eight values per workgroup
+    unsigned long long* const stamps = stamps_arg;
+#else
+    unsigned long long* const stamps = nullptr;
+#endif
+    unsigned long long tstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto stamp = [&](int i) { if (stamps) tstamp[i] = __builtin_amdgcn_s_memtime(); };
+    stamp(0);
     constexpr int KS = HD / 16;                 // MFMA k-steps over the head dimension
     constexpr int DT = (HD + 31) / 32;          // 32-wide output tiles over the head dimension
     constexpr int K_STRIDE = HD + 8;            // elements; +16 B keeps ds_read_b128 conflict-free
@@ -131,6 +145,7 @@ __global__ __launch_bounds__(448, HD == 64 ? 4 : 2) void attention_window_kernel
     }
     __builtin_amdgcn_sched_barrier(0);          // every request is out before the first wait (the scheduler otherwise
                                                 // puts the first table's MFMAs in front of the K / V requests)
+    stamp(1);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         if (!q_real) qf[ks] = zero_h8();
@@ -171,6 +186,7 @@ __global__ __launch_bounds__(448, HD == 64 ? 4 : 2) void attention_window_kernel
         }
         __syncthreads();        // scratch is dead; K / V images may be written over it
     }
+    stamp(2);
 
     // ---- K and V (both row-major, padded rows) of the whole window: registers -> LDS ------------------
 #pragma unroll
@@ -188,6 +204,7 @@ __global__ __launch_bounds__(448, HD == 64 ? 4 : 2) void attention_window_kernel
             *reinterpret_cast<half8_t*>(lds_v + (idx / PADC) * V_STRIDE + HD + (idx % PADC) * 8) = zero_h8();
     }
     __syncthreads();
+    stamp(3);
 
     const float scale = rsqrtf((float)HD);
 
@@ -230,6 +247,7 @@ __global__ __launch_bounds__(448, HD == 64 ? 4 : 2) void attention_window_kernel
         __builtin_amdgcn_sched_barrier(0);
     }
     m = fmaxf(m, swap_halves(m));
+    stamp(4);
     const float c = scale * 1.44269504088896341f;
     const float mc = -m * c;
     // The second pass must really recompute: seen through, the compiler keeps the 112 scores of the first pass alive
@@ -279,11 +297,13 @@ __global__ __launch_bounds__(448, HD == 64 ? 4 : 2) void attention_window_kernel
     }
     l += swap_halves(l);
     const float inv_l = 1.0f / l;
+    stamp(5);
 
     // ---- store.  O^T[d][query]: lane = query, registers = 4-runs of d.  Written straight from here a store
     // instruction would touch 32 rows with 8 bytes each; instead the wave's 32 x HD block goes through an LDS slab (the
     // K image is dead once every wave has left the loop above) and leaves as whole rows, 16 bytes per lane.
     __syncthreads();
+    stamp(6);
     constexpr int ROWB = HD * 2 + 16;                    // slab row in bytes (padded: the 8-byte writes of a wave spread over the banks)
     static_assert(7 * 32 * ROWB <= SLOTS * K_STRIDE * 2, "output slabs must fit in the K image");
     char* slab = smem + wave * 32 * ROWB;
@@ -312,6 +332,12 @@ __global__ __launch_bounds__(448, HD == 64 ? 4 : 2) void attention_window_kernel
             }
         }
     }
+    if (stamps && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tstamp[7] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) stamps[(size_t)blockIdx.x * 8 + i] = tstamp[i];
+    }
 }
 
 template <int HD>
@@ -322,8 +348,42 @@ void launch_window(const half_t* qkv, const half_t* bias, const half_t* rel_h, c
     const size_t lds = images > scratch ? images : scratch;
     static k::LdsOptIn opt_in;       // one per template instance, state per device; lanes and replicas launch concurrently
     opt_in.ensure((const void*)attention_window_kernel<HD>, lds, "attention_window: the device refuses the kernel's LDS size");
+    unsigned long long* stamps = nullptr;
+#ifdef DLIMG_TUNING      // DLIMGEDIT_WINDOW_STAMPS=1: per-phase cycles of every launch (median over the workgroups) on stderr
+    static const bool want = std::getenv("DLIMGEDIT_WINDOW_STAMPS") != nullptr;
+    static unsigned long long* buf = nullptr;
+    const int wgs = B * NW * NW * heads;
+    if (want) {
+        if (!buf) (void)hipMalloc(&buf, (size_t)64 * NW * NW * 64 * 8 * sizeof(unsigned long long));
+        if (wgs <= 64 * NW * NW * 64) stamps = buf;
+    }
+#endif
     hipLaunchKernelGGL(attention_window_kernel<HD>, dim3(B * NW * NW * heads), dim3(448), lds, s, qkv, bias, rel_h,
-                       rel_w, out, heads);
+                       rel_w, out, heads, stamps);
+#ifdef DLIMG_TUNING
+    if (stamps) {
+        static int launches = 0;
+        if (++launches % 50 == 0) {
+            (void)hipStreamSynchronize(s);
+            std::vector<unsigned long long> h((size_t)wgs * 8);
+            (void)hipMemcpy(h.data(), stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            static const char* names[7] = {"requests", "rel-pos", "K/V->LDS", "pass 1", "pass 2", "barrier", "store"};
+            std::string line = "[window stamps] " + std::to_string(wgs) + " workgroups, median cycles:";
+            for (int p = 0; p < 7; ++p) {
+                std::vector<unsigned long long> d(wgs);
+                for (int w = 0; w < wgs; ++w) d[w] = h[(size_t)w * 8 + p + 1] - h[(size_t)w * 8 + p];
+                std::nth_element(d.begin(), d.begin() + wgs / 2, d.end());
+                line += std::string(" ") + names[p] + " " + std::to_string(d[wgs / 2]);
+            }
+            std::vector<unsigned long long> d(wgs);
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (int w = 0; w < wgs; ++w) { d[w] = h[(size_t)w * 8 + 7] - h[(size_t)w * 8]; t0 = std::min(t0, h[(size_t)w * 8]); t1 = std::max(t1, h[(size_t)w * 8 + 7]); }
+            std::nth_element(d.begin(), d.begin() + wgs / 2, d.end());
+            line += " | whole " + std::to_string(d[wgs / 2]) + " | first start to last end " + std::to_string(t1 - t0);
+            fprintf(stderr, "%s\n", line.c_str());
+        }
+    }
+#endif
 }
 
 }  // namespace

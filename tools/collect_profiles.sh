@@ -20,9 +20,8 @@ FLOP=$(python3 -c "import sys; sys.path.insert(0, '$R'); from dlimgedit_amd.sam_
 # the same trace of the timed region alone (bursts of 20 requests + synchronize): block structure is unambiguous there
 DLIMGEDIT_SAM_MODEL=$MODEL timeout -k 10 250 rocprofv3 --kernel-trace -d $O/ktb -o ktb -- python3 $R/tools/burst_trace.py 20 8 > $O/burst.log 2>&1 && echo burst ok
 { echo "# rocprofv3 --kernel-trace of tools/burst_trace.py 20 8 ($MODEL): the timed region of bench.py (20 requests + synchronize)."
-  echo "# NOTE: under rocprofv3 on this pool the execution lanes' passes run ONE AFTER ANOTHER (see the per-lane pass starts"
-  echo "# below; the r03 library behaves the same): this is the profiler's regime, not the overlapped one 'value' is measured in."
-  echo "# The overlapped regime's own clocks are in the bench line: roofline.under_lanes (HIP events on the lanes' streams)."
+  echo "# Whether the lanes overlap under the profiler shows in the per-lane pass starts below and in the burst rate against"
+  echo "# the unprofiled 'value'; the overlapped regime's own clocks are in the bench line (roofline.under_lanes, HIP events)."
   grep "images/s" $O/burst.log
   python3 $R/tools/trace_lanes.py $O/ktb/ktb_results.db 2>&1 | tail -5
   python3 $R/tools/lanes_summary.py $O/ktb/ktb_results.db 20 $FLOP; } > $S/lanes_summary.txt 2>&1

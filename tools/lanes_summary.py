@@ -39,28 +39,25 @@ blocks.append(cur)
 
 
 def describe(b):
-    pre = sum(1 for r in b if "preprocess" in r[3])
+    # images of a block: the pre-processing kernel runs 512 workgroups per image, whatever the step queue made of the requests
+    pre = sum(int(r[2]) // 512 for r in b if "preprocess" in r[3])
     lanes = len({r[5] for r in b})
     return len(b), (max(r[1] for r in b) - b[0][0]) / 1e3, pre, lanes
 
 
-# the timed repeats of bench.py: blocks of `images_per_block` images (two per pass: images / 2 pre-processing launches) that
-# ran on several lanes; the single-lane profiled repeat has one lane, warm-up and the per-stage rates have other sizes
-want_pre = (images_per_block // 2, images_per_block)
-cand = [b for b in blocks if describe(b)[2] in want_pre and describe(b)[3] >= 3]
+# the timed repeats: blocks that hold exactly `images_per_block` images (warm-up and the per-stage rates have other sizes)
+cand = [b for b in blocks if describe(b)[2] == images_per_block]
 if "--blocks" in sys.argv:
     for i, b in enumerate(blocks):
         n, w, pre, lanes = describe(b)
-        print(f"block {i:3d}: {n:5d} kernels {w:9.1f} us, {pre} pre-processing launches, {lanes} lanes")
+        print(f"block {i:3d}: {n:5d} kernels {w:9.1f} us, {pre} images, {lanes} lanes")
 med = statistics.median([describe(b)[1] for b in cand]) if cand else 0.0
 timed = [b for b in cand if describe(b)[1] <= 1.3 * med]
-print(f"{len(blocks)} blocks of kernels in the trace; {len(cand)} look like timed repeats ({images_per_block} images on >= 3 lanes), "
-      f"{len(timed)} of them within 1.3 x the median wall time are used")
+print(f"{len(blocks)} blocks of kernels in the trace; {len(cand)} hold {images_per_block} images (the timed repeats; lanes used: "
+      f"{sorted({describe(b)[3] for b in cand})}), {len(timed)} of them within 1.3 x the median wall time are used")
 if not timed:
-    # what the trace does hold, as a statement (under rocprofv3 the lanes' passes run one after another on this pool: a
-    # "timed repeat" spread over >= 3 lanes may simply not exist in the profiler's regime)
-    print("no block of this trace looks like a timed repeat on >= 3 lanes: the per-kernel table below covers ALL kernels of the "
-          "trace, and the wall-time lines are omitted")
+    print(f"no block of this trace holds {images_per_block} images: the per-kernel table below covers ALL kernels of the trace, and the "
+          "wall-time lines describe arbitrary blocks")
     timed = [b for b in blocks if describe(b)[0] > 0]
     if not timed:
         print("the trace holds no kernels at all")

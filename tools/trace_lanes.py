@@ -18,7 +18,10 @@ for r in rows[1:]:
         cur = []
     cur.append(r)
 blocks.append(cur)
-blocks = [b for b in blocks if len(b) > 500]
+blocks = [b for b in blocks if len(b) > 200]        # a burst of 20 images is >= 5 passes of ~95 launches
+if not blocks:
+    print("no block of more than 200 kernels in this trace")
+    raise SystemExit(0)
 which = int(sys.argv[2]) if len(sys.argv) > 2 else len(blocks) // 2
 blk = blocks[which]
 t0, t1 = blk[0][0], max(r[1] for r in blk)
