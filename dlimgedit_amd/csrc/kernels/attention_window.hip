@@ -231,25 +231,37 @@ __global__ __launch_bounds__(448, HD == 64 ? 4 : 2) void attention_window_kernel
         }
         return t;
     };
-    // Head dimension 80 cannot have two workgroups per CU anyway (82 KB of LDS each): it keeps the scores of the first
-    // pass (112 registers) instead of recomputing them.
-    constexpr bool TWO_PASS = HD == 64;
-    float16_t kept[TWO_PASS ? 1 : 7];
+    // Head dimension 80 cannot have two workgroups per CU anyway (82 KB of LDS each): it keeps the scores of a first
+    // pass (112 registers) and has the exact row maximum.  Head dimension 64 makes ONE pass with a reference maximum per
+    // query that is raised lazily (r05; until then a first pass computed the exact maximum and the second recomputed the
+    // scores: 28 MFMAs, 28 fragment reads and 2.5 k cycles of the workgroup's 21 k): the reference starts as the maximum
+    // of key tile 0 and is raised -- accumulators and row sum rescaled, a wave-uniform branch -- only when a tile's
+    // maximum exceeds it by more than 2^8 in the exponent's units, so probabilities stay below 2^8 (f16: 65504) and
+    // the result o / l is the same quotient.
+#if defined(DLIMG_TUNING) && defined(DLIMG_WINDOW_TWO_PASS)
+    constexpr bool ONLINE = false;
+#else
+    constexpr bool ONLINE = HD == 64;
+#endif
+    constexpr bool TWO_PASS = HD == 64 && !ONLINE;
+    float16_t kept[(TWO_PASS || ONLINE) ? 1 : 7];
     float m = -INFINITY;
-#pragma unroll
-    for (int jt = 0; jt < 7; ++jt) {
-        const float16_t t = score_tile(jt);
-        if (!TWO_PASS) kept[jt] = t;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) m = fmaxf(m, t[r]);
-        // the loops are fully unrolled (bias registers are indexed by the tile); without a fence per tile the scheduler
-        // hoists the fragment reads of all seven tiles to the front and the kernel no longer fits 128 registers
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    m = fmaxf(m, swap_halves(m));
-    stamp(4);
     const float c = scale * 1.44269504088896341f;
-    const float mc = -m * c;
+    if (!ONLINE) {
+#pragma unroll
+        for (int jt = 0; jt < 7; ++jt) {
+            const float16_t t = score_tile(jt);
+            if (!TWO_PASS) kept[jt] = t;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = fmaxf(m, t[r]);
+            // the loops are fully unrolled (bias registers are indexed by the tile); without a fence per tile the scheduler
+            // hoists the fragment reads of all seven tiles to the front and the kernel no longer fits 128 registers
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        m = fmaxf(m, swap_halves(m));
+    }
+    stamp(4);
+    float mc = -m * c;
     // The second pass must really recompute: seen through, the compiler keeps the 112 scores of the first pass alive
     // (common subexpressions) and the kernel is back at 180 registers.  The bias registers are made opaque here, so
     // nothing computed from them before this point is known to equal anything computed after it.
@@ -270,7 +282,28 @@ __global__ __launch_bounds__(448, HD == 64 ? 4 : 2) void attention_window_kernel
     float l = 0.f;
 #pragma unroll
     for (int jt = 0; jt < 7; ++jt) {
-        float16_t t = TWO_PASS ? score_tile(jt) : kept[TWO_PASS ? 0 : jt];
+        float16_t t = (TWO_PASS || ONLINE) ? score_tile(jt) : kept[(TWO_PASS || ONLINE) ? 0 : jt];
+        if (ONLINE) {
+            float tm = fmaxf(fmaxf(t[0], t[1]), t[2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) tm = fmaxf(fmaxf(tm, t[r]), t[r + 1]);
+            tm = fmaxf(tm, t[15]);
+            tm = fmaxf(tm, swap_halves(tm));                    // the query's maximum over the tile's 32 keys, in both halves
+            if (jt == 0) {
+                m = tm;
+                mc = -m * c;
+            } else if (__any(__builtin_fmaf(tm, c, mc) > 8.0f)) {
+                const float m_new = fmaxf(m, tm);
+                const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c);     // 1 where the lane's reference stays
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                l *= alpha;
+                m = m_new;
+                mc = -m * c;
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(t[r], c, mc));

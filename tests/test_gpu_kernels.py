@@ -341,6 +341,41 @@ def test_attention_window_parity(ext, heads, hd):
     assert err < 6e-3, err          # P and V are f16 operands of the second MFMA; output rounded to f16
 
 
+@pytest.mark.gpu
+def test_attention_window_lazy_maximum_rescale(ext):
+    """Head dimension 64 makes one pass with a reference maximum taken from the first key tile: keys late in every window
+    (last window row) aligned with a query and far above the rest force the rescale branch, in windows with and without
+    zero padding; the softmax must come out as the oracle's exact-maximum one."""
+    O = _oracle()
+    heads, hd = 2, 64
+    qkv, bias = _qkv(11, heads, hd)
+    qkv = (qkv.astype(np.float32) * 0.3).astype(np.float16)
+    D = heads * hd
+    for wy in range(5):
+        for wx in range(5):
+            ty, tx = (13, 5) if wy < 4 else (7, 5)          # a real token late in the window's key order
+            gy, gx = wy * 14 + ty, wx * 14 + tx
+            if gx >= 64:
+                gx = wx * 14 + 3
+            q_tok = (wy * 14) * 64 + min(wx * 14 + 2, 63)
+            k_tok = gy * 64 + gx
+            for h in range(heads):
+                qv = qkv[q_tok, h * hd:(h + 1) * hd].astype(np.float32)
+                qkv[k_tok, D + h * hd:D + (h + 1) * hd] = (qv * 60).astype(np.float16)
+    rng = np.random.default_rng(12)
+    rel_h = (0.2 * rng.standard_normal((27, hd))).astype(np.float32)
+    rel_w = (0.2 * rng.standard_normal((27, hd))).astype(np.float32)
+    got = ext.test_attention(False, qkv, bias, rel_h, rel_w, 1, heads, hd).astype(np.float32)
+    ref = O.windowed_attention_from_qkv(qkv.astype(np.float32), bias.astype(np.float16).astype(np.float32),
+                                        rel_h.astype(np.float16).astype(np.float32),
+                                        rel_w.astype(np.float16).astype(np.float32), heads)
+    # the forcing keys really are beyond the lazy threshold (2^8 in the exponent): |q|^2 * 60 / sqrt(hd) * log2(e) >> 8
+    q0 = qkv[0 * 64 + 2, :hd].astype(np.float32)
+    assert float(q0 @ q0) * 60 / 8.0 * 1.4427 > 16
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() < 6e-3, np.abs(got - ref).max()
+
+
 @pytest.mark.parametrize("heads,hd,batch", [(2, 64, 1), (2, 80, 1), (1, 64, 2)])
 def test_attention_global_parity(ext, heads, hd, batch):
     """Flash-style global attention with on-the-fly rel-pos bias against the explicit 4096x4096 softmax."""
