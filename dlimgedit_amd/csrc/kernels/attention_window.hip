@@ -54,10 +54,13 @@ DLIMG_DEVICE WinSlot win_slot(int slot, int wy, int wx) {
     return s;
 }
 
+// row of a key slot in the K image: the window's tokens packed 14 per row; the two dummy slots of a row share its last token's
+DLIMG_DEVICE int k_row(int slot) { const int tx = slot & 15; return (slot >> 4) * WS + (tx < WS ? tx : WS - 1); }
+
 // Registers: head dimension 64 is held to 128 VGPRs (4 waves per SIMD = two 7-wave workgroups per CU; LDS 75 KB each);
 // head dimension 80 needs 82 KB of LDS per workgroup, so one per CU whatever the registers.
 template <int HD>
-__global__ __launch_bounds__(448, HD == 64 ? 4 : 2) void attention_window_kernel(const half_t* __restrict__ qkv,
+__global__ __launch_bounds__(448, 4) void attention_window_kernel(const half_t* __restrict__ qkv,
                                                                const half_t* __restrict__ qkv_pad,
                                                                const half_t* __restrict__ rel_h,
                                                                const half_t* __restrict__ rel_w,
@@ -78,8 +81,8 @@ __global__ __launch_bounds__(448, HD == 64 ? 4 : 2) void attention_window_kernel
     static_assert(DT * 32 <= V_STRIDE, "head dimension tiles must fit the padded V row");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    half_t* lds_k = reinterpret_cast<half_t*>(smem);                              // [224][K_STRIDE]
-    half_t* lds_v = lds_k + SLOTS * K_STRIDE;                                     // [224][V_STRIDE]
+    half_t* lds_k = reinterpret_cast<half_t*>(smem);                              // [196][K_STRIDE]
+    half_t* lds_v = lds_k + WS * WS * K_STRIDE;                                   // [224][V_STRIDE]
     float* lds_g = reinterpret_cast<float*>(smem);          // prologue only: [7 waves][32][G_STRIDE]
 
     const int D = heads * HD;
@@ -122,27 +125,24 @@ __global__ __launch_bounds__(448, HD == 64 ? 4 : 2) void attention_window_kernel
     }
     // ---- K and V of the window: requested now, parked in registers; their latency runs behind the rel-pos prologue
     // below, whose LDS scratch aliases the K / V images.  Consecutive threads take consecutive 16-byte chunks of one
-    // slot (whole global lines per request).  With head dimension 64 a thread's chunk index is the same for all its
-    // pieces (448 % CHUNKS == 0) and it needs ONE chunk of the padding token's k and v; with 80, one per piece.
+    // slot (whole global lines per request).  A zero-padding token's k and v are the qkv bias: qkv_pad is laid out like
+    // a token's row, so such a slot simply reads THAT row.
     static_assert((SLOTS * CHUNKS) % 448 == 0, "K/V chunks split evenly over the workgroup");
     constexpr int KV_IT = SLOTS * CHUNKS / 448;
-    constexpr int PADS = 448 % CHUNKS == 0 ? 1 : KV_IT;
-    half8_t kpad[PADS], vpad[PADS];
-#pragma unroll
-    for (int it = 0; it < PADS; ++it) {
-        const int ch = (tid + it * 448) % CHUNKS;
-        kpad[it] = *reinterpret_cast<const half8_t*>(qkv_pad + D + head * HD + ch * 8);
-        vpad[it] = *reinterpret_cast<const half8_t*>(qkv_pad + 2 * D + head * HD + ch * 8);
-    }
+    // (head dimension 80: the last two of a thread's five pieces are requested after the rel-pos products, when the
+    // tables' fragments are dead -- with all five in front the kernel does not fit 128 registers, and a spilled load
+    // result is a wait for that load in the middle of the request phase: 12 k cycles measured)
+    constexpr int KV_EARLY = HD == 64 ? KV_IT : 3;
     half8_t kreg[KV_IT], vreg[KV_IT];
-#pragma unroll
-    for (int it = 0; it < KV_IT; ++it) {
+    auto request_kv = [&](int it) {
         const int idx = tid + it * 448;
         const WinSlot ws = win_slot(idx / CHUNKS, wy, wx);
-        const half_t* row = base + (size_t)((ws.dummy || ws.pad) ? token0 : ws.token) * ld + head * HD + (idx % CHUNKS) * 8;
+        const half_t* row = (ws.pad ? qkv_pad : base + (size_t)(ws.dummy ? token0 : ws.token) * ld) + head * HD + (idx % CHUNKS) * 8;
         kreg[it] = *reinterpret_cast<const half8_t*>(row + D);
         vreg[it] = *reinterpret_cast<const half8_t*>(row + 2 * D);
-    }
+    };
+#pragma unroll
+    for (int it = 0; it < KV_EARLY; ++it) request_kv(it);
     __builtin_amdgcn_sched_barrier(0);          // every request is out before the first wait (the scheduler otherwise
                                                 // puts the first table's MFMAs in front of the K / V requests)
     stamp(1);
@@ -163,11 +163,18 @@ __global__ __launch_bounds__(448, HD == 64 ? 4 : 2) void attention_window_kernel
         float16_t acc = zero16();
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) acc = mfma32(rfh[ks], qf[ks], acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[l31 * G_STRIDE + acc_row(r, hi)] = acc[r];
+        __builtin_amdgcn_sched_barrier(0);      // (the first table's fragments and products are dead before the second's live)
         float16_t acc_w = zero16();
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) acc_w = mfma32(rfw[ks], qf[ks], acc_w);
+        if (KV_EARLY < KV_IT) {
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) g[l31 * G_STRIDE + acc_row(r, hi)] = acc[r];
+            for (int it = KV_EARLY; it < KV_IT; ++it) request_kv(it);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -193,10 +200,11 @@ __global__ __launch_bounds__(448, HD == 64 ? 4 : 2) void attention_window_kernel
     for (int it = 0; it < KV_IT; ++it) {
         const int idx = tid + it * 448;
         const int slot = idx / CHUNKS, ch = idx % CHUNKS;
-        const WinSlot ws = win_slot(slot, wy, wx);
-        const half8_t kp = kpad[PADS == 1 ? 0 : it], vp = vpad[PADS == 1 ? 0 : it];
-        *reinterpret_cast<half8_t*>(lds_k + slot * K_STRIDE + ch * 8) = ws.dummy ? zero_h8() : ws.pad ? kp : kreg[it];
-        *reinterpret_cast<half8_t*>(lds_v + slot * V_STRIDE + ch * 8) = ws.dummy ? zero_h8() : ws.pad ? vp : vreg[it];
+        const bool dummy = (slot & 15) >= WS;
+        // K image: 196 rows, one per token of the window (a dummy slot's scores are removed by its -inf bias, so
+        // score_tile lets it read the row of its neighbour); V image: all 224 slots, dummies zero (their p is 0)
+        if (!dummy) *reinterpret_cast<half8_t*>(lds_k + k_row(slot) * K_STRIDE + ch * 8) = kreg[it];
+        *reinterpret_cast<half8_t*>(lds_v + slot * V_STRIDE + ch * 8) = dummy ? zero_h8() : vreg[it];
     }
     if (DT * 32 > HD) {         // V columns beyond the head dimension must not hold NaN patterns
         constexpr int PADC = (DT * 32 - HD) / 8;
@@ -226,7 +234,7 @@ __global__ __launch_bounds__(448, HD == 64 ? 4 : 2) void attention_window_kernel
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            half8_t kf = *reinterpret_cast<const half8_t*>(lds_k + (jt * 32 + l31) * K_STRIDE + ks * 16 + hi * 8);
+            half8_t kf = *reinterpret_cast<const half8_t*>(lds_k + k_row(jt * 32 + l31) * K_STRIDE + ks * 16 + hi * 8);
             t = mfma32(kf, qf[ks], t);
         }
         return t;
@@ -241,7 +249,7 @@ __global__ __launch_bounds__(448, HD == 64 ? 4 : 2) void attention_window_kernel
 #if defined(DLIMG_TUNING) && defined(DLIMG_WINDOW_TWO_PASS)
     constexpr bool ONLINE = false;
 #else
-    constexpr bool ONLINE = HD == 64;
+    constexpr bool ONLINE = true;
 #endif
     constexpr bool TWO_PASS = HD == 64 && !ONLINE;
     float16_t kept[(TWO_PASS || ONLINE) ? 1 : 7];
@@ -338,7 +346,7 @@ __global__ __launch_bounds__(448, HD == 64 ? 4 : 2) void attention_window_kernel
     __syncthreads();
     stamp(6);
     constexpr int ROWB = HD * 2 + 16;                    // slab row in bytes (padded: the 8-byte writes of a wave spread over the banks)
-    static_assert(7 * 32 * ROWB <= SLOTS * K_STRIDE * 2, "output slabs must fit in the K image");
+    static_assert(7 * 32 * ROWB <= WS * WS * K_STRIDE * 2 + SLOTS * V_STRIDE * 2, "output slabs must fit in the K / V images");
     char* slab = smem + wave * 32 * ROWB;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -376,7 +384,7 @@ __global__ __launch_bounds__(448, HD == 64 ? 4 : 2) void attention_window_kernel
 template <int HD>
 void launch_window(const half_t* qkv, const half_t* bias, const half_t* rel_h, const half_t* rel_w, half_t* out, int B,
                    int heads, hipStream_t s) {
-    const size_t images = (size_t)SLOTS * (HD + 8) * 2 + (size_t)SLOTS * V_STRIDE * 2;
+    const size_t images = (size_t)WS * WS * (HD + 8) * 2 + (size_t)SLOTS * V_STRIDE * 2;
     const size_t scratch = 7 * 32 * G_STRIDE * 4;
     const size_t lds = images > scratch ? images : scratch;
     static k::LdsOptIn opt_in;       // one per template instance, state per device; lanes and replicas launch concurrently
