@@ -13,12 +13,20 @@
 // Slots are numbered ty*16 + tx (tx = 14, 15 are dummies), which makes 224 = 7*32 slots and lets
 // every MFMA accumulator register know its key's (ty, tx) at compile time.
 // Per wave:   G   = rel_pos . Q^T   (MFMA, 27 rows each for h and w)  -> per-lane bias registers
-//             S^T = K . Q^T + bias/scale   (swapped operands: a lane owns one query column), computed twice:
-//                   once for the exact row maximum, once more tile by tile for the probabilities
+//             S^T = K . Q^T + bias/scale   (swapped operands: a lane owns one query column), ONE pass over the seven
+//                   key tiles with a lazily raised reference maximum (r05)
 //             O^T = V^T . P^T   with the S^T accumulator tile as the B operand as it stands and V^T read
 //                   through ds_read_b64_tr_b16 from V's row-major LDS image; lane = query, so 1 / rowsum is lane-local
 //             O leaves through an LDS slab as whole 128-byte rows.
-// LDS: the rel-pos scratch of the prologue and the output slabs alias the K / V images (75 KB -> 2 workgroups per CU).
+// LDS: K image of the window's 196 tokens + V image of the 224 slots; the rel-pos scratch of the prologue and the output
+// slabs alias them: 71 KB (head dimension 64) / 77.5 KB (80) and <= 128 VGPRs -> two workgroups per CU for both.
+// r05, by the in-kernel phase stamps (tuning build, DLIMGEDIT_WINDOW_STAMPS=1): unconditional requests in the order Q, tables,
+// K / V; wave-local ordering in the prologue; one softmax pass; 49.5 -> 37.5 us per four-image ViT-B launch, ViT-H 96 -> 67.
+// [Measured and NOT kept: a workgroup walking several items with the next item's requests issued before the current
+// item's stores (the cold start of an item is 2.7-4.4 k of its 21 k cycles).  Inside a loop the compiler hoists everything
+// that depends on the thread index alone (~40 registers of addresses and masks, the rel-pos table loads) and, at 128
+// registers, keeps it in scratch memory; with those made opaque per item the kernel still needed 8-26 spilled registers,
+// and ran 20.4 us against 15.6 for one image, 45.7 against 37.5 for four.]
 #include "device_common.hpp"
 #include "kernels.hpp"
 
@@ -57,8 +65,6 @@ DLIMG_DEVICE WinSlot win_slot(int slot, int wy, int wx) {
 // row of a key slot in the K image: the window's tokens packed 14 per row; the two dummy slots of a row share its last token's
 DLIMG_DEVICE int k_row(int slot) { const int tx = slot & 15; return (slot >> 4) * WS + (tx < WS ? tx : WS - 1); }
 
-// Registers: head dimension 64 is held to 128 VGPRs (4 waves per SIMD = two 7-wave workgroups per CU; LDS 75 KB each);
-// head dimension 80 needs 82 KB of LDS per workgroup, so one per CU whatever the registers.
 template <int HD>
 __global__ __launch_bounds__(448, 4) void attention_window_kernel(const half_t* __restrict__ qkv,
                                                                const half_t* __restrict__ qkv_pad,
@@ -217,13 +223,7 @@ __global__ __launch_bounds__(448, 4) void attention_window_kernel(const half_t* 
     const float scale = rsqrtf((float)HD);
 
     // ---- S^T tile jt (32 key slots x this wave's 32 queries) = K . Q^T on top of bias / scale ------------------
-    // Two passes over the seven key tiles instead of keeping all 224 scores of a query in registers (112 VGPRs):
-    //   pass 1   scores -> running maximum, nothing kept
-    //   pass 2   scores again -> p = exp2((s - m) c) -> row sum, f16 -> O^T += V^T . P^T tile by tile
-    // The 28 extra MFMAs are ~0.5 us of matrix time; what they buy is a kernel of <= 128 VGPRs (head dimension 64), i.e.
-    // TWO workgroups per CU: this kernel is a chain of dependent latencies (global loads, LDS round trips, barriers;
-    // 12 us per workgroup for 1 us of MFMA work) and a second resident workgroup runs in the gaps of the first.  One
-    // exact maximum per query, fixed summation order: deterministic, no online rescaling.
+    const half_t* kb = lds_k + k_row(l31) * K_STRIDE + hi * 8;
     auto score_tile = [&](int jt) {
         float16_t t;
 #pragma unroll
@@ -234,7 +234,8 @@ __global__ __launch_bounds__(448, 4) void attention_window_kernel(const half_t* 
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            half8_t kf = *reinterpret_cast<const half8_t*>(lds_k + k_row(jt * 32 + l31) * K_STRIDE + ks * 16 + hi * 8);
+            // row of slot jt * 32 + l31 in the packed K image = k_row(l31) + 28 jt: one base address, the rest is immediates
+            half8_t kf = *reinterpret_cast<const half8_t*>(kb + (jt * 2 * WS) * K_STRIDE + ks * 16);
             t = mfma32(kf, qf[ks], t);
         }
         return t;
@@ -352,11 +353,11 @@ __global__ __launch_bounds__(448, 4) void attention_window_kernel(const half_t* 
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-            const int d0 = dt * 32 + 8 * g4 + 4 * hi;
-            if (d0 < HD) {
+            const int d0 = dt * 32 + 8 * g4;
+            if (d0 < HD) {                      // (compile-time: the lane's + 4 hi stays inside the same 8 columns)
                 const half4_t v = {(half_t)(o[dt][g4 * 4 + 0] * inv_l), (half_t)(o[dt][g4 * 4 + 1] * inv_l),
                                    (half_t)(o[dt][g4 * 4 + 2] * inv_l), (half_t)(o[dt][g4 * 4 + 3] * inv_l)};
-                *reinterpret_cast<half4_t*>(slab + l31 * ROWB + d0 * 2) = v;
+                *reinterpret_cast<half4_t*>(slab + l31 * ROWB + hi * 8 + d0 * 2) = v;
             }
         }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slab is private to the wave: wave-local ordering is enough
