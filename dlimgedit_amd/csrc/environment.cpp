@@ -90,6 +90,21 @@ bool EnvironmentImpl::is_supported(dlimg_Backend backend) noexcept {
     return ok;
 }
 
+// One operation on the device's NULL stream before any stream of this library exists.  Measured (r05, tools/launch_mt.cpp
+// and a probe of slot 4 from four threads): in a process whose first GPU work goes to non-blocking streams, four callers of
+// compute_mask() on four lanes complete 3900 prompts/s together -- barely more than one caller's 3200 -- while in a process
+// that has used the null stream first (any torch host does: its first tensor is filled there) they complete 9700.  What the
+// runtime ties to that first use is not visible from here (queue count and runtime version were ruled out: GPU_MAX_HW_QUEUES
+// 4 / 8, ROCm 7.0 / 7.2 behave alike); the operation costs ~20 us once per device and Environment.
+static void prime_null_stream(int device) {
+    HIP_CHECK(hipSetDevice(device));
+    void* p = nullptr;
+    HIP_CHECK(hipMalloc(&p, 4096));
+    HIP_CHECK(hipMemset(p, 0, 4096));
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipFree(p));
+}
+
 EnvironmentImpl::EnvironmentImpl(dlimg_Options const& options) : backend(options.backend) {
     namespace fs = std::filesystem;
     const char* dir = options.model_directory ? options.model_directory : "models";
@@ -147,6 +162,7 @@ EnvironmentImpl::EnvironmentImpl(dlimg_Options const& options) : backend(options
         if (d < 0 || d >= device_count())
             throw Exception("GPU index " + std::to_string(d) + " (DLIMGEDIT_DEVICE / DLIMGEDIT_DEVICES) is out of range: " +
                             std::to_string(device_count()) + " device(s) visible");
+        prime_null_stream(d);
         auto r = std::make_unique<Replica>();
         r->device = d;
         r->pool = std::make_shared<EmbeddingPool>(d);
