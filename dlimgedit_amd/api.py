@@ -21,11 +21,16 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libdlimgedit.so"
-# tools/ only: the -DDLIMG_TUNING build with ablated kernel variants and in-kernel stamps (python -m dlimgedit_amd.build --tuning)
+# The test and benchmark hooks (include/dlimgedit/dlimgedit_amd_test.h: ext.test_*, ext.bench_*, ext.force_gemm_tile,
+# ext.mask_pieces, ext.plan_steps) are not in the product library: they come from lib/libdlimgedit_test.so, the product's own
+# objects plus csrc/test_hooks.cpp, loaded next to the product the first time a hook is called.
+HOOKS_LIB_PATH = LIB_PATH.with_name("libdlimgedit_test.so")
+# tools/ only: the -DDLIMG_TUNING build with ablated kernel variants and in-kernel stamps (python -m dlimgedit_amd.build --tuning);
+# it exports the hooks too, so one library serves both roles
 if os.environ.get("DLIMGEDIT_TUNING_LIB") == "1":
-    LIB_PATH = LIB_PATH.with_name("libdlimgedit_tuning.so")
+    LIB_PATH = HOOKS_LIB_PATH = LIB_PATH.with_name("libdlimgedit_tuning.so")
 elif os.environ.get("DLIMGEDIT_TUNING_LIB"):          # a copy of a tuning build kept under another name (A/B of several variants)
-    LIB_PATH = LIB_PATH.with_name(os.environ["DLIMGEDIT_TUNING_LIB"])
+    LIB_PATH = HOOKS_LIB_PATH = LIB_PATH.with_name(os.environ["DLIMGEDIT_TUNING_LIB"])
 
 
 class Error(RuntimeError):
@@ -129,6 +134,32 @@ def library() -> C.CDLL:
         _lib.dlimg_init.restype = C.POINTER(_Api)
         _lib.dlimg_init.argtypes = []
     return _lib
+
+
+_hooks_lib = None
+
+
+def hooks_library() -> C.CDLL:
+    """Loads the library that exports the test / benchmark hooks (libdlimgedit_test.so; the tuning library when one is
+    selected).  Raises if it has not been built: there is no fallback, a hook never runs anything but HIP code."""
+    global _hooks_lib
+    if _hooks_lib is None:
+        if HOOKS_LIB_PATH == LIB_PATH:
+            _hooks_lib = library()
+        else:
+            if not HOOKS_LIB_PATH.exists():
+                raise Error(f"{HOOKS_LIB_PATH} not found: build it with `python -m dlimgedit_amd.build`")
+            _hooks_lib = C.CDLL(str(HOOKS_LIB_PATH))
+            _hooks_lib.dlimg_init.restype = C.POINTER(_Api)
+            _hooks_lib.dlimg_init.argtypes = []
+    return _hooks_lib
+
+
+def _check_hook(result: int) -> None:
+    """As _check, with the message of the library the hook lives in (last_error is per library and per thread)."""
+    if result != 0:
+        msg = hooks_library().dlimg_init().contents.last_error()
+        raise Error(msg.decode("utf-8", "replace") if msg else "Unknown error")
 
 
 def api() -> _Api:
@@ -360,21 +391,29 @@ STAGES = ("pre", "gemm", "layernorm", "attention_window", "attention_global", "e
 
 class ext:
     _sigs_done = False
+    _hook_sigs_done = False
+
+    @staticmethod
+    def _apply(lib, sig):
+        for name, (args, res) in sig.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError:           # an older library selected for an A/B (DLIMGEDIT_TUNING_LIB=<file>): the tools
+                continue                     # that need the entry point fail when they call it; tests/test_abi.py checks them all
+            fn.argtypes, fn.restype = args, res
 
     @classmethod
     def _l(cls):
+        """The product library with the argument types of its extension entry points set."""
         lib = library()
         if not cls._sigs_done:
-            vp, ci, cf = C.c_void_p, C.c_int, C.c_float
-            sig = {
+            vp, ci = C.c_void_p, C.c_int
+            cls._apply(lib, {
                 "dlimg_amd_device_count": ([], ci),
                 "dlimg_amd_model_geometry": ([vp, C.POINTER(ci)], ci),
                 "dlimg_amd_get_embedding": ([vp, vp], ci),
                 "dlimg_amd_get_logits": ([vp, C.POINTER(ci), C.POINTER(ci), vp, vp], ci),
                 "dlimg_amd_decoder_state": ([vp, C.POINTER(ci), vp, ci, C.c_char_p, ci], ci),
-                "dlimg_amd_test_mask_pieces": ([ci, C.POINTER(C.c_longlong), C.c_longlong, C.POINTER(C.c_longlong), ci,
-                                               C.POINTER(C.c_longlong), ci, C.POINTER(ci)], ci),
-                "dlimg_amd_test_plan_steps": ([ci, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), ci, ci, ci, ci, C.POINTER(ci), C.POINTER(ci), ci], ci),
                 "dlimg_amd_device_alloc": ([vp, C.c_size_t, C.POINTER(vp)], ci),
                 "dlimg_amd_device_free": ([vp, vp], ci),
                 "dlimg_amd_copy_to_device": ([vp, vp, vp, C.c_size_t], ci),
@@ -390,6 +429,23 @@ class ext:
                                                              C.POINTER(C.c_size_t)], ci),
                 "dlimg_amd_set_profiling": ([vp, ci], ci),
                 "dlimg_amd_take_stage_stats": ([vp, vp, vp, vp], ci),
+                "dlimg_amd_birefnet_prepare_image": ([vp, ci, ci, ci, ci, vp, vp, vp], ci),
+                "dlimg_amd_birefnet_process_mask": ([vp, ci, ci, vp], ci),
+                "dlimg_amd_resize_mask": ([vp, ci, ci, ci, ci, ci, vp], ci),
+            })
+            cls._sigs_done = True
+        return lib
+
+    @classmethod
+    def _h(cls):
+        """The library with the test / benchmark hooks (hooks_library())."""
+        lib = hooks_library()
+        if not cls._hook_sigs_done:
+            vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+            cls._apply(lib, {
+                "dlimg_amd_test_mask_pieces": ([ci, C.POINTER(C.c_longlong), C.c_longlong, C.POINTER(C.c_longlong), ci,
+                                               C.POINTER(C.c_longlong), ci, C.POINTER(ci)], ci),
+                "dlimg_amd_test_plan_steps": ([ci, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), ci, ci, ci, ci, C.POINTER(ci), C.POINTER(ci), ci], ci),
                 "dlimg_amd_test_preprocess": ([vp, ci, ci, ci, ci, vp], ci),
                 "dlimg_amd_test_postprocess": ([vp, ci, vp, ci, ci, vp], ci),
                 "dlimg_amd_test_postprocess_batch": ([vp, ci, ci, ci, vp], ci),
@@ -402,33 +458,33 @@ class ext:
                 "dlimg_amd_test_layernorm": ([vp, vp, vp, cf, ci, ci, ci, vp, vp], ci),
                 "dlimg_amd_test_attention": ([ci, vp, vp, vp, vp, ci, ci, ci, vp], ci),
                 "dlimg_amd_test_resize": ([vp, ci, ci, ci, ci, ci, ci, vp], ci),
-                "dlimg_amd_birefnet_prepare_image": ([vp, ci, ci, ci, ci, vp, vp, vp], ci),
-                "dlimg_amd_birefnet_process_mask": ([vp, ci, ci, vp], ci),
-                "dlimg_amd_resize_mask": ([vp, ci, ci, ci, ci, ci, vp], ci),
                 "dlimg_amd_bench_attention": ([ci, ci, ci, ci, ci, C.POINTER(C.c_double)], ci),
                 "dlimg_amd_bench_prepost": ([ci, ci, ci, C.POINTER(C.c_double), C.POINTER(C.c_double)], ci),
                 "dlimg_amd_bench_gemm": ([ci, ci, ci, ci, ci, ci, C.POINTER(C.c_double)], ci),
                 "dlimg_amd_bench_gemm_streams": ([ci, ci, ci, ci, ci, ci, ci, ci, ci, C.POINTER(C.c_double)], ci),
                 "dlimg_amd_bench_gemm_stamps": ([ci, ci, ci, ci, ci, ci, ci, ci, ci, C.POINTER(C.c_double), vp, ci], ci),
-            }
-            for name, (args, res) in sig.items():
-                try:
-                    fn = getattr(lib, name)
-                except AttributeError:           # an older library selected for an A/B (DLIMGEDIT_TUNING_LIB=<file>): the tools
-                    continue                     # that need the entry point fail when they call it; tests/test_abi.py checks them all
-                fn.argtypes, fn.restype = args, res
-            cls._sigs_done = True
+            })
+            cls._hook_sigs_done = True
         return lib
 
-    EXPORTS = ("dlimg_amd_device_count", "dlimg_amd_model_geometry", "dlimg_amd_get_embedding", "dlimg_amd_get_logits",
-               "dlimg_amd_decoder_state", "dlimg_amd_test_plan_steps", "dlimg_amd_test_lane_worker", "dlimg_amd_test_mask_pieces", "dlimg_amd_device_alloc", "dlimg_amd_device_free", "dlimg_amd_copy_to_device", "dlimg_amd_copy_to_host",
-               "dlimg_amd_encode_and_mask", "dlimg_amd_encode_only", "dlimg_amd_synchronize", "dlimg_amd_lane_count",
-               "dlimg_amd_queue_config", "dlimg_amd_replica_count", "dlimg_amd_segmentation_device", "dlimg_amd_get_segmentation_masks_device",
-               "dlimg_amd_set_profiling",
-               "dlimg_amd_take_stage_stats", "dlimg_amd_test_preprocess", "dlimg_amd_test_postprocess", "dlimg_amd_test_postprocess_batch",
-               "dlimg_amd_test_force_gemm_tile", "dlimg_amd_test_force_gemm_consumer_tile", "dlimg_amd_test_gemm", "dlimg_amd_test_gemm_ln", "dlimg_amd_test_gemm_stream", "dlimg_amd_test_layernorm", "dlimg_amd_test_attention", "dlimg_amd_test_resize",
-               "dlimg_amd_birefnet_prepare_image", "dlimg_amd_birefnet_process_mask", "dlimg_amd_resize_mask",
-               "dlimg_amd_bench_attention", "dlimg_amd_bench_prepost", "dlimg_amd_bench_gemm", "dlimg_amd_bench_gemm_streams", "dlimg_amd_bench_gemm_stamps")
+    # entry points of the product library (include/dlimgedit/dlimgedit_amd.h; csrc/exports.map)
+    EXPORTS = (
+               "dlimg_amd_device_count", "dlimg_amd_model_geometry", "dlimg_amd_get_embedding",
+               "dlimg_amd_get_logits", "dlimg_amd_decoder_state", "dlimg_amd_device_alloc", "dlimg_amd_device_free",
+               "dlimg_amd_copy_to_device", "dlimg_amd_copy_to_host", "dlimg_amd_encode_and_mask",
+               "dlimg_amd_encode_only", "dlimg_amd_synchronize", "dlimg_amd_lane_count", "dlimg_amd_queue_config",
+               "dlimg_amd_replica_count", "dlimg_amd_segmentation_device", "dlimg_amd_get_segmentation_masks_device",
+               "dlimg_amd_set_profiling", "dlimg_amd_take_stage_stats", "dlimg_amd_birefnet_prepare_image",
+               "dlimg_amd_birefnet_process_mask", "dlimg_amd_resize_mask")
+    # hooks of the test / tuning libraries (include/dlimgedit/dlimgedit_amd_test.h)
+    HOOK_EXPORTS = (
+               "dlimg_amd_test_mask_pieces", "dlimg_amd_test_plan_steps", "dlimg_amd_test_preprocess",
+               "dlimg_amd_test_postprocess", "dlimg_amd_test_postprocess_batch", "dlimg_amd_test_force_gemm_tile",
+               "dlimg_amd_test_force_gemm_consumer_tile", "dlimg_amd_test_gemm", "dlimg_amd_test_gemm_ln",
+               "dlimg_amd_test_lane_worker", "dlimg_amd_test_gemm_stream", "dlimg_amd_test_layernorm",
+               "dlimg_amd_test_attention", "dlimg_amd_test_resize", "dlimg_amd_bench_attention",
+               "dlimg_amd_bench_prepost", "dlimg_amd_bench_gemm", "dlimg_amd_bench_gemm_streams",
+               "dlimg_amd_bench_gemm_stamps")
 
     @staticmethod
     def _ptr(a: Optional[np.ndarray]):
@@ -484,9 +540,9 @@ class ext:
         cap = 8 * (n + 1)
         copies = (C.c_longlong * (5 * cap))()
         pieces = C.c_int(0)
-        got = cls._l().dlimg_amd_test_mask_pieces(n, sizes, extra_bytes, ends, 8, copies, cap, C.byref(pieces))
+        got = cls._h().dlimg_amd_test_mask_pieces(n, sizes, extra_bytes, ends, 8, copies, cap, C.byref(pieces))
         if got < 0:
-            _check(1)
+            _check_hook(1)
         return [ends[i] for i in range(pieces.value)], [tuple(copies[5 * k + j] for j in range(5)) for k in range(got)]
 
     @classmethod
@@ -499,9 +555,9 @@ class ext:
         cur = C.c_int(cursor)
         cap = pending + lanes + 1
         out_lane, out_images = (C.c_int * cap)(), (C.c_int * cap)()
-        n = cls._l().dlimg_amd_test_plan_steps(lanes, p, i, C.byref(cur), pending, width, depth, int(all_), out_lane, out_images, cap)
+        n = cls._h().dlimg_amd_test_plan_steps(lanes, p, i, C.byref(cur), pending, width, depth, int(all_), out_lane, out_images, cap)
         if n < 0:
-            _check(1)
+            _check_hook(1)
         return [(out_lane[k], out_images[k]) for k in range(n)], list(p), list(i), cur.value
 
     # -- benchmark path
@@ -602,7 +658,7 @@ class ext:
             pixels = np.ascontiguousarray(pixels)
             stride = w * count(channels)
         out = np.empty((4096, 768), dtype=np.float16)
-        _check(cls._l().dlimg_amd_test_preprocess(pixels.ctypes.data, w, h, stride, int(channels), out.ctypes.data))
+        _check_hook(cls._h().dlimg_amd_test_preprocess(pixels.ctypes.data, w, h, stride, int(channels), out.ctypes.data))
         return out
 
     @classmethod
@@ -610,7 +666,7 @@ class ext:
         planes = np.ascontiguousarray(planes, dtype=np.float32).reshape(-1, 256, 256)
         out = np.empty((out_h, out_w), dtype=np.uint8)
         iou = None if iou is None else np.ascontiguousarray(iou, dtype=np.float32)
-        _check(cls._l().dlimg_amd_test_postprocess(planes.ctypes.data, planes.shape[0], cls._ptr(iou), out_w, out_h,
+        _check_hook(cls._h().dlimg_amd_test_postprocess(planes.ctypes.data, planes.shape[0], cls._ptr(iou), out_w, out_h,
                                                    out.ctypes.data))
         return out
 
@@ -619,15 +675,15 @@ class ext:
         """One launch for all planes (one mask each): the batched form of the post-processing kernel."""
         planes = np.ascontiguousarray(planes, dtype=np.float32).reshape(-1, 256, 256)
         out = np.empty((planes.shape[0], out_h, out_w), dtype=np.uint8)
-        _check(cls._l().dlimg_amd_test_postprocess_batch(planes.ctypes.data, planes.shape[0], out_w, out_h, out.ctypes.data))
+        _check_hook(cls._h().dlimg_amd_test_postprocess_batch(planes.ctypes.data, planes.shape[0], out_w, out_h, out.ctypes.data))
         return out
 
     @classmethod
     def force_gemm_tile(cls, tile: int = -1, consumer_tile: int = -1) -> None:
         """Tile configuration the GEMM test hooks use wherever it fits (-1: the product's own choice); consumer_tile: a
         separate one for the LayerNorm-folded consumer of test_gemm_ln."""
-        _check(cls._l().dlimg_amd_test_force_gemm_tile(int(tile)))
-        _check(cls._l().dlimg_amd_test_force_gemm_consumer_tile(int(consumer_tile)))
+        _check_hook(cls._h().dlimg_amd_test_force_gemm_tile(int(tile)))
+        _check_hook(cls._h().dlimg_amd_test_force_gemm_consumer_tile(int(consumer_tile)))
 
     @classmethod
     def test_gemm(cls, A: np.ndarray, W: np.ndarray, bias=None, resid=None, act: int = 0, want_f16: bool = False):
@@ -639,7 +695,7 @@ class ext:
         resid = None if resid is None else np.ascontiguousarray(resid, dtype=np.float32)
         out32 = np.empty((M, N), dtype=np.float32)
         out16 = np.empty((M, N), dtype=np.float16) if want_f16 else None
-        _check(cls._l().dlimg_amd_test_gemm(M, N, K, A.ctypes.data, W.ctypes.data, cls._ptr(bias), cls._ptr(resid),
+        _check_hook(cls._h().dlimg_amd_test_gemm(M, N, K, A.ctypes.data, W.ctypes.data, cls._ptr(bias), cls._ptr(resid),
                                             0 if resid is None else resid.shape[0], act, out32.ctypes.data,
                                             cls._ptr(out16)))
         return (out32, out16) if want_f16 else out32
@@ -663,7 +719,7 @@ class ext:
         x = np.empty((M, D), dtype=np.float32)
         xh = np.empty((M, D), dtype=np.float16)
         y = np.empty((M, N), dtype=np.float32)
-        _check(cls._l().dlimg_amd_test_gemm_ln(M, D, K1, N, A1.ctypes.data, W1.ctypes.data, cls._ptr(bias1),
+        _check_hook(cls._h().dlimg_amd_test_gemm_ln(M, D, K1, N, A1.ctypes.data, W1.ctypes.data, cls._ptr(bias1),
                                                cls._ptr(resid), wg.ctypes.data, colsum.ctypes.data, b2.ctypes.data,
                                                eps, act, x.ctypes.data, xh.ctypes.data, y.ctypes.data))
         return x, xh, y
@@ -672,9 +728,9 @@ class ext:
     def test_lane_worker(cls, tasks: int, sleep_us: int = 0):
         """Runs the LaneWorker host-logic check; returns the order the tasks ran in (tasks + 1 entries when all ran)."""
         order = np.full(tasks + 1, -1, dtype=np.int32)
-        ran = cls._l().dlimg_amd_test_lane_worker(tasks, sleep_us, order.ctypes.data)
+        ran = cls._h().dlimg_amd_test_lane_worker(tasks, sleep_us, order.ctypes.data)
         if ran < 0:
-            _check(1)
+            _check_hook(1)
         return order[:ran].tolist()
 
     @classmethod
@@ -691,7 +747,7 @@ class ext:
         hi = np.empty((M, D), dtype=np.float16)
         lo = np.empty((M, D), dtype=np.float16) if pair else None
         stats = np.empty((M * 48,), dtype=np.float32)
-        _check(cls._l().dlimg_amd_test_gemm_stream(M, D, K, A.ctypes.data, W.ctypes.data, cls._ptr(bias), cls._ptr(resid_hi),
+        _check_hook(cls._h().dlimg_amd_test_gemm_stream(M, D, K, A.ctypes.data, W.ctypes.data, cls._ptr(bias), cls._ptr(resid_hi),
                                                    cls._ptr(resid_lo), int(pair), cls._ptr(x), hi.ctypes.data,
                                                    cls._ptr(lo), stats.ctypes.data))
         return x, hi, lo, stats
@@ -704,7 +760,7 @@ class ext:
         rows, dim = x.shape
         o32 = np.empty_like(x)
         o16 = np.empty(x.shape, dtype=np.float16)
-        _check(cls._l().dlimg_amd_test_layernorm(x.ctypes.data, w.ctypes.data, b.ctypes.data, eps, rows, dim, act,
+        _check_hook(cls._h().dlimg_amd_test_layernorm(x.ctypes.data, w.ctypes.data, b.ctypes.data, eps, rows, dim, act,
                                                  o32.ctypes.data, o16.ctypes.data))
         return o32, o16
 
@@ -715,7 +771,7 @@ class ext:
         rel_w = np.ascontiguousarray(rel_w, dtype=np.float32)
         qkv_bias = None if qkv_bias is None else np.ascontiguousarray(qkv_bias, dtype=np.float32)
         out = np.empty((batch * 4096, heads * hd), dtype=np.float16)
-        _check(cls._l().dlimg_amd_test_attention(int(is_global), qkv.ctypes.data, cls._ptr(qkv_bias), rel_h.ctypes.data,
+        _check_hook(cls._h().dlimg_amd_test_attention(int(is_global), qkv.ctypes.data, cls._ptr(qkv_bias), rel_h.ctypes.data,
                                                  rel_w.ctypes.data, batch, heads, hd, out.ctypes.data))
         return out
 
@@ -725,7 +781,7 @@ class ext:
         h, w = pixels.shape[:2]
         c = count(channels)
         out = np.empty((out_h, out_w, c), dtype=np.uint8)
-        _check(cls._l().dlimg_amd_test_resize(pixels.ctypes.data, w, h, w * c, int(channels), out_w, out_h,
+        _check_hook(cls._h().dlimg_amd_test_resize(pixels.ctypes.data, w, h, w * c, int(channels), out_w, out_h,
                                               out.ctypes.data))
         return out
 
@@ -764,21 +820,21 @@ class ext:
         """(ms per launch of the pre-processing kernel, of the post-processing kernel) on `batch` images / masks; launches
         rotate over `working_set_mb` MB of distinct inputs and outputs (nothing Infinity-Cache resident)."""
         pre, post = C.c_double(), C.c_double()
-        _check(cls._l().dlimg_amd_bench_prepost(batch, iters, working_set_mb, C.byref(pre), C.byref(post)))
+        _check_hook(cls._h().dlimg_amd_bench_prepost(batch, iters, working_set_mb, C.byref(pre), C.byref(post)))
         return pre.value, post.value
 
     @classmethod
     def bench_attention(cls, is_global: bool, heads: int = 12, hd: int = 64, batch: int = 1, iters: int = 50) -> float:
         """ms per launch of the encoder attention kernel alone, device-resident random data."""
         ms = C.c_double()
-        _check(cls._l().dlimg_amd_bench_attention(int(is_global), batch, heads, hd, iters, C.byref(ms)))
+        _check_hook(cls._h().dlimg_amd_bench_attention(int(is_global), batch, heads, hd, iters, C.byref(ms)))
         return ms.value
 
     @classmethod
     def bench_gemm(cls, M: int, N: int, K: int, act: int = 0, iters: int = 20, flavour: int = 0, tile: int = -1,
                    shared: bool = False, streams: int = 1) -> float:
         ms = C.c_double()
-        _check(cls._l().dlimg_amd_bench_gemm_streams(M, N, K, act, flavour, tile, int(shared), streams, iters,
+        _check_hook(cls._h().dlimg_amd_bench_gemm_streams(M, N, K, act, flavour, tile, int(shared), streams, iters,
                                                      C.byref(ms)))
         return ms.value
 
@@ -788,6 +844,6 @@ class ext:
         """(ms per GEMM, stamps [groups][4] u64: main-loop cycles, main-loop 100 MHz ticks, kernel cycles, kernel ticks)."""
         ms = C.c_double()
         st = np.zeros((groups, 4), np.uint64)
-        _check(cls._l().dlimg_amd_bench_gemm_stamps(M, N, K, act, flavour, tile, 0, streams, iters, C.byref(ms),
+        _check_hook(cls._h().dlimg_amd_bench_gemm_stamps(M, N, K, act, flavour, tile, 0, streams, iters, C.byref(ms),
                                                     st.ctypes.data, groups))
         return ms.value, st

@@ -3,10 +3,16 @@
 In-tree, no cmake: `python -m dlimgedit_amd.build`.  hipcc cross-compiles without a GPU, so this also
 runs in the CPU-only build container.  Objects are cached by source mtime under csrc/_obj/.
 
-`--tuning` builds a SECOND library, lib/libdlimgedit_tuning.so, with -DDLIMG_TUNING: it additionally holds the ablated
-kernel variants and in-kernel cycle stamps the scripts under tools/ use (DLIMGEDIT_*_ABLATE, GemmArgs::stamps).  The
-product library never contains them; tools select the tuning library with DLIMGEDIT_TUNING_LIB=1 (or the file name of a
-copy kept under lib/).  DLIMG_TUNING_DEFS in the environment adds compiler flags to the tuning build only (A/B of variants).
+Three libraries come out of the same sources:
+  lib/libdlimgedit.so         the product: dlimg_init + the extension entry points of include/dlimgedit/dlimgedit_amd.h,
+                              named one by one in csrc/exports.map
+  lib/libdlimgedit_test.so    the product's OBJECTS plus csrc/test_hooks.cpp: additionally exports the dlimg_amd_test_* /
+                              dlimg_amd_bench_* hooks (include/dlimgedit/dlimgedit_amd_test.h) the parity tests and the
+                              kernels-alone timing loops call; built by default next to the product
+  lib/libdlimgedit_tuning.so  `--tuning`: everything compiled with -DDLIMG_TUNING -- additionally the ablated kernel variants
+                              and in-kernel cycle stamps the scripts under tools/ use (DLIMGEDIT_*_ABLATE, GemmArgs::stamps);
+                              tools select it with DLIMGEDIT_TUNING_LIB=1 (or the file name of a copy kept under lib/).
+                              DLIMG_TUNING_DEFS in the environment adds compiler flags to this build only (A/B of variants).
 """
 from __future__ import annotations
 
@@ -23,10 +29,13 @@ CSRC = PKG / "csrc"
 OBJ = CSRC / "_obj"
 OBJ_TUNING = CSRC / "_obj_tuning"
 LIB = PKG / "lib" / "libdlimgedit.so"
+LIB_TEST = PKG / "lib" / "libdlimgedit_test.so"
 LIB_TUNING = PKG / "lib" / "libdlimgedit_tuning.so"
 ARCH = "gfx950"
 SONAME = "libdlimgedit.so.1"
 EXPORTS_MAP = CSRC / "exports.map"
+EXPORTS_TEST_MAP = CSRC / "exports_test.map"
+HOOK_SOURCES = ["test_hooks.cpp"]          # test and tuning libraries only
 
 SOURCES = [
     "kernels/gemm.hip",
@@ -151,6 +160,19 @@ def check_packed_select_erratum(obj: Path) -> dict:
     return counts
 
 
+def _link(out: Path, objs: list, exports: Path, soname: str = "") -> None:
+    cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(out), *map(str, objs),
+           "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined", *([f"-Wl,-soname,{soname}"] if soname else []),
+           f"-Wl,--version-script={exports}", "-ldl", "-lz"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+
+
+def _stale(lib: Path, objs: list, force: bool) -> bool:
+    return force or not lib.exists() or lib.stat().st_mtime < max(o.stat().st_mtime for o in objs)
+
+
 def build(force: bool = False, verbose: bool = False, tuning: bool = False) -> Path:
     (OBJ_TUNING if tuning else OBJ).mkdir(parents=True, exist_ok=True)
     LIB.parent.mkdir(parents=True, exist_ok=True)
@@ -158,33 +180,28 @@ def build(force: bool = False, verbose: bool = False, tuning: bool = False) -> P
     workers = min(6, os.cpu_count() or 1)
     with ThreadPoolExecutor(workers) as ex:
         objs = list(ex.map(lambda s: _compile(s, force, hdr, tuning), SOURCES))
+        hooks = list(ex.map(lambda s: _compile(s, force, hdr, tuning), HOOK_SOURCES))
     if tuning:
-        if force or not LIB_TUNING.exists() or LIB_TUNING.stat().st_mtime < max(o.stat().st_mtime for o in objs):
-            cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB_TUNING), *map(str, objs),
-                   "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined", f"-Wl,--version-script={EXPORTS_MAP}", "-ldl", "-lz"]
-            r = subprocess.run(cmd, capture_output=True, text=True)
-            if r.returncode != 0:
-                raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        if _stale(LIB_TUNING, objs + hooks, force):
+            _link(LIB_TUNING, objs + hooks, EXPORTS_TEST_MAP)
         if verbose:
             print(f"built {LIB_TUNING} ({LIB_TUNING.stat().st_size / 1e6:.1f} MB)")
         return LIB_TUNING
-    if force or not LIB.exists() or LIB.stat().st_mtime < max(o.stat().st_mtime for o in objs):
+    if _stale(LIB, objs, force) or _stale(LIB_TEST, objs + hooks, force):
         for o in objs:                                          # before anything is linked: a refused build leaves no library
             if o.name.startswith("kernels_"):
                 check_packed_select_erratum(o)
-        cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs),
-               "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined", f"-Wl,-soname,{SONAME}",
-               f"-Wl,--version-script={EXPORTS_MAP}", "-ldl", "-lz"]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        if _stale(LIB, objs, force):
+            _link(LIB, objs, EXPORTS_MAP, SONAME)
+        # the test library: the SAME objects (what the parity tests exercise is the product's code) + the hooks
+        _link(LIB_TEST, objs + hooks, EXPORTS_TEST_MAP)
     # consumers linked against the reference's library resolve libdlimgedit.so.1 (SOVERSION 1,
     # /root/reference/src/CMakeLists.txt:20-23)
     link = LIB.parent / SONAME
     if not link.is_symlink() and not link.exists():
         link.symlink_to(LIB.name)
     if verbose:
-        print(f"built {LIB} ({LIB.stat().st_size / 1e6:.1f} MB)")
+        print(f"built {LIB} ({LIB.stat().st_size / 1e6:.1f} MB) and {LIB_TEST.name}")
     return LIB
 
 
