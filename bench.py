@@ -66,19 +66,124 @@ HBM_PEAK_GBS = 8000.0
 HBM_COPY_GBS = 6290.0               # what a float4 copy kernel reaches from HBM (MI355X_MICROARCH.md)
 
 
-def synthetic_image(seed: int, size: int = 1024) -> np.ndarray:
+def synthetic_image(seed: int, width: int = 1024, height: int = 1024) -> np.ndarray:
     rng = np.random.default_rng(1000 + seed)
-    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32)
-    img = np.zeros((size, size, 4), np.uint8)
+    yy, xx = np.mgrid[0:height, 0:width].astype(np.float32)
+    img = np.zeros((height, width, 4), np.uint8)
     for c in range(3):
-        f = np.full((size, size), 128.0, np.float32)
+        f = np.full((height, width), 128.0, np.float32)
         for _ in range(8):
             fx, fy = rng.uniform(0.002, 0.02, 2)
             f += 14.0 * np.sin(xx * fx + yy * fy + rng.uniform(0, 6.28)).astype(np.float32)
-        f += rng.uniform(-8, 8, (size, size)).astype(np.float32)
+        f += rng.uniform(-8, 8, (height, width)).astype(np.float32)
         img[:, :, c] = np.clip(f, 0, 255).astype(np.uint8)
     img[:, :, 3] = 255
     return img
+
+
+DECODER_FLOPS = 3.62e9              # per prompt
+MIXED_SIZES = [(1800, 1200), (1024, 768), (512, 512), (640, 960), (1024, 1024)]     # config 5
+
+
+def gemm_shapes(cfg, images: float) -> dict:
+    """Algorithmic FLOPs and HBM bytes of ONE launch of each encoder GEMM shape over `images` images stacked in M
+    (DESIGN.md section 6): operands once (A [M,K] f16, W [N,K] f16), the residual stream as an f16 pair in and out for the
+    stream writers (4 bytes per element each way; the patch embedding reads the fp32 position embedding of ONE image
+    instead), the f16 result for the LayerNorm-folded consumers, the per-row statistic partials (8 bytes per row and 256
+    columns written by a stream writer, read by a consumer)."""
+    M, D, F, PK = images * 4096.0, cfg.embed_dim, cfg.mlp_dim, 768
+    pair, stats = 4.0 * M * D, 8.0 * M * (D // 256)
+    return {
+        "gemm_patch": {"what": "patch embedding", "flops": 2.0 * M * D * PK, "bytes": 2 * M * PK + 2 * D * PK + 4 * 4096 * D + pair + stats},
+        "gemm_proj": {"what": "proj (K = D)", "flops": 2.0 * M * D * D, "bytes": 2 * M * D + 2 * D * D + 2 * pair + stats},
+        "gemm_fc2": {"what": "fc2 (K = 4 D)", "flops": 2.0 * M * D * F, "bytes": 2 * M * F + 2 * D * F + 2 * pair + stats},
+        "gemm_norm": {"what": "qkv", "flops": 2.0 * M * 3 * D * D, "bytes": 2 * M * D + 2 * 3 * D * D + 2 * M * 3 * D + stats},
+        "gemm_norm_gelu": {"what": "fc1", "flops": 2.0 * M * F * D, "bytes": 2 * M * D + 2 * F * D + 2 * M * F + stats},
+    }
+
+
+def run_for(fn, threads: int, seconds: float) -> float:
+    """Calls fn() -> units from `threads` host threads for `seconds`; returns units per second over all threads."""
+    import threading
+    fn()
+    counts = [0] * threads
+    stop = time.perf_counter() + seconds
+
+    def worker(i):
+        while time.perf_counter() < stop:
+            counts[i] += fn()
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(threads)]
+    t0 = time.perf_counter()
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    return sum(counts) / (time.perf_counter() - t0)
+
+
+def config_legs(api, ext, env, cfg, seconds: float) -> dict:
+    """BASELINE.json configs 3, 4 and 5 at ONE GPU's share, through the drop-in table with host buffers in and out (PCIe and
+    host copies inclusive): slots 13 / 14 with 8 images per call, one caller thread per execution lane.  chip_frac = the
+    FLOPs the GPU did per second (encoder + decoder per prompt) / the dense f16 MFMA peak."""
+    lanes = ext.lane_count(env)
+    enc = cfg.encoder_flops()
+
+    def entry(rate_images, prompts_per_image, what):
+        return {"value": rate_images, "unit": "images/s", "masks_per_s": rate_images * prompts_per_image, "caller_threads": lanes,
+                "chip_frac": rate_images * (enc + prompts_per_image * DECODER_FLOPS) / 1e12 / MFMA_F16_PEAK_TFLOPS, "workload": what}
+
+    views8 = [api.ImageView(synthetic_image(100 + i), api.Channels.rgba) for i in range(8)]
+    pts8 = [api.Point(512, 512)] * 8
+    boxes8 = [api.Region(api.Point(256, 256), api.Point(768, 768))] * 8
+
+    def batch8(points=None, regions=None):
+        segs = api.Segmentation.process_batch(views8, env)
+        api.Segmentation.compute_mask_batch(segs, points=points, regions=regions)
+        for sg in segs:
+            sg.close()
+        return 8
+
+    mixed = [api.ImageView(synthetic_image(10 + i, w, h), api.Channels.rgba) for i, (w, h) in enumerate(MIXED_SIZES)]
+    frac5 = ((.5, .5), (.25, .33), (.75, .2), (.6, .8), (.1, .9))
+
+    def mixed_5prompts():
+        for v in mixed:
+            seg = api.Segmentation.process(v, env)
+            e = seg.extent()
+            api.Segmentation.compute_mask_batch([seg] * 5, points=[api.Point(int(e.width * fx), int(e.height * fy)) for fx, fy in frac5])
+            seg.close()
+        return len(mixed)
+
+    return {
+        "config3_share": entry(run_for(lambda: batch8(points=pts8), lanes, seconds), 1,
+                               f"configs[2] at one GPU's share: {cfg.name}, 8 images per call (slots 13 / 14), one point each"),
+        "config4": entry(run_for(lambda: batch8(regions=boxes8), lanes, seconds), 1,
+                         f"configs[3]: {cfg.name}, batch 8 per call (slots 13 / 14), box prompts"),
+        "config5_share": entry(run_for(mixed_5prompts, lanes, seconds), 5,
+                               f"configs[4] at one GPU's share: {cfg.name}, mixed resolutions {MIXED_SIZES} resized to 1024 on the "
+                               "device (slot 3), 5 point prompts per image on the cached embedding (slot 14)"),
+    }
+
+
+def device_resident_rate(api, ext, env, steps: int, repeats: int) -> dict:
+    """The headline measurement (single-image requests through dlimg_amd_encode_and_mask, everything resident in HBM) for a
+    second model in the same run: median over `repeats` blocks of `steps` steps."""
+    img = synthetic_image(0)
+    p_img, p_mask = ext.device_alloc(env, img.nbytes), ext.device_alloc(env, 1024 * 1024)
+    ext.copy_to_device(env, p_img, img)
+    views, pts = ext.device_views([p_img], 1024, 1024), [api.Point(512, 512)]
+    for _ in range(4):
+        ext.encode_and_mask(env, views, pts, [p_mask])
+    ext.synchronize(env)
+    times = []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ext.encode_and_mask(env, views, pts, [p_mask])
+        ext.synchronize(env)
+        times.append(time.perf_counter() - t0)
+    ext.device_free(env, p_img)
+    ext.device_free(env, p_mask)
+    dt = float(np.median(times))
+    return {"value": steps / dt, "unit": "images/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "repeats": repeats}
 
 
 def spawn_ranks(n: int, argv: list) -> int:
@@ -174,6 +279,8 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the BASELINE configs 3-5 / ViT-H legs (`configs`)")
+    ap.add_argument("--leg-seconds", type=float, default=2.0, help="duration of each leg of `configs`")
     ap.add_argument("--model-dir", default=None, help="existing model directory (default: seeded synthetic weights)")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="one-GPU rehearsal of the N > 1 code path: every rank uses GPU 0 and the collectives run on gloo / CPU "
@@ -275,7 +382,7 @@ def main() -> None:
     for _ in range(args.warmup):
         step()
     sync_all()
-    repeat_s = []
+    repeat_s, own_s = [], []
     for _ in range(max(1, args.repeats)):
         sync_all()                               # barrier + synchronize in front of the timed steps ...
         t0 = time.perf_counter()
@@ -283,12 +390,17 @@ def main() -> None:
             step()
         engine_sync()
         device_synchronize()                     # ... and behind them
-        repeat_s.append(sharding.max_over_ranks(time.perf_counter() - t0, device=coll_dev))
+        own = time.perf_counter() - t0
+        own_s.append(own)
+        repeat_s.append(sharding.max_over_ranks(own, device=coll_dev))
         if world > 1:
             dist.barrier()
     elapsed = float(np.median(repeat_s))
+    # every rank's own clock of the median repeat (N > 1): the MAX above is what `value` uses, this shows who set it
+    median_repeat = int(np.argsort(repeat_s)[len(repeat_s) // 2])
+    per_rank_s = sharding.all_ranks(own_s[median_repeat], device=coll_dev) if world > 1 else [own_s[median_repeat]]
 
-    decoder_flops = 3.62e9                       # per prompt
+    decoder_flops = DECODER_FLOPS                # per prompt
     result = None
     if rank == 0:
         images = world * B * args.steps
@@ -314,6 +426,7 @@ def main() -> None:
             "timed_total_s": float(sum(repeat_s)),
             "repeat_ms": [round(1e3 * t, 3) for t in repeat_s],
             "value_min_max": [images / max(repeat_s), images / min(repeat_s)],
+            "per_rank_value": [B * args.steps / t for t in per_rank_s],
         }
         if stub:
             result["stub_device"] = "no GPU: a host stand-in took the device's place (orchestration rehearsal); the numbers mean nothing"
@@ -387,56 +500,97 @@ def main() -> None:
         st_lanes = profiled(2)
         st = profiled(1)
         g, gl = st["gemm"], st_lanes["gemm"]
-        flavours = {"gemm_stats": "gemm_pp_kernel<ACT_NONE, EPI_STATS> / gemm_pp128_kernel<.., EPI_STATS>: patch, proj, fc2 "
-                                  "(bias + residual in, residual stream as an f16 pair + row statistics out)",
-                    "gemm_norm": "gemm_pp_kernel<ACT_NONE, EPI_NORM>: qkv (LayerNorm folded in, f16 out)",
-                    "gemm_norm_gelu": "gemm_pp_kernel<ACT_GELU, EPI_NORM>: fc1 (LayerNorm folded in, GELU, f16 out)",
-                    "gemm_other": "gemm_f16_kernel: neck 1x1 / 3x3"}
+        # Every GEMM SHAPE of the encoder has its own clock (r06: patch / proj / fc2 share a kernel and a grid but not an
+        # arithmetic intensity -- proj at ViT-B moves a byte per 152 FLOPs, below the ridge of 2500 TFLOP/s : 8 TB/s = 312).
+        flavours = ("gemm_stats", "gemm_norm", "gemm_norm_gelu", "gemm_other", "gemm_patch", "gemm_proj", "gemm_fc2")   # sub-clocks of "gemm"
+        kernels = {"gemm_patch": "gemm_pp_kernel<ACT_NONE, EPI_STATS>: patch embedding (bias + position embedding in, residual "
+                                 "stream as an f16 pair + row statistics out)",
+                   "gemm_proj": "gemm_pp_kernel<ACT_NONE, EPI_STATS>: proj (bias + stream pair in, pair + row statistics out)",
+                   "gemm_fc2": "gemm_pp_kernel<ACT_NONE, EPI_STATS>: fc2 (the same, K = 4 D)",
+                   "gemm_norm": "gemm_pp_kernel<ACT_NONE, EPI_NORM>: qkv (LayerNorm folded in, f16 out)",
+                   "gemm_norm_gelu": "gemm_pp_kernel<ACT_GELU, EPI_NORM>: fc1 (LayerNorm folded in, GELU, f16 out)",
+                   "gemm_other": "gemm_f16_kernel: neck 1x1 / 3x3"}
+        ridge = MFMA_F16_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)          # FLOP per byte where the two roofs meet
 
         def rate(s_):       # TFLOP/s of a stage record
             return s_["work"] / (s_["ms"] * 1e-3) / 1e12 if s_["ms"] > 0 else 0.0
 
         per_kernel = {}
-        for key, what in flavours.items():
+        for key, what in kernels.items():
             a1, al = st[key], st_lanes[key]
             if a1["launches"] == 0:
                 continue
-            per_kernel[key] = {"kernel": what, "launches_per_step": a1["launches"] / args.steps,
-                               "gflop_per_launch": a1["work"] / a1["launches"] / 1e9,
-                               "avg_launch_us": 1e3 * a1["ms"] / a1["launches"], "tflops": rate(a1),
-                               "frac": rate(a1) / MFMA_F16_PEAK_TFLOPS,
-                               "share_of_gemm_time": a1["ms"] / g["ms"] if g["ms"] > 0 else 0.0,
-                               "under_lanes_avg_launch_us": 1e3 * al["ms"] / max(1, al["launches"])}
+            e = {"kernel": what, "launches_per_step": a1["launches"] / args.steps,
+                 "gflop_per_launch": a1["work"] / a1["launches"] / 1e9,
+                 "avg_launch_us": 1e3 * a1["ms"] / a1["launches"], "tflops": rate(a1),
+                 "frac_mfma": rate(a1) / MFMA_F16_PEAK_TFLOPS,
+                 "share_of_gemm_time": a1["ms"] / g["ms"] if g["ms"] > 0 else 0.0,
+                 "under_lanes_avg_launch_us": 1e3 * al["ms"] / max(1, al["launches"])}
+            shape1 = gemm_shapes(cfg, 1.0).get(key)
+            if shape1:
+                # images stacked in an average launch of this shape (whole passes: 4 at ViT-B, 2 at the larger models)
+                images = (a1["work"] / a1["launches"]) / shape1["flops"]
+                sh = gemm_shapes(cfg, images)[key]
+                gbs = sh["bytes"] / (e["avg_launch_us"] * 1e-6) / 1e9
+                e.update({"images_per_launch": images, "algorithmic_mb_per_launch": sh["bytes"] / 1e6, "gbs": gbs,
+                          "frac_hbm": gbs / HBM_PEAK_GBS, "flop_per_byte": sh["flops"] / sh["bytes"],
+                          "bound": "hbm" if sh["flops"] / sh["bytes"] < ridge else "mfma"})
+                e["frac"] = e["frac_hbm"] if e["bound"] == "hbm" else e["frac_mfma"]
+            else:
+                e.update({"bound": "mfma", "frac": e["frac_mfma"]})
+            per_kernel[key] = e
         dominant = max(per_kernel, key=lambda k_: per_kernel[k_]["share_of_gemm_time"]) if per_kernel else None
-        dom = per_kernel.get(dominant, {"tflops": 0.0, "frac": 0.0, "avg_launch_us": 0.0, "gflop_per_launch": 0.0, "kernel": "-"})
+        dom = per_kernel.get(dominant, {"tflops": 0.0, "frac": 0.0, "frac_mfma": 0.0, "avg_launch_us": 0.0, "gflop_per_launch": 0.0,
+                                        "kernel": "-", "bound": "mfma"})
         achieved_alone = rate(g)
-        # HBM-side bytes per GEMM launch are NOT measured in this run: they come from separate rocprofv3 --pmc passes of
-        # this command (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE), kept under profiles/
+        # HBM-side bytes per launch of the dominant kernel are NOT measured in this run: counters cannot be read inside it.
+        # They come from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE doubled as
+        # MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE) -- and only from a profile whose recorded command names this
+        # model and whose table has the dominant kernel AT THE GRID it ran with here; otherwise `traffic` stays null.
         traffic, traffic_source = None, None
-        newest = sorted((ROOT / "profiles").glob("r*_hbm_traffic_pmc.json"))
-        if newest and args.model == "vit_b" and B == 1 and dominant:
+
+        def round_of(path):
+            import re
+            m = re.match(r"r(\d+)_", path.name)
+            return int(m.group(1)) if m else -1
+        newest = sorted((ROOT / "profiles").glob("r*_hbm_traffic_pmc.json"), key=round_of)
+        if newest and B == 1 and dominant and "images_per_launch" in dom:
             doc = json.loads(newest[-1].read_text())
-            # the dominant flavour's launches of the timed region: the row of its kernel at the grid it runs with there
-            tag = {"gemm_stats": ("gemm_pp_kernel<0,2>",), "gemm_norm": ("gemm_pp_kernel<0,1>",),
-                   "gemm_norm_gelu": ("gemm_pp_kernel<1,1>",)}.get(dominant, ())
-            rows = [(k, v) for k, v in doc.get("by_kernel_and_grid", {}).items() if any(k.startswith(t) for t in tag)]
-            if rows:
-                k, v = max(rows, key=lambda kv: kv[1]["launches_in_run"])
-                traffic = v["fetch_bytes_per_launch_corrected_x2"] + v["write_bytes_per_launch"]
-                traffic_source = (f"profiles/{newest[-1].name}, row '{k}': FETCH_SIZE (doubled, gfx950) + WRITE_SIZE per launch from "
-                                  "separate rocprofv3 --pmc passes of this command -- counters cannot be read inside the timed run")
+            tag, ncols = {"gemm_patch": ("gemm_pp_kernel<0,2>", cfg.embed_dim), "gemm_proj": ("gemm_pp_kernel<0,2>", cfg.embed_dim),
+                          "gemm_fc2": ("gemm_pp_kernel<0,2>", cfg.embed_dim), "gemm_norm": ("gemm_pp_kernel<0,1>", 3 * cfg.embed_dim),
+                          "gemm_norm_gelu": ("gemm_pp_kernel<1,1>", cfg.mlp_dim)}.get(dominant, (None, 0))
+            wgs = int(round(dom["images_per_launch"])) * 16 * (ncols // 256)
+            by_shape = doc.get("by_shape", {}).get(dominant)              # r06 profiles: the stream writers told apart
+            row_key = f"{tag} wgs={wgs}"
+            row = by_shape if by_shape and by_shape.get("grid") == wgs else doc.get("by_kernel_and_grid", {}).get(row_key)
+            shared_row = dominant in ("gemm_patch", "gemm_proj", "gemm_fc2") and row is not by_shape
+            import re
+            doc_model = re.search(r"--model (\w+)", doc.get("command", ""))
+            if row and (doc_model.group(1) if doc_model else "vit_b") == args.model and not shared_row:
+                traffic = row["fetch_bytes_per_launch_corrected_x2"] + row["write_bytes_per_launch"]
+                traffic_source = (f"profiles/{newest[-1].name}, row '{dominant if row is by_shape else row_key}': FETCH_SIZE (doubled, "
+                                  "gfx950) + WRITE_SIZE per launch from separate rocprofv3 --pmc passes of this command, committed "
+                                  "with the round -- not measured inside this run")
         step_flops = B * (cfg.encoder_flops() + decoder_flops)
         chip_tflops = step_flops / (result["ms_per_step"] * 1e-3) / 1e12          # per GPU (every rank runs the same step)
         lanes_wall_ms = result["ms_per_step"] * args.steps
+        hbm_bound = dom.get("bound") == "hbm"
         result["roofline"] = {
-            # the dominant kernel = the GEMM flavour with the largest share of GPU time, clocked ALONE on the chip (single
-            # lane): algorithmic FLOPs of its launches / their own dispatch-to-completion time.  This is the number a
-            # per-kernel rocprofv3 table reproduces (profiles/*_kernel_stats_single_lane_by_grid.txt).
+            # the dominant kernel = the GEMM shape with the largest share of GPU time, clocked ALONE on the chip (single
+            # lane): algorithmic FLOPs (or bytes, when its arithmetic intensity puts it under the HBM roof) of its launches /
+            # their own dispatch-to-completion time.  A per-kernel rocprofv3 table reproduces it
+            # (profiles/*_kernel_stats_single_lane_by_grid.txt; the stream writers' shapes: profiles/*_gemm_shapes.txt).
             "kernel": dom["kernel"], "kernel_key": dominant,
-            "bound": "mfma", "achieved": dom["tflops"], "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "bound": dom.get("bound", "mfma"),
+            "achieved": dom.get("gbs", 0.0) if hbm_bound else dom["tflops"],
+            "peak": HBM_PEAK_GBS if hbm_bound else MFMA_F16_PEAK_TFLOPS, "unit": "GB/s" if hbm_bound else "TFLOP/s",
             "frac": dom["frac"], "traffic": traffic, "traffic_source": traffic_source,
+            "bound_rule": f"arithmetic intensity of the launch (algorithmic FLOPs / algorithmic bytes, DESIGN.md section 6) against the "
+                          f"ridge {ridge:.0f} FLOP/B = {MFMA_F16_PEAK_TFLOPS:.0f} TFLOP/s : {HBM_PEAK_GBS / 1e3:.0f} TB/s; every shape "
+                          "carries both fractions in per_kernel",
             "mode": "single lane: every request on lane 0, each kernel alone on the chip; passes of as many images as in the timed region",
             "avg_launch_us": dom["avg_launch_us"], "gflop_per_launch": dom["gflop_per_launch"],
+            "algorithmic_mb_per_launch": dom.get("algorithmic_mb_per_launch"),
             "per_kernel": per_kernel,
             "all_gemm_launches": {"achieved_single_lane": achieved_alone, "frac_single_lane": achieved_alone / MFMA_F16_PEAK_TFLOPS,
                                   "avg_launch_us_single_lane": 1e3 * g["ms"] / max(1, g["launches"]), "launches": g["launches"]},
@@ -509,7 +663,9 @@ def main() -> None:
               "achievable_note": "float4 copy kernel, HBM to HBM (MI355X_MICROARCH.md)",
               "working_set_mb": 768, "clock": "HIP events around 60 back-to-back launches on one stream, each on the next "
               "set of a ring of distinct inputs and outputs (768 MB footprint, nothing Infinity-Cache resident)",
-              "bytes_per_image": {"pre": pre_b, "post": post_b}}
+              "bytes_per_image": {"pre": pre_b, "post": post_b},
+              "library": "lib/libdlimgedit_test.so (dlimg_amd_bench_prepost: the product's kernel objects behind a timing loop "
+                         "that the product library does not export)"}
         for n in (1, 16):
             pre_ms, post_ms = ext.bench_prepost(n, 60, 768)
             e = {"pre_us": 1e3 * pre_ms, "pre_gbs": n * pre_b / (pre_ms * 1e-3) / 1e9,
@@ -582,6 +738,40 @@ def main() -> None:
             "slots_13_14_batch8_one_thread": rate(batch8, 1),
             "slots_13_14_batch8_two_threads": rate(batch8, 2),
         }
+
+    # ---- BASELINE.json configs 3-5 at one GPU's share and the ViT-H model, in the driver's own run: the
+    # headline above is configs[1]; these legs are short (--leg-seconds each) and run after it, rank 0, N = 1 only
+    if rank == 0 and world == 1 and not stub and not args.no_config_legs:
+        legs = {args.model: config_legs(api, ext, env, cfg, args.leg_seconds)}
+        if args.model == "vit_b" and args.model_dir is None:
+            # configs[3] / configs[4] name the ViT-H encoder: a second Environment on seeded synthetic ViT-H weights (this
+            # process writes them once: ~40 s of host time on a fresh box), its device-resident rate measured like `value`
+            # and the same three legs through the drop-in table
+            h_cfg = get_config("vit_h")
+            h_dir = os.path.join(tempfile.gettempdir(), f"dlimgedit_bench_vit_h_{args.seed}_{os.getuid()}")
+            h_target = Path(h_dir) / "segmentation" / W.weight_file_name(h_cfg)
+            t_w = time.perf_counter()
+            if not h_target.exists():
+                h_tmp = h_target.with_suffix(".tmp")
+                W.save_weights(h_tmp, h_cfg, W.synthetic_weights(h_cfg, args.seed))
+                os.replace(h_tmp, h_target)
+            t_w = time.perf_counter() - t_w
+            os.environ["DLIMGEDIT_SAM_MODEL"] = "vit_h"
+            h_env = api.Environment(api.Options(api.Backend.gpu, h_dir))
+            try:
+                resident = device_resident_rate(api, ext, h_env, args.steps, 5)
+                resident["chip_frac"] = resident["value"] * (h_cfg.encoder_flops() + DECODER_FLOPS) / 1e12 / MFMA_F16_PEAK_TFLOPS
+                resident["workload"] = ("SAM vit_h encoder + 1 point prompt, 1 image per step, inputs and masks resident in HBM, through "
+                                        "dlimg_amd_encode_and_mask: the headline's measurement on the ViT-H model")
+                resident["queue"] = ext.queue_config(h_env)
+                legs["vit_h"] = {"device_resident": resident, **config_legs(api, ext, h_env, h_cfg, args.leg_seconds),
+                                 "weights_written_s": t_w}
+            finally:
+                h_env.close()
+                os.environ["DLIMGEDIT_SAM_MODEL"] = args.model
+        result["configs"] = {"note": "BASELINE.json configs[2..4] at ONE GPU's share through the drop-in table (host pixels in, host masks "
+                                     "out: PCIe and host copies inclusive), one caller thread per execution lane; `value` above is "
+                                     "configs[1].  chip_frac = FLOPs done per second / 2500 TFLOP/s", **legs}
 
     # ---- CPU baseline (oracle port) + mask IoU, rank 0, N = 1 only
     if rank == 0 and world == 1 and not stub and not args.no_cpu_baseline:

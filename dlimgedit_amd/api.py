@@ -386,7 +386,7 @@ def segment_objects(img: ImageView, env: Environment) -> np.ndarray:
 # extension entry points (include/dlimgedit/dlimgedit_amd.h)
 
 STAGES = ("pre", "gemm", "layernorm", "attention_window", "attention_global", "encoder_other", "decoder", "post",
-          "gemm_stats", "gemm_norm", "gemm_norm_gelu", "gemm_other")
+          "gemm_stats", "gemm_norm", "gemm_norm_gelu", "gemm_other", "gemm_patch", "gemm_proj", "gemm_fc2")
 
 
 class ext:

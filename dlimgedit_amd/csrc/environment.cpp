@@ -1,5 +1,7 @@
 #include "environment.hpp"
 
+#include <algorithm>
+
 #include <cstdlib>
 #include <cstring>
 #include <filesystem>
@@ -96,13 +98,23 @@ bool EnvironmentImpl::is_supported(dlimg_Backend backend) noexcept {
 // that has used the null stream first (any torch host does: its first tensor is filled there) they complete 9700.  What the
 // runtime ties to that first use is not visible from here (queue count and runtime version were ruled out: GPU_MAX_HW_QUEUES
 // 4 / 8, ROCm 7.0 / 7.2 behave alike); the operation costs ~20 us once per device and Environment.
+// Once per device and PROCESS (r06: it used to run for every Environment and every listing of a device, and waited for the
+// whole device -- a host with work in flight on other streams paid a device-wide synchronisation per Environment): the
+// effect belongs to the process's first use of the null stream, so later environments have nothing to add, and the wait
+// is for the null stream alone.
 static void prime_null_stream(int device) {
+    static std::mutex m;
+    static std::vector<int> primed;
+    std::lock_guard<std::mutex> lock(m);
+    if (std::find(primed.begin(), primed.end(), device) != primed.end()) return;
     HIP_CHECK(hipSetDevice(device));
     void* p = nullptr;
     HIP_CHECK(hipMalloc(&p, 4096));
-    HIP_CHECK(hipMemset(p, 0, 4096));
-    HIP_CHECK(hipDeviceSynchronize());
-    HIP_CHECK(hipFree(p));
+    const hipError_t set = hipMemsetAsync(p, 0, 4096, nullptr);
+    const hipError_t done = set == hipSuccess ? hipStreamSynchronize(nullptr) : set;
+    (void)hipFree(p);
+    HIP_CHECK(done);
+    primed.push_back(device);
 }
 
 EnvironmentImpl::EnvironmentImpl(dlimg_Options const& options) : backend(options.backend) {

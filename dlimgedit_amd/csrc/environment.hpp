@@ -101,7 +101,9 @@ class EnvironmentImpl {
     struct PendingStep { dlimg_ImageView view; int x, y; uint8_t* mask; };
     // A planned pass on its way: handed to the lane's worker (state 0), then on the lane's stream with `done` recorded
     // behind it (1), or failed while being enqueued (2: its requests are counted in dropped_steps)
-    struct StepTicket { std::atomic<int> state{0}; hipEvent_t done = nullptr; };
+    // overflow: the pass's own f16-range report (SamModel::last_pass_flag, taken under the lane's mutex right after the pass
+    // was enqueued); read once `done` has been reached, by whoever retires the ticket -- nobody else looks at that flag
+    struct StepTicket { std::atomic<int> state{0}; hipEvent_t done = nullptr; const volatile int* overflow = nullptr; };
     struct StepPass { std::shared_ptr<StepTicket> ticket; int images; };
     std::mutex pending_mutex;
     std::vector<PendingStep> pending;
@@ -123,6 +125,7 @@ class EnvironmentImpl {
     std::mutex step_error_mutex;                       // the two below: written by the workers
     std::string step_error;                            // first failure of a queued pass since the last synchronize (sticky)
     int dropped_steps = 0;                             // requests that failure took with it
+    int overflowed_steps = 0;                          // requests whose encoder pass left the f16 range (their masks are not valid)
 
   private:
     struct SamLanes {

@@ -164,13 +164,15 @@ namespace {
 // One batched pass of the device-resident hot path over `steps` on lane `lane` of replica 0: pre-process, encode, decode
 // one point prompt per image (single-mask mode), masks to the callers' device buffers.  Enqueues only; returns the
 // event recorded behind the pass.
-hipEvent_t enqueue_device_steps(EnvironmentImpl& env, int lane, EnvironmentImpl::PendingStep const* steps, int count) {
+hipEvent_t enqueue_device_steps(EnvironmentImpl& env, int lane, EnvironmentImpl::PendingStep const* steps, int count,
+                                const volatile int** out_overflow) {
     SamModel& m = env.lane(0, lane);
     std::lock_guard<std::mutex> lock(m.mutex());
     HIP_CHECK(hipSetDevice(m.device()));
     std::vector<dlimg_ImageView> views(count);
     for (int i = 0; i < count; ++i) views[i] = steps[i].view;
     encode_device_images(m, views.data(), count);
+    *out_overflow = m.last_pass_flag();          // THIS pass's report: owned by its ticket from here on
     std::vector<float> coords((size_t)count * 4), labels((size_t)count * 2);
     std::vector<float const*> emb(count);
     std::vector<ResizeLongestSide> rs(count);
@@ -205,7 +207,7 @@ void run_device_steps(EnvironmentImpl& env, int lane, EnvironmentImpl::PendingSt
     if ((int)env.step_passes.size() < env.lane_count(0)) env.step_passes.resize(env.lane_count(0));
     if (!env.use_step_workers) {
         try {
-            ticket->done = enqueue_device_steps(env, lane, steps, count);
+            ticket->done = enqueue_device_steps(env, lane, steps, count, &ticket->overflow);
             ticket->state.store(1, std::memory_order_release);
         } catch (std::exception const& ex) {
             note_failed_pass(env, count, ex.what());
@@ -219,7 +221,7 @@ void run_device_steps(EnvironmentImpl& env, int lane, EnvironmentImpl::PendingSt
     EnvironmentImpl* e = &env;
     env.lane_worker(0, lane).post([e, lane, ticket, owned = std::move(owned)] {
         try {
-            ticket->done = enqueue_device_steps(*e, lane, owned.data(), (int)owned.size());
+            ticket->done = enqueue_device_steps(*e, lane, owned.data(), (int)owned.size(), &ticket->overflow);
             ticket->state.store(1, std::memory_order_release);
         } catch (std::exception const& ex) {
             note_failed_pass(*e, (int)owned.size(), ex.what());
@@ -256,6 +258,12 @@ int retire_device_steps(EnvironmentImpl& env) {
             if (state == 0) break;                                     // still with the lane's enqueue thread
             if (state == 1 && !env.lane(0, (int)l).poll_and_recycle(t.done)) break;
             t.done = nullptr;                                          // recycled (or never recorded: state 2)
+            // the pass has run: its own f16-range report, and only its own (process() / process_batch() callers on the same
+            // lane read theirs themselves; SamModel hands every pass another slot of the lane's ring)
+            if (state == 1 && t.overflow && *t.overflow != 0) {
+                std::lock_guard<std::mutex> errors(env.step_error_mutex);
+                env.overflowed_steps += q.front().images;
+            }
             q.pop_front();
         }
     }
@@ -375,23 +383,21 @@ DLIMG_API int dlimg_amd_synchronize(dlimg_Environment env) {
             e.drain_step_workers();                 // (the workers never take pending_mutex)
         }
         for_each_lane(e, [](SamModel& m) { m.synchronize(); });
-        // an encoder pass whose activations left the f16 range says so (SamModel::last_pass_flag); the asynchronous entry
-        // point learns it here, like every other failure of a queued pass
-        bool overflow = false;
-        for_each_lane(e, [&](SamModel& m) { overflow = m.any_pass_flag_set_and_clear() || overflow; });
+        // an encoder pass whose activations left the f16 range says so in ITS flag, which the pass's ticket owns
+        // (retire_device_steps); the asynchronous entry point learns it here, like every other failure of a queued pass
         std::lock_guard<std::mutex> lock(e.pending_mutex);
         retire_device_steps(e);
         std::lock_guard<std::mutex> errors(e.step_error_mutex);
-        if (overflow && e.step_error.empty())
-            throw Exception("dlimg_amd_encode_and_mask: an image encoder pass produced non-finite values (an activation left "
-                            "the f16 range); the masks of the requests queued since the last synchronize are not valid");
-        if (!e.step_error.empty()) {
-            const std::string msg = "dlimg_amd_encode_and_mask: " + std::to_string(e.dropped_steps) +
-                                    " queued request(s) were dropped because their pass failed: " + e.step_error;
-            e.step_error.clear();
-            e.dropped_steps = 0;
-            throw Exception(msg);
-        }
+        std::string msg;
+        if (!e.step_error.empty())
+            msg = std::to_string(e.dropped_steps) + " queued request(s) were dropped because their pass failed: " + e.step_error;
+        if (e.overflowed_steps > 0)
+            msg += std::string(msg.empty() ? "" : "; ") + std::to_string(e.overflowed_steps) + " request(s) ran in an image encoder "
+                   "pass that produced non-finite values (an activation left the f16 range): their masks are not valid";
+        e.step_error.clear();
+        e.dropped_steps = 0;
+        e.overflowed_steps = 0;
+        if (!msg.empty()) throw Exception("dlimg_amd_encode_and_mask: " + msg);
     });
 }
 

@@ -255,7 +255,7 @@ __global__ __launch_bounds__(512, 2) void attention_global_kernel(const half_t* 
     // (25 requests back to back overflow the 4-bit lgkmcnt and stall the wave ~300 cycles).  Ops 0..AHEAD-1 are
     // requested by the X slot before.
     constexpr int NKOP = 2 * KS, NVOP = 4 * DT, NOPS = NKOP + NVOP;
-#ifdef DLIMG_PP2_AHEAD
+#if defined(DLIMG_TUNING) && defined(DLIMG_PP2_AHEAD)      // operand window depth, A/B in the tuning build only
     constexpr int AHEAD = DLIMG_PP2_AHEAD;
 #else
     constexpr int AHEAD = 4;

@@ -240,13 +240,14 @@ __global__ __launch_bounds__(448, 4) void attention_window_kernel(const half_t* 
         }
         return t;
     };
-    // Head dimension 80 cannot have two workgroups per CU anyway (82 KB of LDS each): it keeps the scores of a first
-    // pass (112 registers) and has the exact row maximum.  Head dimension 64 makes ONE pass with a reference maximum per
-    // query that is raised lazily (r05; until then a first pass computed the exact maximum and the second recomputed the
-    // scores: 28 MFMAs, 28 fragment reads and 2.5 k cycles of the workgroup's 21 k): the reference starts as the maximum
-    // of key tile 0 and is raised -- accumulators and row sum rescaled, a wave-uniform branch -- only when a tile's
-    // maximum exceeds it by more than 2^8 in the exponent's units, so probabilities stay below 2^8 (f16: 65504) and
-    // the result o / l is the same quotient.
+    // ONE pass for both head dimensions (r05), with a reference maximum per query that is raised lazily: the reference
+    // starts as the maximum of key tile 0 and is raised -- accumulators and row sum rescaled, a wave-uniform branch -- only
+    // when a tile's maximum exceeds it by more than 2^8 in the exponent's units, so probabilities stay below 2^8 (f16: 65504)
+    // and the result o / l is the same quotient (tests: test_attention_window_lazy_maximum_rescale forces the branch in
+    // every window at head dimension 64 and 80).  [Until r05 a first pass computed the exact maximum and a second one
+    // recomputed the scores (head dimension 64: 28 MFMAs, 28 fragment reads and 2.5 k cycles of the workgroup's 21 k) or
+    // kept them in 112 registers (head dimension 80, one workgroup per CU); the tuning build still has the two-pass form
+    // for head dimension 64 (-DDLIMG_WINDOW_TWO_PASS).]
 #if defined(DLIMG_TUNING) && defined(DLIMG_WINDOW_TWO_PASS)
     constexpr bool ONLINE = false;
 #else

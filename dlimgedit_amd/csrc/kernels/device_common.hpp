@@ -79,7 +79,7 @@ DLIMG_DEVICE float2_t gelu_pair_erf(float2_t x) {
 // round beyond |x| ~ 11; at 8 the sigmoid is 1 - 1e-12 / e^-27 already); the final product takes the unclamped x.
 // Per value 3.5 packed instructions + v_exp_f32 + v_rcp_f32 against 8.5 + v_rcp_f32 above.
 DLIMG_DEVICE float2_t gelu_pair(float2_t x) {
-#if defined(DLIMG_GELU_ERF)
+#if defined(DLIMG_TUNING) && defined(DLIMG_GELU_ERF)      // A/B of the two forms, tuning build only
     return gelu_pair_erf(x);
 #endif
     constexpr float L2E = 1.44269504088896341f;

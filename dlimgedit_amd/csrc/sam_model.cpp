@@ -413,10 +413,11 @@ void SamModel::flush_events() {
         stats_.ms[p.st] += ms;
         stats_.work[p.st] += p.work;
         stats_.launches[p.st] += 1;
-        if (p.also != ST_COUNT) {
-            stats_.ms[p.also] += ms;
-            stats_.work[p.also] += p.work;
-            stats_.launches[p.also] += 1;
+        for (Stage extra : {p.also, p.shape}) {
+            if (extra == ST_COUNT) continue;
+            stats_.ms[extra] += ms;
+            stats_.work[extra] += p.work;
+            stats_.launches[extra] += 1;
         }
         event_pool_.push_back(p.a);
         event_pool_.push_back(p.b);
@@ -455,7 +456,7 @@ template <typename F> void SamModel::timed(Stage st, double work, F&& launch) {
     if (pending_.size() > 8192) flush_events();
 }
 
-void SamModel::gemm(k::GemmArgs const& args) {
+void SamModel::gemm(k::GemmArgs const& args, Stage shape) {
     k::GemmArgs a = args;
     a.shared_gpu = shared_gpu_;
     a.alone = alone_;
@@ -466,7 +467,7 @@ void SamModel::gemm(k::GemmArgs const& args) {
     }
     // the clock of a GEMM launch is the kernel's own dispatch-to-completion time (events attached to the dispatch)
     const Stage flavour = a.stats_out ? ST_GEMM_STATS : a.ln_stats ? (a.act == k::ACT_GELU ? ST_GEMM_NORM_GELU : ST_GEMM_NORM) : ST_GEMM_OTHER;
-    Pending p{take_event(), take_event(), ST_GEMM, 2.0 * a.M * a.N * a.K, flavour};
+    Pending p{take_event(), take_event(), ST_GEMM, 2.0 * a.M * a.N * a.K, flavour, shape};
     k::gemm(a, stream_, p.a, p.b);
     pending_.push_back(p);
     if (pending_.size() > 8192) flush_events();
@@ -495,15 +496,6 @@ void SamModel::wait_and_recycle(hipEvent_t e) {
         done_pool_.push_back(e);
     }
     HIP_CHECK(err);
-}
-
-bool SamModel::any_pass_flag_set_and_clear() {
-    bool any = false;
-    for (int i = 0; pass_flags_ && i < kPassFlags; ++i) {
-        any = any || pass_flags_[i] != 0;
-        pass_flags_[i] = 0;
-    }
-    return any;
 }
 
 bool SamModel::poll_and_recycle(hipEvent_t e) {
@@ -739,7 +731,7 @@ void SamModel::encode(int batch, float* const* emb_dst) {
     g.A = patches_.get(); g.lda = kPatchK; g.W = W.patch_.w.get(); g.ldw = kPatchK; g.bias = W.patch_.b.get();
     g.resid = W.pos_embed_.get(); g.ldr = D; g.resid_mod = kTokens; g.K = kPatchK;
     writes_stream(g);
-    gemm(g);
+    gemm(g, ST_GEMM_PATCH);
 
     for (EncoderLayer const& L : W.layers_) {
         g = k::GemmArgs{};
@@ -762,7 +754,7 @@ void SamModel::encode(int batch, float* const* emb_dst) {
         g.A = att_.get(); g.lda = D; g.W = L.proj.w.get(); g.ldw = D; g.bias = L.proj.b.get(); g.K = D;
         stream_residual(g);
         writes_stream(g);
-        gemm(g);
+        gemm(g, ST_GEMM_PROJ);
         g = k::GemmArgs{};
         reads_stream(g, L.fc1, L.ln2);
         g.act = k::ACT_GELU; g.out_h = hid_.get(); g.ldc16 = mlp;
@@ -771,7 +763,7 @@ void SamModel::encode(int batch, float* const* emb_dst) {
         g.A = hid_.get(); g.lda = mlp; g.W = L.fc2.w.get(); g.ldw = mlp; g.bias = L.fc2.b.get(); g.K = mlp;
         stream_residual(g);
         writes_stream(g);
-        gemm(g);
+        gemm(g, ST_GEMM_FC2);
     }
 
     // neck: 1x1 conv -> LayerNorm2d -> 3x3 conv (pad 1) -> LayerNorm2d, all channel-last

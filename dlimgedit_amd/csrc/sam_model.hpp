@@ -100,7 +100,11 @@ struct SamWeights {
 // the by-grid table of a kernel trace tells apart): residual-stream writers with row statistics (patch / proj / fc2),
 // LayerNorm-folded consumers without / with GELU (qkv / fc1), everything else (neck).
 enum Stage { ST_PRE = 0, ST_GEMM, ST_LAYERNORM, ST_ATTN_WINDOW, ST_ATTN_GLOBAL, ST_ENC_OTHER, ST_DECODER, ST_POST,
-             ST_GEMM_STATS, ST_GEMM_NORM, ST_GEMM_NORM_GELU, ST_GEMM_OTHER, ST_COUNT };
+             ST_GEMM_STATS, ST_GEMM_NORM, ST_GEMM_NORM_GELU, ST_GEMM_OTHER,
+             // r06: the stream writers (ST_GEMM_STATS) once more by shape -- they share a kernel and a grid, so no profiler
+             // table can tell them apart, and proj (K = D: 152 FLOP per byte at ViT-B) sits on the other side of the ridge
+             // from fc2 (K = 4 D)
+             ST_GEMM_PATCH, ST_GEMM_PROJ, ST_GEMM_FC2, ST_COUNT };
 
 struct StageStats {
     double ms[ST_COUNT] = {0};
@@ -227,7 +231,6 @@ class SamModel {
     // kPassFlags further passes of this lane.
     static constexpr int kPassFlags = 64;
     const volatile int* last_pass_flag() const { return pass_flag_; }
-    bool any_pass_flag_set_and_clear();
     void wait_and_recycle(hipEvent_t e);      // no mutex needed
     bool poll_and_recycle(hipEvent_t e);      // no mutex needed: true (and the event is taken back) once it has completed
 
@@ -238,7 +241,7 @@ class SamModel {
     void reserve_encoder(int batch);
     void reserve_decoder(int count);
     void decode_chunk(float const* const* emb, float const* coords, float const* labels, int count, int first);
-    void gemm(k::GemmArgs const& a);
+    void gemm(k::GemmArgs const& a, Stage shape = ST_COUNT);     // shape: ST_GEMM_PATCH / _PROJ / _FC2 for the stage clocks
     template <typename F> void timed(Stage st, double work, F&& launch);
     void flush_events();
     hipEvent_t take_event();
@@ -297,7 +300,7 @@ class SamModel {
 
     // ---- profiling
     bool profiling_ = false;
-    struct Pending { hipEvent_t a, b; Stage st; double work; Stage also = ST_COUNT; };
+    struct Pending { hipEvent_t a, b; Stage st; double work; Stage also = ST_COUNT; Stage shape = ST_COUNT; };
     std::vector<Pending> pending_;
     std::vector<hipEvent_t> event_pool_;
     StageStats stats_;

@@ -474,6 +474,15 @@ DLIMG_API int dlimg_amd_bench_attention(int global, int batch, int heads, int hd
         for (auto& v : hq) v = (half_t)(rnd() * 1.5f);
         for (auto& v : hb) v = rnd() * 0.2f;
         for (auto& v : hrel) v = rnd() * 0.3f;
+        if (global) {
+            // the global kernel's contract (kernels.hpp): q columns times log2(e) / sqrt(hd), rel-pos tables times sqrt(hd), as
+            // SamWeights prepares them -- unscaled operands give scores ~6 x hotter than the product's, i.e. another frequency
+            // of the lazy-maximum raise and other timings than the product's
+            const float qs = k::attention_global_q_scale(hd), rs = k::attention_global_rel_scale(hd);
+            for (size_t r = 0; r < rows; ++r)
+                for (int c = 0; c < D; ++c) hq[r * 3 * D + c] = (half_t)((float)hq[r * 3 * D + c] * qs);
+            for (auto& v : hrel) v *= rs;
+        }
         Upload<half_t> dq(hq.data(), hq.size());
         Upload<float> db(hb.data(), hb.size()), dh(hrel.data(), nrel), dw(hrel.data(), nrel);
         DeviceBuffer<half_t> o(rows * D), dh16(nrel), dw16(nrel), db16((size_t)3 * D);

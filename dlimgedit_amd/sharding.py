@@ -36,6 +36,19 @@ def max_over_ranks(value: float, device=None) -> float:
     return float(t.item())
 
 
+def all_ranks(value: float, device=None) -> List[float]:
+    """Every rank's host scalar, in rank order, on every rank (a straggler shows as one slow entry where the MAX hides it)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(value)]
+    world = dist.get_world_size()
+    mine = torch.tensor([value], dtype=torch.float64, device=device or "cpu")
+    out = torch.empty(world, dtype=torch.float64, device=device or "cpu")
+    dist.all_gather_into_tensor(out, mine)
+    return [float(v) for v in out.cpu().tolist()]
+
+
 def gather_results(local: Dict[int, np.ndarray], n_items: int, root: int = 0):
     """Collects per-item host arrays on `root` in item order (None elsewhere).  Every item must be
     produced by exactly one rank."""

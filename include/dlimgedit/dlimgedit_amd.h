@@ -93,11 +93,12 @@ DLIMG_API int dlimg_amd_get_segmentation_masks_device(dlimg_Segmentation const* 
                                                       size_t* out_offsets);
 
 /* ---- stage clocks (HIP events on the executor's stream) -------------------------------------- */
-#define DLIMG_AMD_STAGE_COUNT 12
+#define DLIMG_AMD_STAGE_COUNT 15
 /* stage ids: 0 pre, 1 gemm (all MFMA GEMMs of the encoder), 2 layernorm, 3 attention_window,
  * 4 attention_global, 5 encoder_other, 6 decoder (whole prompt+mask decoder), 7 post;
  * 8-11 split the launches of stage 1 by kernel flavour: 8 residual-stream writers with row statistics (patch, proj, fc2),
- * 9 LayerNorm-folded consumer (qkv), 10 LayerNorm-folded consumer + GELU (fc1), 11 other (neck) */
+ * 9 LayerNorm-folded consumer (qkv), 10 LayerNorm-folded consumer + GELU (fc1), 11 other (neck);
+ * 12-14 split stage 8 once more by shape: 12 patch embedding, 13 proj (K = D), 14 fc2 (K = 4 D) */
 /* enabled = 1: all requests run on lane 0, so every kernel is clocked alone on the chip; enabled = 2: the lanes run as
  * usual and every lane clocks its own launches (the regime the throughput figure is measured in); 0 = off.
  * dlimg_amd_take_stage_stats sums over the lanes. */

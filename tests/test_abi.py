@@ -22,27 +22,61 @@ def api():
     return api
 
 
+def _declared(header: Path) -> set:
+    return set(re.findall(r"DLIMG_API\s+[\w\s\*]+?\b(dlimg_\w+)\s*\(", header.read_text()))
+
+
 def test_library_exports_every_declared_symbol(api):
-    lib = api.library()
-    declared = set()
+    """Product library <-> dlimgedit.h + dlimgedit_amd.h; test library <-> dlimgedit_amd_test.h on top of those."""
+    product = _declared(INCLUDE / "dlimgedit" / "dlimgedit.h") | _declared(INCLUDE / "dlimgedit" / "dlimgedit_amd.h")
+    hooks = _declared(INCLUDE / "dlimgedit" / "dlimgedit_amd_test.h")
+    every = set()
     for header in INCLUDE.rglob("*.h"):
-        text = header.read_text()
-        declared |= set(re.findall(r"DLIMG_API\s+[\w\s\*]+?\b(dlimg_\w+)\s*\(", text))
-    assert "dlimg_init" in declared and len(declared) >= 15
-    assert declared == {"dlimg_init", *api.ext.EXPORTS}, "python binding and header disagree"
-    for name in declared:
+        every |= _declared(header)
+    assert every == product | hooks, "a header declares an entry point that no library is checked for"
+    assert "dlimg_init" in product and len(product) >= 15
+    assert product == {"dlimg_init", *api.ext.EXPORTS}, "python binding and dlimgedit_amd.h disagree"
+    assert hooks == set(api.ext.HOOK_EXPORTS), "python binding and dlimgedit_amd_test.h disagree"
+    lib, hooks_lib = api.library(), api.hooks_library()
+    for name in product:
         assert getattr(lib, name) is not None
+    for name in product | hooks:
+        assert getattr(hooks_lib, name) is not None
+
+
+def _dynamic_symbols(lib: Path) -> list:
+    out = subprocess.run(["nm", "-D", "--defined-only", str(lib)], capture_output=True, text=True, check=True).stdout
+    return sorted(l.split()[-1] for l in out.splitlines() if l.strip())
 
 
 def test_only_dlimg_symbols_are_exported(api):
-    """The reference hides everything but dlimg_init (/root/reference/src/CMakeLists.txt:11, dlimgedit.h:70).  Here:
-    dlimg_init + the dlimg_amd_* extension entry points and NOTHING else of any symbol type -- weak libstdc++ template
-    instantiations (std::filesystem::path::..., std::vector<...>::~vector) included (csrc/exports.map)."""
-    out = subprocess.run(["nm", "-D", "--defined-only", str(ROOT / "dlimgedit_amd" / "lib" / "libdlimgedit.so")],
-                         capture_output=True, text=True, check=True).stdout
-    names = [l.split()[-1] for l in out.splitlines() if l.strip()]
-    assert "dlimg_init" in names
-    assert sorted(names) == sorted({"dlimg_init", *api.ext.EXPORTS}), sorted(set(names) ^ {"dlimg_init", *api.ext.EXPORTS})
+    """The reference hides everything but dlimg_init (/root/reference/src/CMakeLists.txt:11, dlimgedit.h:70).  The PRODUCT
+    library: dlimg_init + the 22 extension entry points of dlimgedit_amd.h, named one by one in csrc/exports.map, and NOTHING
+    else of any symbol type -- no test or benchmark hook, no weak libstdc++ template instantiation
+    (std::filesystem::path::..., std::vector<...>::~vector).  The hooks live in the test library only."""
+    lib_dir = ROOT / "dlimgedit_amd" / "lib"
+    names = _dynamic_symbols(lib_dir / "libdlimgedit.so")
+    assert names == sorted({"dlimg_init", *api.ext.EXPORTS}), sorted(set(names) ^ {"dlimg_init", *api.ext.EXPORTS})
+    assert len(names) == 23 and not [n for n in names if "_test_" in n or "_bench_" in n]
+    test_names = _dynamic_symbols(lib_dir / "libdlimgedit_test.so")
+    want = sorted({"dlimg_init", *api.ext.EXPORTS, *api.ext.HOOK_EXPORTS})
+    assert test_names == want, sorted(set(test_names) ^ set(want))
+    assert len(api.ext.HOOK_EXPORTS) == 19 and all("_test_" in n or "_bench_" in n for n in api.ext.HOOK_EXPORTS)
+
+
+def test_hooks_come_from_the_test_library_not_the_product(api):
+    """A hook call loads lib/libdlimgedit_test.so (the product's objects + csrc/test_hooks.cpp); the product library has no
+    such symbol to fall back on, and a hook's error text comes from the library it ran in."""
+    assert api.hooks_library() is not api.library()
+    assert not hasattr(api.library(), "dlimg_amd_test_plan_steps")
+    passes, *_ = api.ext.plan_steps([0, 0], [0, 0], 0, 3, 2, 4, True)
+    assert sum(n for _, n in passes) == 3
+    with pytest.raises(api.Error, match="piece array is too small|assert|Assertion"):
+        api.ext._h().dlimg_amd_test_mask_pieces.argtypes        # (signatures are set)
+        sizes = (C.c_longlong * 1)(1 << 40)
+        got = api.ext._h().dlimg_amd_test_mask_pieces(1, sizes, 0, (C.c_longlong * 1)(), 0, (C.c_longlong * 5)(), 1, C.byref(C.c_int()))
+        assert got < 0
+        api._check_hook(1)
 
 
 def test_pod_layouts_match_reference(api):
@@ -64,7 +98,7 @@ def test_pod_layouts_match_reference(api):
 def test_header_is_valid_c_and_cpp(tmp_path):
     cc = shutil.which("gcc")
     src = tmp_path / "t.c"
-    src.write_text('#include <dlimgedit/dlimgedit_amd.h>\n'
+    src.write_text('#include <dlimgedit/dlimgedit_amd_test.h>\n'
                    '_Static_assert(sizeof(dlimg_ImageView) == 24, "view");\n'
                    '_Static_assert(sizeof(dlimg_Options) == 16, "options");\n'
                    '_Static_assert(sizeof(dlimg_Api) == 15 * sizeof(void*), "table");\n'

@@ -441,6 +441,21 @@ def test_values_beyond_the_f16_range_are_reported_not_decoded(api, model_dirs, t
         api.Segmentation.process(img, env)
     with pytest.raises(api.Error, match="non-finite values"):
         api.Segmentation.process_batch([img, img, img], env)
+    # a flag has an owner (r06): the reports above belonged to process() / process_batch() and were consumed there -- a
+    # later synchronize of the asynchronous entry point, which queued nothing, has nothing to report
+    api.ext.synchronize(env)
+    # ... while a queued pass of its own is reported by the synchronize that retires it, once, with the request count
+    dev_img = api.ext.device_alloc(env, 1024 * 1024 * 4)
+    dev_mask = api.ext.device_alloc(env, 1024 * 1024)
+    api.ext.copy_to_device(env, dev_img, synthetic_image(0))
+    views = api.ext.device_views([dev_img], 1024, 1024)
+    for _ in range(3):
+        api.ext.encode_and_mask(env, views, [api.Point(512, 512)], [dev_mask])
+    with pytest.raises(api.Error, match=r"3 request\(s\) ran in an image encoder pass that produced non-finite values"):
+        api.ext.synchronize(env)
+    api.ext.synchronize(env)
+    api.ext.device_free(env, dev_img)
+    api.ext.device_free(env, dev_mask)
     env.close()
 
     # the same images on the unmodified weights still work in this process (nothing sticky, no poisoned buffers)

@@ -65,7 +65,7 @@ def test_preprocess_honours_stride(ext):
     O = _oracle()
     full = synthetic_image(9, width=1100, height=1024, channels=4)
     out = np.empty((4096, 768), dtype=np.float16)
-    rc = api.ext._l().dlimg_amd_test_preprocess(full.ctypes.data, 1024, 1024, 1100 * 4, 4, out.ctypes.data)
+    rc = api.ext._h().dlimg_amd_test_preprocess(full.ctypes.data, 1024, 1024, 1100 * 4, 4, out.ctypes.data)
     assert rc == 0
     want = O.patchify(O.preprocess(O.create_image_tensor(np.ascontiguousarray(full[:, :1024]), 4))).astype(np.float16)
     assert np.array_equal(out.view(np.uint16), want.view(np.uint16))
@@ -342,12 +342,14 @@ def test_attention_window_parity(ext, heads, hd):
 
 
 @pytest.mark.gpu
-def test_attention_window_lazy_maximum_rescale(ext):
-    """Head dimension 64 makes one pass with a reference maximum taken from the first key tile: keys late in every window
-    (last window row) aligned with a query and far above the rest force the rescale branch, in windows with and without
-    zero padding; the softmax must come out as the oracle's exact-maximum one."""
+@pytest.mark.parametrize("hd", [64, 80])
+def test_attention_window_lazy_maximum_rescale(ext, hd):
+    """Both head dimensions make one pass with a reference maximum taken from the first key tile: keys late in every window
+    (last window row) aligned with a query and far above the rest force the rescale branch (accumulators and row sum, 80
+    columns at head dimension 80), in windows with and without zero padding; the softmax must come out as the oracle's
+    exact-maximum one."""
     O = _oracle()
-    heads, hd = 2, 64
+    heads = 2
     qkv, bias = _qkv(11, heads, hd)
     qkv = (qkv.astype(np.float32) * 0.3).astype(np.float16)
     D = heads * hd
@@ -371,7 +373,7 @@ def test_attention_window_lazy_maximum_rescale(ext):
                                         rel_w.astype(np.float16).astype(np.float32), heads)
     # the forcing keys really are beyond the lazy threshold (2^8 in the exponent): |q|^2 * 60 / sqrt(hd) * log2(e) >> 8
     q0 = qkv[0 * 64 + 2, :hd].astype(np.float32)
-    assert float(q0 @ q0) * 60 / 8.0 * 1.4427 > 16
+    assert float(q0 @ q0) * 60 / np.sqrt(hd) * 1.4427 > 16
     assert np.isfinite(got).all()
     assert np.abs(got - ref).max() < 6e-3, np.abs(got - ref).max()
 

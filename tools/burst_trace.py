@@ -1,6 +1,6 @@
 """Runs only bench.py's timed region (bursts of K single-image requests + synchronize) with a pause between bursts, so that a
 rocprofv3 --kernel-trace shows each burst as one block:   rocprofv3 --kernel-trace ... -- python3 tools/burst_trace.py [K] [bursts]
-then tools/trace_lanes.py / tools/trace_timeline.py on the .db."""
+then tools/trace_lanes.py / tools/lanes_summary.py on the .db."""
 import os
 import sys
 import tempfile

@@ -8,7 +8,8 @@ MODEL="${1:-vit_b}"
 export GPU_MAX_HW_QUEUES=8 DLIMGEDIT_PLAIN_STREAMS=1
 O=$R/gpurun_out/prof_$MODEL
 rm -rf "$O"; mkdir -p "$O"
-B="python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-abi-path --repeats 5 --model $MODEL"
+B="python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-abi-path --no-config-legs --repeats 5 --model $MODEL"
+DEPTH=$(python3 -c "import sys; sys.path.insert(0, '$R'); from dlimgedit_amd.sam_config import get_config; print(get_config('$MODEL').depth)")
 timeout -k 10 200 rocprofv3 --kernel-trace -d $O/kt -o kt -- $B > $O/bench_kt.log 2>&1 && echo kt ok &&
 DLIMGEDIT_SINGLE_LANE=1 timeout -k 10 200 rocprofv3 --kernel-trace -d $O/kt1 -o kt1 -- $B > $O/bench_kt1.log 2>&1 && echo kt1 ok &&
 timeout -k 10 250 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o fetch -- $B > $O/f.log 2>&1 && echo fetch ok &&
@@ -27,7 +28,7 @@ DLIMGEDIT_SAM_MODEL=$MODEL timeout -k 10 250 rocprofv3 --kernel-trace -d $O/ktb 
   python3 $R/tools/lanes_summary.py $O/ktb/ktb_results.db 20 $FLOP; } > $S/lanes_summary.txt 2>&1
 python3 $R/tools/kernel_stats.py $O/kt1/kt1_results.db 40 > $S/kernel_stats_single_lane.txt
 python3 $R/tools/kernel_stats.py $O/kt1/kt1_results.db 60 --by-grid > $S/kernel_stats_single_lane_by_grid.txt 2>&1
-python3 $R/tools/pmc_traffic.py $O/pmc_fetch/fetch_results.db $O/pmc_write/write_results.db $S/hbm_traffic_pmc.json "$B" > $S/traffic.log 2>&1
+python3 $R/tools/pmc_traffic.py $O/pmc_fetch/fetch_results.db $O/pmc_write/write_results.db $S/hbm_traffic_pmc.json "$B" $DEPTH > $S/traffic.log 2>&1
 python3 $R/tools/pmc_mfma.py $O/pmc_mfma/m_results.db $S/mfma_util_pmc.json "$B" > $S/mfma.log 2>&1
 cp $(ls $O/st/*/st_kernel_stats.csv $O/st/st_kernel_stats.csv 2>/dev/null | head -1) $S/kernel_stats_rocprofv3.csv 2>/dev/null
 grep "^{" $O/bench_kt.log | tail -1 > $S/bench_under_kernel_trace.json

@@ -53,9 +53,49 @@ def collect(db_path, counter, by_grid=None):
     return out
 
 
+def stream_writer_shapes(db_path, counter, depth):
+    """The encoder's stream writers -- patch embedding, proj, fc2 -- are ONE kernel (gemm_pp_kernel<0,2>) at ONE grid, so no
+    by-name table can tell them apart; what can is their order on a stream: every pass launches patch, then (proj, fc2) per
+    block, i.e. 2 * depth + 1 launches with that grid, always in this order.  Returns {shape: [launches, counter sum, grid]}
+    for the grid with the most launches, or {} when a stream's launch count is not a whole number of passes (another kernel
+    mix: nothing is guessed)."""
+    db = sqlite3.connect(db_path)
+    try:
+        rows = db.execute("select c.kernel_name, c.value, c.grid_size, c.workgroup_size, c.dispatch_id, k.stream_id "
+                          "from counters_collection c join rocpd_kernel_dispatch k on k.dispatch_id = c.dispatch_id and k.guid = c.guid "
+                          "where c.counter_name = ?", (counter,)).fetchall()
+    except sqlite3.Error:
+        return {}
+    seqs = {}
+    for name, value, grid, wg, dispatch, stream in rows:
+        if short(name) != "gemm_pp_kernel<0,2>":
+            continue
+        seqs.setdefault((int(grid // max(wg, 1)), stream), []).append((dispatch, value))
+    if not seqs:
+        return {}
+    per_grid = {}
+    for (wgs, _), seq in seqs.items():
+        per_grid[wgs] = per_grid.get(wgs, 0) + len(seq)
+    wgs = max(per_grid, key=per_grid.get)
+    period = 2 * depth + 1
+    out = {"gemm_patch": [0, 0.0, wgs], "gemm_proj": [0, 0.0, wgs], "gemm_fc2": [0, 0.0, wgs]}
+    for (g, _), seq in seqs.items():
+        if g != wgs:
+            continue
+        if len(seq) % period:
+            return {}
+        for i, (_, value) in enumerate(sorted(seq)):
+            key = "gemm_patch" if i % period == 0 else ("gemm_proj" if (i % period) % 2 == 1 else "gemm_fc2")
+            out[key][0] += 1
+            out[key][1] += value
+    return out
+
+
 def main():
     fetch_grid, write_grid = {}, {}
     fetch, write = collect(sys.argv[1], "FETCH_SIZE", fetch_grid), collect(sys.argv[2], "WRITE_SIZE", write_grid)
+    depth = int(sys.argv[5]) if len(sys.argv) > 5 else 12
+    shape_f, shape_w = stream_writer_shapes(sys.argv[1], "FETCH_SIZE", depth), stream_writer_shapes(sys.argv[2], "WRITE_SIZE", depth)
     per_kernel = {}
     for g in sorted(set(fetch) | set(write)):
         n_f, kb_f = fetch.get(g, [0, 0.0])
@@ -80,9 +120,21 @@ def main():
             "fetch_bytes_per_launch_corrected_x2": 2.0 * 1024.0 * fetch_grid.get(k, [0, 0.0])[1] / max(fetch_grid.get(k, [0, 0.0])[0], 1),
             "write_bytes_per_launch": 1024.0 * write_grid.get(k, [0, 0.0])[1] / max(write_grid.get(k, [0, 0.0])[0], 1)}
         for k in sorted(set(fetch_grid) | set(write_grid))}
+    # r06: the stream writers once more by shape (launch order on their stream; stream_writer_shapes)
+    if shape_f and shape_w and set(shape_f) == set(shape_w):
+        doc["by_shape"] = {
+            k: {"kernel": "gemm_pp_kernel<0,2>", "grid": shape_f[k][2], "launches_in_run": shape_f[k][0],
+                "fetch_bytes_per_launch_corrected_x2": 2.0 * 1024.0 * shape_f[k][1] / max(shape_f[k][0], 1),
+                "write_bytes_per_launch": 1024.0 * shape_w[k][1] / max(shape_w[k][0], 1)}
+            for k in shape_f}
+        doc["by_shape_note"] = ("patch / proj / fc2 share gemm_pp_kernel<0,2> and its grid; told apart by their position in the "
+                                f"{2 * depth + 1} launches of that kernel per pass on its stream (patch, then proj and fc2 per block)")
     doc.update(per_kernel.get("gemm_pp", {}))
     with open(sys.argv[3], "w") as f:
         json.dump(doc, f, indent=1)
+    for k, v in doc.get("by_shape", {}).items():
+        print(f"{k:12s} launches {v['launches_in_run']:5d}  fetch {v['fetch_bytes_per_launch_corrected_x2'] / 1e6:8.2f} MB  "
+              f"write {v['write_bytes_per_launch'] / 1e6:8.2f} MB per launch (grid {v['grid']})")
     for g, v in per_kernel.items():
         print(f"{g:12s} launches {v['launches_in_run']:5d}  fetch {v['fetch_bytes_per_launch_corrected_x2'] / 1e6:8.2f} MB  "
               f"write {v['write_bytes_per_launch'] / 1e6:8.2f} MB per launch")
