@@ -446,6 +446,7 @@ class ext:
                 "dlimg_amd_test_mask_pieces": ([ci, C.POINTER(C.c_longlong), C.c_longlong, C.POINTER(C.c_longlong), ci,
                                                C.POINTER(C.c_longlong), ci, C.POINTER(ci)], ci),
                 "dlimg_amd_test_plan_steps": ([ci, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), ci, ci, ci, ci, C.POINTER(ci), C.POINTER(ci), ci], ci),
+                "dlimg_amd_test_parse_cpu_list": ([C.c_char_p, C.POINTER(ci), ci], ci),
                 "dlimg_amd_test_preprocess": ([vp, ci, ci, ci, ci, vp], ci),
                 "dlimg_amd_test_postprocess": ([vp, ci, vp, ci, ci, vp], ci),
                 "dlimg_amd_test_postprocess_batch": ([vp, ci, ci, ci, vp], ci),
@@ -478,7 +479,7 @@ class ext:
                "dlimg_amd_birefnet_process_mask", "dlimg_amd_resize_mask")
     # hooks of the test / tuning libraries (include/dlimgedit/dlimgedit_amd_test.h)
     HOOK_EXPORTS = (
-               "dlimg_amd_test_mask_pieces", "dlimg_amd_test_plan_steps", "dlimg_amd_test_preprocess",
+               "dlimg_amd_test_mask_pieces", "dlimg_amd_test_plan_steps", "dlimg_amd_test_parse_cpu_list", "dlimg_amd_test_preprocess",
                "dlimg_amd_test_postprocess", "dlimg_amd_test_postprocess_batch", "dlimg_amd_test_force_gemm_tile",
                "dlimg_amd_test_force_gemm_consumer_tile", "dlimg_amd_test_gemm", "dlimg_amd_test_gemm_ln",
                "dlimg_amd_test_lane_worker", "dlimg_amd_test_gemm_stream", "dlimg_amd_test_layernorm",
@@ -559,6 +560,15 @@ class ext:
         if n < 0:
             _check_hook(1)
         return [(out_lane[k], out_images[k]) for k in range(n)], list(p), list(i), cur.value
+
+    @classmethod
+    def parse_cpu_list(cls, text: str) -> list:
+        """Host logic (no GPU needed): sysfs cpulist text -> CPU indices, as the multi-GPU helper threads' binding reads it."""
+        out = (C.c_int * 4096)()
+        n = cls._h().dlimg_amd_test_parse_cpu_list(text.encode(), out, 4096)
+        if n < 0:
+            _check_hook(1)
+        return list(out[:n])
 
     # -- benchmark path
     @classmethod

@@ -12,6 +12,7 @@
 #include <mutex>
 #include <optional>
 #include <string>
+#include <vector>
 #include <tuple>
 #include <utility>
 
@@ -33,6 +34,14 @@ class Exception : public std::exception {
 // Did the HIP runtime read a GPU_MAX_HW_QUEUES of at least 8 (environment.cpp: set by the host, or by this library's load-time
 // constructor while the runtime was demonstrably not yet initialised)?  Decides the lanes' stream layout (sam_model.cpp).
 bool hardware_queues_trusted();
+
+// Multi-GPU host hygiene (r06): binds the CALLING thread to the CPUs of the NUMA node HIP device `device` hangs off (its PCI
+// function's numa_node in sysfs), intersected with the CPUs the process may use; returns the number of CPUs it was bound
+// to, 0 when nothing was changed (no NUMA information, a single node, DLIMGEDIT_NUMA_AFFINITY=0, or any failure: never an
+// error).  Used by the helper threads that feed the replicas of a multi-GPU environment, never on a one-GPU environment.
+int bind_thread_near_device(int device) noexcept;
+// "0-3,8,10-11" -> {0,1,2,3,8,10,11} (sysfs cpulist format); malformed pieces are skipped
+std::vector<int> parse_cpu_list(std::string const& text);
 
 #define DLIMG_ASSERT(cond)                                           \
     do {                                                             \

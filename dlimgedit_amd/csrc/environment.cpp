@@ -1,6 +1,9 @@
 #include "environment.hpp"
 
 #include <algorithm>
+#include <cctype>
+#include <cstdio>
+#include <sched.h>
 
 #include <cstdlib>
 #include <cstring>
@@ -53,6 +56,70 @@ bool hardware_queues_trusted() {
     }
     }
     return false;
+}
+
+std::vector<int> parse_cpu_list(std::string const& text) {
+    std::vector<int> cpus;
+    size_t pos = 0;
+    while (pos < text.size()) {
+        size_t end = text.find(',', pos);
+        if (end == std::string::npos) end = text.size();
+        const std::string item = text.substr(pos, end - pos);
+        pos = end + 1;
+        char* tail = nullptr;
+        const long a = std::strtol(item.c_str(), &tail, 10);
+        if (tail == item.c_str() || a < 0) continue;
+        long b = a;
+        if (*tail == '-') {
+            char* tail2 = nullptr;
+            b = std::strtol(tail + 1, &tail2, 10);
+            if (tail2 == tail + 1 || b < a) continue;
+        }
+        for (long c = a; c <= b && cpus.size() < 4096; ++c) cpus.push_back((int)c);
+    }
+    return cpus;
+}
+
+int bind_thread_near_device(int device) noexcept {
+    try {
+        if (const char* e = std::getenv("DLIMGEDIT_NUMA_AFFINITY"))
+            if (std::atoi(e) == 0) return 0;
+        char bus[64] = {0};
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0;
+        }
+        std::string id(bus);
+        for (auto& c : id) c = (char)std::tolower((unsigned char)c);
+        auto read_line = [](std::string const& path) {
+            std::string line;
+            if (FILE* f = std::fopen(path.c_str(), "r")) {
+                char buf[4096];
+                if (std::fgets(buf, sizeof(buf), f)) line = buf;
+                std::fclose(f);
+            }
+            while (!line.empty() && (line.back() == '\n' || line.back() == ' ')) line.pop_back();
+            return line;
+        };
+        const std::string node = read_line("/sys/bus/pci/devices/" + id + "/numa_node");
+        if (node.empty() || std::atoi(node.c_str()) < 0) return 0;
+        const std::vector<int> cpus = parse_cpu_list(read_line("/sys/devices/system/node/node" + node + "/cpulist"));
+        if (cpus.empty()) return 0;
+        cpu_set_t allowed, want;
+        CPU_ZERO(&allowed);
+        CPU_ZERO(&want);
+        if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return 0;
+        int n = 0;
+        for (int c : cpus)
+            if (c < CPU_SETSIZE && CPU_ISSET(c, &allowed)) {
+                CPU_SET(c, &want);
+                ++n;
+            }
+        if (n == 0 || n == CPU_COUNT(&allowed)) return 0;          // nothing to gain (one node) or nothing allowed there
+        return sched_setaffinity(0, sizeof(want), &want) == 0 ? n : 0;
+    } catch (...) {
+        return 0;
+    }
 }
 
 void throw_error(const char* msg) { throw Exception(msg); }
@@ -286,7 +353,7 @@ float* EmbeddingPool::take() {
     }
     HIP_CHECK(hipSetDevice(device_));
     float* p = nullptr;
-    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), (size_t)kTokens * kEmbedDim * sizeof(float)));
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), SamModel::kEmbeddingBufferBytes));     // embedding + block-0 image side (r06)
     return p;
 }
 

@@ -85,26 +85,60 @@ void stage_image(SamModel& model, int slot, int batch, dlimg_ImageView const& im
     }
 }
 
-// Runs body(replica) for every replica in `used`: inline when there is one, on one host thread per GPU otherwise
-// (staging copies and kernel launches of different GPUs then proceed side by side).  The first exception wins.
-template <typename F> void for_each_replica(std::vector<int> const& used, F&& body) {
+// Runs body(replica) for every replica in `used`: inline when there is one; otherwise the calling thread takes the first
+// replica itself and hands the others to helper threads of ITS OWN (staging copies and kernel launches of different GPUs
+// then proceed side by side).  The helpers are kept per calling thread and reused from call to call (r06; until then every
+// call created and joined G threads): a caller's helpers serve nobody else, so concurrent callers never wait for each
+// other here, and a helper that serves GPU g is bound to the CPUs of that GPU's NUMA node the first time it does
+// (environment.cpp, bind_thread_near_device; DLIMGEDIT_NUMA_AFFINITY=0 switches that off).  The first exception wins.
+struct ReplicaHelpers {
+    std::vector<std::unique_ptr<LaneWorker>> workers;       // [helper]: joined when the calling thread ends
+    std::vector<int> bound_to;                              // device the helper's thread was last bound near (-1: none)
+};
+template <typename F> void for_each_replica(EnvironmentImpl& env, std::vector<int> const& used, F&& body) {
     if (used.size() == 1) {
         body(used[0]);
         return;
     }
-    std::vector<std::exception_ptr> errors(used.size());
-    std::vector<std::thread> workers;
-    for (size_t t = 0; t < used.size(); ++t)
-        workers.emplace_back([&, t] {
+    thread_local ReplicaHelpers helpers;
+    const size_t n_help = used.size() - 1;
+    while (helpers.workers.size() < n_help) {
+        helpers.workers.push_back(std::make_unique<LaneWorker>());
+        helpers.bound_to.push_back(-1);
+    }
+    struct Handed { std::promise<void> result; std::future<void> answer; };
+    std::vector<std::shared_ptr<Handed>> handed;
+    for (size_t t = 0; t < n_help; ++t) {
+        auto h = std::make_shared<Handed>();
+        h->answer = h->result.get_future();
+        handed.push_back(h);
+        const int replica = used[t + 1], device = env.device_of(replica);
+        const bool bind = helpers.bound_to[t] != device;
+        helpers.bound_to[t] = device;
+        helpers.workers[t]->post([h, &body, replica, device, bind] {
             try {
-                body(used[t]);
+                if (bind) bind_thread_near_device(device);
+                body(replica);
+                h->result.set_value();
             } catch (...) {
-                errors[t] = std::current_exception();
+                h->result.set_exception(std::current_exception());
             }
         });
-    for (auto& w : workers) w.join();
-    for (auto& e : errors)
-        if (e) std::rethrow_exception(e);
+    }
+    std::exception_ptr first;
+    try {
+        body(used[0]);
+    } catch (...) {
+        first = std::current_exception();
+    }
+    for (auto& h : handed) {                     // every task is waited for: they refer to the caller's frame
+        try {
+            h->answer.get();
+        } catch (...) {
+            if (!first) first = std::current_exception();
+        }
+    }
+    if (first) std::rethrow_exception(first);
 }
 
 // overflow: the pass's report (SamModel::last_pass_flag), read once its event has been waited for
@@ -187,7 +221,7 @@ void SegmentationImpl::process_batch(EnvironmentImpl& env, SegmentationImpl* con
         ~InFlight() { n.fetch_sub(1); }
     } in_flight(env.batch_calls_in_flight);
     const bool alone = in_flight.before == 0;    // no other batch call is being worked on right now
-    for_each_replica(used, [&](int replica) {
+    for_each_replica(env, used, [&](int replica) {
         HIP_CHECK(hipSetDevice(env.device_of(replica)));
         std::vector<Waiting> waiting;
         SamModel* enqueueing = nullptr;          // the lane whose request is being put together (error path: drained)
@@ -318,7 +352,7 @@ void SegmentationImpl::compute_mask(Point const* point, Region const* region, ui
             float const* emb = embedding_;
             {
                 roctx::Range rd("dlimg.decode");
-                model_.decode(&emb, coords, labels, 1);
+                model_.decode(&emb, coords, labels, 1, /*cached_side0=*/true);
             }
             if (is_single_mask) {
                 // single-mask decoder: best of the four by SamOnnxModel.select_masks, chosen on the device
@@ -365,7 +399,7 @@ void SegmentationImpl::compute_mask_batch(SegmentationImpl const* const* segs, i
         }
         if (std::find(used.begin(), used.end(), segs[i]->replica_) == used.end()) used.push_back(segs[i]->replica_);
     }
-    for_each_replica(used, [&](int replica) {
+    for_each_replica(env, used, [&](int replica) {
         HIP_CHECK(hipSetDevice(env.device_of(replica)));
         std::vector<int> mine;
         for (int i = 0; i < count; ++i)
@@ -403,7 +437,7 @@ void SegmentationImpl::compute_mask_batch(SegmentationImpl const* const* segs, i
                 Chunk& cur = chunks.back();
                 roctx::Range range("dlimg.compute_masks");
                 std::lock_guard<std::mutex> lock(model.mutex());
-                model.decode(emb.data(), cc.data(), ll.data(), n);
+                model.decode(emb.data(), cc.data(), ll.data(), n, /*cached_side0=*/true);
                 for (int j = 0; j < n; ++j) {
                     const int i = mine[base + j];
                     const Extent o = segs[i]->image_size_.original, r = segs[i]->image_size_.resized;
@@ -460,7 +494,7 @@ void SegmentationImpl::compute_mask_batch_device(SegmentationImpl const* const* 
         if (std::find(used.begin(), used.end(), segs[i]->replica_) == used.end()) used.push_back(segs[i]->replica_);
     }
     if (out_offsets) std::copy(offsets.begin(), offsets.end(), out_offsets);
-    for_each_replica(used, [&](int replica) {
+    for_each_replica(env, used, [&](int replica) {
         HIP_CHECK(hipSetDevice(env.device_of(replica)));
         std::vector<int> mine;
         for (int i = 0; i < count; ++i)
@@ -498,7 +532,7 @@ void SegmentationImpl::compute_mask_batch_device(SegmentationImpl const* const* 
                 chunks.push_back(Chunk{&model, &model.acquire_mask_slot()});
                 roctx::Range range("dlimg.compute_masks_device");
                 std::lock_guard<std::mutex> lock(model.mutex());
-                model.decode(emb.data(), cc.data(), ll.data(), n);
+                model.decode(emb.data(), cc.data(), ll.data(), n, /*cached_side0=*/true);
                 for (int j = 0; j < n; ++j) {
                     const int i = mine[base + j];
                     const Extent o = segs[i]->image_size_.original, r = segs[i]->image_size_.resized;

@@ -111,6 +111,19 @@ DLIMG_API int dlimg_amd_test_lane_worker(int tasks, int sleep_us, int* out_order
     return rc == 0 ? ran : -1;
 }
 
+// "0-3,8,10-11" -> CPU indices (the parser behind bind_thread_near_device, environment.cpp); returns their number (-1: error)
+DLIMG_API int dlimg_amd_test_parse_cpu_list(char const* text, int* out_cpus, int capacity) {
+    int count = -1;
+    const int rc = guarded([&] {
+        DLIMG_ASSERT(text != nullptr && out_cpus != nullptr && capacity >= 0);
+        const std::vector<int> cpus = parse_cpu_list(text);
+        if ((int)cpus.size() > capacity) throw Exception("test_parse_cpu_list: the output array is too small");
+        for (size_t i = 0; i < cpus.size(); ++i) out_cpus[i] = cpus[i];
+        count = (int)cpus.size();
+    });
+    return rc == 0 ? count : -1;
+}
+
 DLIMG_API int dlimg_amd_test_plan_steps(int lanes, int* passes_in_flight, int* images_in_flight, int* cursor, int pending, int width,
                                         int depth, int all, int* out_lane, int* out_images, int capacity) {
     int planned = -1;

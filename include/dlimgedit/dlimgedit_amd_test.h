@@ -32,6 +32,10 @@ DLIMG_API int dlimg_amd_test_plan_steps(int lanes, int* passes_in_flight, int* i
  * run when the worker is destroyed.  out_order: tasks + 1 entries.  Returns the number of tasks that ran, -1 on error. */
 DLIMG_API int dlimg_amd_test_lane_worker(int tasks, int sleep_us, int* out_order);
 
+/* Host logic of the multi-GPU helper threads' CPU binding (csrc/environment.cpp, bind_thread_near_device): the sysfs cpulist
+ * parser, "0-3,8,10-11" -> indices; returns their number, -1 on error. */
+DLIMG_API int dlimg_amd_test_parse_cpu_list(char const* text, int* out_cpus, int capacity);
+
 /* ---- single-kernel hooks (host buffers in and out; device memory handled inside) ------------- */
 /* K1: pixels -> patch matrix [4096][768] f16. */
 DLIMG_API int dlimg_amd_test_preprocess(uint8_t const* pixels, int width, int height, int stride, int channels,

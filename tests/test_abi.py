@@ -61,7 +61,7 @@ def test_only_dlimg_symbols_are_exported(api):
     test_names = _dynamic_symbols(lib_dir / "libdlimgedit_test.so")
     want = sorted({"dlimg_init", *api.ext.EXPORTS, *api.ext.HOOK_EXPORTS})
     assert test_names == want, sorted(set(test_names) ^ set(want))
-    assert len(api.ext.HOOK_EXPORTS) == 19 and all("_test_" in n or "_bench_" in n for n in api.ext.HOOK_EXPORTS)
+    assert len(api.ext.HOOK_EXPORTS) == 20 and all("_test_" in n or "_bench_" in n for n in api.ext.HOOK_EXPORTS)
 
 
 def test_hooks_come_from_the_test_library_not_the_product(api):
@@ -206,3 +206,10 @@ def test_packed_select_guard_passes_on_the_product_and_fires_on_the_known_bad_fo
                     str(B.CSRC / "kernels" / "decoder.hip"), "-o", str(bad)], check=True, capture_output=True)
     with pytest.raises(RuntimeError, match="src1 low-lane select"):
         B.check_packed_select_erratum(bad)
+
+
+def test_cpu_list_parser_of_the_numa_binding(api):
+    """bind_thread_near_device (csrc/environment.cpp) reads /sys/devices/system/node/nodeN/cpulist: ranges, singles, junk."""
+    assert api.ext.parse_cpu_list("0-3,8,10-11") == [0, 1, 2, 3, 8, 10, 11]
+    assert api.ext.parse_cpu_list("64-67,192-193\n") == [64, 65, 66, 67, 192, 193]
+    assert api.ext.parse_cpu_list("") == [] and api.ext.parse_cpu_list("x,5,7-6,-2,9") == [5, 9]
