@@ -353,7 +353,7 @@ float* EmbeddingPool::take() {
     }
     HIP_CHECK(hipSetDevice(device_));
     float* p = nullptr;
-    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), SamModel::kEmbeddingBufferBytes));     // embedding + block-0 image side (r06)
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), (size_t)kTokens * kEmbedDim * sizeof(float)));
     return p;
 }
 

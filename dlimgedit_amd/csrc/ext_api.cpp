@@ -84,7 +84,7 @@ DLIMG_API int dlimg_amd_get_logits(dlimg_Segmentation seg, int const* point, int
         std::lock_guard<std::mutex> lock(m.mutex());
         HIP_CHECK(hipSetDevice(m.device()));
         float const* emb = s.embedding();
-        m.decode(&emb, coords, labels, 1, /*cached_side0=*/true);
+        m.decode(&emb, coords, labels, 1);
         m.synchronize();
         download(out_logits, m.logits(), (size_t)4 * kLowRes * kLowRes);
         download(out_iou, m.iou(), 4);
@@ -114,7 +114,7 @@ DLIMG_API int dlimg_amd_decoder_state(dlimg_Segmentation seg, int const* point, 
         std::lock_guard<std::mutex> lock(m.mutex());
         HIP_CHECK(hipSetDevice(m.device()));
         float const* emb = s.embedding();
-        m.decode(&emb, coords, labels, 1, /*cached_side0=*/true);
+        m.decode(&emb, coords, labels, 1);
         m.synchronize();
         m.decoder_state(out);
     });

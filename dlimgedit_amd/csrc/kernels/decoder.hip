@@ -339,13 +339,10 @@ constexpr int T2I_KEYS = NTOK_IMG / T2I_GROUPS / T2I_THREADS;  // keys per threa
 constexpr int T2I_WAVES = T2I_THREADS / 64;
 constexpr int T2I_PARTS = T2I_GROUPS;                          // partial triples per (prompt, head, query)
 
-// SIDE: prompt p's keys / values are columns K_COL / V_COL (passed in ldk / ldv's place: the leading dimension is
-// kImageSide0Cols) of ITS image's cached block-0 matrix, side.base[p], instead of rows p * 4096 .. of one matrix.
-template <bool SIDE>
 __global__ __launch_bounds__(T2I_THREADS) void token_to_image_partial_kernel(const float* __restrict__ q, k::TokenLinear qp,
                                                                              const half_t* __restrict__ K, int ldk,
                                                                              const half_t* __restrict__ V, int ldv,
-                                                                             k::ImageSide0 side, float* __restrict__ part) {
+                                                                             float* __restrict__ part) {
     __shared__ float sq[TOK * 16];
     __shared__ float qrows[TOK * INNER];
     __shared__ __attribute__((aligned(16))) float xrows[TOK * DIM];
@@ -353,11 +350,9 @@ __global__ __launch_bounds__(T2I_THREADS) void token_to_image_partial_kernel(con
     __shared__ float wpart[TOK][T2I_WAVES][18];
     const int grp = blockIdx.x % T2I_GROUPS, h = (blockIdx.x / T2I_GROUPS) % HEADS, p = blockIdx.x / (T2I_GROUPS * HEADS);
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
-    const int k_col = ldk, v_col = ldv;          // (SIDE)
-    if (SIDE) ldk = ldv = k::kImageSide0Cols;
-    const size_t key0 = (SIDE ? (size_t)0 : (size_t)p * NTOK_IMG) + (size_t)grp * (NTOK_IMG / T2I_GROUPS);
-    const half_t* kb = (SIDE ? side.base[p] + k_col : K) + key0 * ldk + h * 16;
-    const half_t* vb = (SIDE ? side.base[p] + v_col : V) + key0 * ldv + h * 16;
+    const size_t key0 = (size_t)p * NTOK_IMG + (size_t)grp * (NTOK_IMG / T2I_GROUPS);
+    const half_t* kb = K + key0 * ldk + h * 16;
+    const half_t* vb = V + key0 * ldv + h * 16;
     half8_t kreg[T2I_KEYS][2], vreg[T2I_KEYS][2];
 #pragma unroll
     for (int i = 0; i < T2I_KEYS; ++i) {
@@ -821,8 +816,7 @@ void decoder_start(const DecoderPrompts& prompts, const float* gauss, const floa
     if (P > kDecoderMaxPrompts || n_first < 0 || n_first > TL_MAX_OPS) throw_error("decoder_start: too many prompts or layers");
     const size_t n4 = (size_t)NTOK_IMG * DIM / 4;
     const size_t total = n4 * P;
-    const int key_blocks = !keys ? 0 : (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    if (keys && !keys_h) throw_error("decoder_start: keys without their f16 copy");
+    const int key_blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     DecoderStart a{};
     a.prompts = prompts;
     a.gauss = gauss; a.point_embed = point_embed; a.not_a_point = not_a_point; a.iou_token = iou_token; a.mask_tokens = mask_tokens;
@@ -910,28 +904,8 @@ void token_to_image_partials(const float* q, const TokenLinear* q_proj, const ha
     } else if (!q) {
         throw_error("token_to_image_attention: neither queries nor their projection given");
     }
-    hipLaunchKernelGGL(token_to_image_partial_kernel<false>, dim3(P * HEADS * T2I_GROUPS), dim3(T2I_THREADS), 0, s, q, qp, K, ldk, V,
-                       ldv, ImageSide0{}, scratch);
-}
-
-void token_to_image_partials(const float* q, const TokenLinear* q_proj, const ImageSide0& side, int k_col, int v_col,
-                             float* scratch, int P, hipStream_t s) {
-    if (P <= 0) return;
-    if (P > kDecoderMaxPrompts || k_col < 0 || v_col < 0 || k_col % 8 || v_col % 8 || k_col + INNER > kImageSide0Cols ||
-        v_col + INNER > kImageSide0Cols)
-        throw_error("token_to_image_attention: bad columns of the cached image-side matrix");
-    for (int i = 0; i < P; ++i)
-        if (!side.base[i] || ((uintptr_t)side.base[i] & 15)) throw_error("token_to_image_attention: a prompt has no (aligned) cached image side");
-    TokenLinear qp{};
-    if (q_proj) {
-        if (q_proj->K != DIM || q_proj->N != INNER || q_proj->resid.x || q_proj->relu)
-            throw_error("token_to_image_attention: the query projection is 256 -> 128 without residual");
-        qp = *q_proj;
-    } else if (!q) {
-        throw_error("token_to_image_attention: neither queries nor their projection given");
-    }
-    hipLaunchKernelGGL(token_to_image_partial_kernel<true>, dim3(P * HEADS * T2I_GROUPS), dim3(T2I_THREADS), 0, s, q, qp, nullptr, k_col,
-                       nullptr, v_col, side, scratch);
+    hipLaunchKernelGGL(token_to_image_partial_kernel, dim3(P * HEADS * T2I_GROUPS), dim3(T2I_THREADS), 0, s, q, qp, K, ldk, V,
+                       ldv, scratch);
 }
 
 void output_heads(const float* scratch, const TokenLinear& out, const float* out_wt, const TokenRows& norm,

@@ -46,14 +46,8 @@ struct ImageUpdate {
     const half_t* W; const float* bias;
     const float* ln_w; const float* ln_b; float eps;
     float* keys; half_t* keys_h;
-    // SIDE (block 0 with the cached projections, kernels.hpp ImageSide0): q = columns ldq .. of side.base[p]; the keys that go
-    // in are emb[p] + no_mask, added here exactly as decoder_start would have (one fp32 addition)
-    k::ImageSide0 side;
-    const float* emb[k::kDecoderMaxPrompts];
-    const float* no_mask;
 };
 
-template <bool SIDE>
 __global__ __launch_bounds__(256) void image_update_kernel(ImageUpdate a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* w_lds = reinterpret_cast<half_t*>(smem);                                   // [256][IU_WSTRIDE]
@@ -79,19 +73,13 @@ __global__ __launch_bounds__(256) void image_update_kernel(ImageUpdate a) {
         kvreg[1] = reinterpret_cast<const float4_t*>(a.tv + (size_t)p * TOK * INNER)[tid];
     }
     const float c0 = a.bias[tid], c1 = a.ln_w[tid], c2 = a.ln_b[tid];
-    const size_t row_in_image = row - (size_t)p * NTOK_IMG;
-    const half_t* qr = SIDE ? a.side.base[p] + row_in_image * k::kImageSide0Cols + a.ldq + 32 * g : a.q + row * a.ldq + 32 * g;
+    const half_t* qr = a.q + row * a.ldq + 32 * g;
     half8_t q8[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) q8[i] = *reinterpret_cast<const half8_t*>(qr + 8 * i);
     f32x4 res[16];
-    const float* keys_in = SIDE ? a.emb[p] + row_in_image * DIM : a.keys + row * DIM;
 #pragma unroll
-    for (int jt = 0; jt < 16; ++jt) res[jt] = *reinterpret_cast<const f32x4*>(keys_in + jt * 16 + 4 * g);
-    if (SIDE) {
-#pragma unroll
-        for (int jt = 0; jt < 16; ++jt) res[jt] += *reinterpret_cast<const f32x4*>(a.no_mask + jt * 16 + 4 * g);
-    }
+    for (int jt = 0; jt < 16; ++jt) res[jt] = *reinterpret_cast<const f32x4*>(a.keys + row * DIM + jt * 16 + 4 * g);
 
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -413,27 +401,9 @@ void image_update(const half_t* q, int ldq, const float* tk, const float* tv, co
     if (ldq % 8 || (((uintptr_t)q | (uintptr_t)W | (uintptr_t)keys | (uintptr_t)keys_h) & 15))
         throw_error("image_update: operands must be 16-byte aligned");
     static k::LdsOptIn opt_in;
-    opt_in.ensure((const void*)image_update_kernel<false>, IU_LDS, "image_update: the device refuses the kernel's LDS size");
-    ImageUpdate a{q, ldq, tk, tv, W, bias, ln_w, ln_b, eps, keys, keys_h, {}, {}, nullptr};
-    hipLaunchKernelGGL(image_update_kernel<false>, dim3(P * NTOK_IMG / IU_ROWS), dim3(256), IU_LDS, s, a);
-}
-
-void image_update(const ImageSide0& side, int q_col, const DecoderPrompts& prompts, const float* no_mask, const float* tk,
-                  const float* tv, const half_t* W, const float* bias, const float* ln_w, const float* ln_b, float eps,
-                  float* keys, half_t* keys_h, int P, hipStream_t s) {
-    if (P <= 0) return;
-    if (P > kDecoderMaxPrompts || q_col < 0 || q_col % 8 || q_col + INNER > kImageSide0Cols || !no_mask ||
-        (((uintptr_t)W | (uintptr_t)keys | (uintptr_t)keys_h | (uintptr_t)no_mask) & 15))
-        throw_error("image_update: bad arguments of the cached-projection form");
-    ImageUpdate a{nullptr, q_col, tk, tv, W, bias, ln_w, ln_b, eps, keys, keys_h, side, {}, no_mask};
-    for (int i = 0; i < P; ++i) {
-        if (!side.base[i] || !prompts.emb[i] || (((uintptr_t)side.base[i] | (uintptr_t)prompts.emb[i]) & 15))
-            throw_error("image_update: a prompt has no (aligned) embedding or cached image side");
-        a.emb[i] = prompts.emb[i];
-    }
-    static k::LdsOptIn opt_in;
-    opt_in.ensure((const void*)image_update_kernel<true>, IU_LDS, "image_update: the device refuses the kernel's LDS size");
-    hipLaunchKernelGGL(image_update_kernel<true>, dim3(P * NTOK_IMG / IU_ROWS), dim3(256), IU_LDS, s, a);
+    opt_in.ensure((const void*)image_update_kernel, IU_LDS, "image_update: the device refuses the kernel's LDS size");
+    ImageUpdate a{q, ldq, tk, tv, W, bias, ln_w, ln_b, eps, keys, keys_h};
+    hipLaunchKernelGGL(image_update_kernel, dim3(P * NTOK_IMG / IU_ROWS), dim3(256), IU_LDS, s, a);
 }
 
 

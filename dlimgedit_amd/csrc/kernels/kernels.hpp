@@ -168,17 +168,9 @@ struct DecoderPrompts {
     float labels[kDecoderMaxPrompts * 2];
     const float* emb[kDecoderMaxPrompts];
 };
-// Block 0's image-side projections do not depend on the prompt (r06): [K of token->image | Q of image->token | V of
-// token->image] = [(keys + pos) Wk | (keys + pos) Wq | keys Wv] with keys = embedding + no_mask_embed is a function of the
-// image alone, so process() computes it once per image (SamModel::encode) and keeps it beside the embedding: f16
-// [4096][kImageSide0Cols].  A decode that is given these per-prompt matrices skips the first image-side GEMM and the
-// initialisation of the keys (block 0's image_update reads embedding + no_mask_embed itself).
-constexpr int kImageSide0Cols = 384;
-struct ImageSide0 { const half_t* base[kDecoderMaxPrompts]; };      // per prompt: its image's matrix; base[0] == nullptr: none
 // First launch of a decode.  tokens [P,7,256]: iou token, 4 mask tokens, 2 prompt tokens (the positional part later steps
 // add); `first` (n_first <= 5 layers, K = 256, no LayerNorm / residual; their `in` is ignored) are applied to those same
-// rows in this launch.  Image side: keys = emb[p] + no_mask (fp32 + f16) for all prompts -- unless keys == nullptr (the
-// decode has the cached block-0 projections, see ImageSide0).
+// rows in this launch.  Image side: keys = emb[p] + no_mask (fp32 + f16) for all prompts.
 void decoder_start(const DecoderPrompts& prompts, const float* gauss, const float* point_embed, const float* not_a_point,
                    const float* iou_token, const float* mask_tokens, float* tokens, const TokenLinear* first, int n_first,
                    const float* no_mask, float* keys, half_t* keys_h, int P, hipStream_t s);
@@ -193,9 +185,6 @@ void token_self_attention_out(const float* q, const float* k, const float* v, co
 // next.in's LayerNorm of out.Y) or output_heads.
 void token_to_image_partials(const float* q, const TokenLinear* q_proj, const half_t* K, int ldk, const half_t* V, int ldv,
                              float* scratch, int P, hipStream_t);
-// the same with prompt p's keys / values in ITS image's cached matrix: columns k_col .. + 127 and v_col .. + 127 of side.base[p]
-void token_to_image_partials(const float* q, const TokenLinear* q_proj, const ImageSide0& side, int k_col, int v_col,
-                             float* scratch, int P, hipStream_t);
 void token_merge_linear(const float* scratch, const TokenLinear& out, const float* out_wt, const TokenLinear& next, int P,
                         hipStream_t);
 // The image positions' half of a two-way block in one launch (kernels/decoder_image.hip):
@@ -203,11 +192,6 @@ void token_merge_linear(const float* scratch, const TokenLinear& out, const floa
 // tk / tv: fp32 [P][7][128], W: f16 [256][128].
 void image_update(const half_t* q, int ldq, const float* tk, const float* tv, const half_t* W, const float* bias,
                   const float* ln_w, const float* ln_b, float eps, float* keys, half_t* keys_h, int P, hipStream_t);
-// Block 0 with the cached projections: q = columns q_col .. + 127 of side.base[p], and the keys that go IN are
-// prompts.emb[p] + no_mask (what decoder_start would have written); keys / keys_h are written only.
-void image_update(const ImageSide0& side, int q_col, const DecoderPrompts& prompts, const float* no_mask, const float* tk,
-                  const float* tv, const half_t* W, const float* bias, const float* ln_w, const float* ln_b, float eps,
-                  float* keys, half_t* keys_h, int P, hipStream_t);
 // Up-scaling path + mask product in one launch (kernels/decoder_image.hip): logits [P,4,256,256] from the f16 keys, the two
 // transposed convolutions as GEMM weights (W1 [256][256], rows = sub-pixel * 64 + channel; W2 [128][64], rows = sub-pixel * 32
 // + channel), the LayerNorm2d between them and the hyper vectors [P,4,32].

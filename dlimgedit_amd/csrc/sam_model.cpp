@@ -808,29 +808,6 @@ void SamModel::encode(int batch, float* const* emb_dst) {
             if (emb_dst[i])
                 HIP_CHECK(hipMemcpyAsync(emb_dst[i], emb_.get() + i * n, n * sizeof(float), hipMemcpyDeviceToDevice, stream_));
     }
-    // Handles (emb_dst given): block 0 of the mask decoder projects the image positions before any prompt is involved --
-    // [K | Q | V] = [(keys + pos) Wk | (keys + pos) Wq | keys Wv], keys = embedding + no_mask_embed -- so it is computed here,
-    // once per image, and kept behind the embedding (image_side0): the same f16 keys, the same GEMM on the same tile as
-    // the decode's own first image-side GEMM (the tile is chosen per 4096-row unit), hence the same bits, and every
-    // prompt on this image saves that GEMM and the 10 MB key initialisation (config 5: five prompts per image).
-    if (emb_dst) {
-        reserve_decoder(batch);
-        DecoderLayer const& L0 = W.dec_[0];
-        const size_t n = (size_t)kTokens * kEmbedDim;
-        timed(ST_DECODER, (double)batch * 2.0 * kTokens * k::kImageSide0Cols * kEmbedDim, [&] {
-            k::add_cast(direct ? direct : emb_.get(), W.pe_no_mask_.get(), kEmbedDim, n * batch, nullptr, keys_h_.get(), stream_);
-            for (int i = 0; i < batch; ++i) {
-                if (!emb_dst[i]) continue;
-                k::GemmArgs s0;
-                s0.A = keys_h_.get() + i * n; s0.lda = kEmbedDim; s0.W = L0.img_kqv.w.get(); s0.ldw = kEmbedDim; s0.bias = L0.img_kqv.b.get();
-                s0.resid = L0.pos_kqv.get(); s0.ldr = L0.img_kqv.out; s0.resid_mod = kTokens;
-                s0.out_h = image_side0(emb_dst[i]); s0.ldc16 = L0.img_kqv.out; s0.M = kTokens; s0.N = L0.img_kqv.out; s0.K = kEmbedDim;
-                s0.shared_gpu = shared_gpu_;
-                s0.unit_rows = kTokens;
-                k::gemm(s0, stream_);
-            }
-        });
-    }
     HIP_CHECK(hipGetLastError());     // a refused launch (bad grid, LDS size) is reported here, not at a later sync
     mark_activity();                  // behind the last kernel of the pass
 }
@@ -863,22 +840,18 @@ void SamModel::reserve_decoder(int count) {
     dec_count_ = count;
 }
 
-void SamModel::decode(float const* const* emb, float const* coords, float const* labels, int count, bool cached_side0) {
+void SamModel::decode(float const* const* emb, float const* coords, float const* labels, int count) {
     DLIMG_ASSERT(count > 0);
     reserve_decoder(count);
-    // measurement / test aid, read per call: DLIMGEDIT_DECODER_CACHE=0 decodes without the cached projections (same bits)
-    if (cached_side0)
-        if (const char* e = std::getenv("DLIMGEDIT_DECODER_CACHE")) cached_side0 = std::atoi(e) != 0;
     // the token-side kernels take at most 16 prompts (112 rows) per launch: larger requests run in chunks that share
     // the workspaces (stream order) and write their own part of logits() / iou()
     constexpr int kChunk = 16;
     for (int c0 = 0; c0 < count; c0 += kChunk)
-        decode_chunk(emb + c0, coords + (size_t)c0 * 4, labels + (size_t)c0 * 2, std::min(kChunk, count - c0), c0, cached_side0);
+        decode_chunk(emb + c0, coords + (size_t)c0 * 4, labels + (size_t)c0 * 2, std::min(kChunk, count - c0), c0);
     mark_activity();
 }
 
-void SamModel::decode_chunk(float const* const* emb, float const* coords, float const* labels, int count, int first,
-                            bool cached_side0) {
+void SamModel::decode_chunk(float const* const* emb, float const* coords, float const* labels, int count, int first) {
     SamWeights const& W = *weights_;
     const int P = count, M = P * kTokens, T = P * kDecTokens;
     hipStream_t s = stream_;
@@ -890,11 +863,7 @@ void SamModel::decode_chunk(float const* const* emb, float const* coords, float 
         k::DecoderPrompts prompts{};
         std::memcpy(prompts.coords, coords, (size_t)P * 4 * sizeof(float));
         std::memcpy(prompts.labels, labels, (size_t)P * 2 * sizeof(float));
-        k::ImageSide0 side0{};
-        for (int i = 0; i < P; ++i) {
-            prompts.emb[i] = emb[i];
-            if (cached_side0) side0.base[i] = image_side0(emb[i]);
-        }
+        for (int i = 0; i < P; ++i) prompts.emb[i] = emb[i];
 
         // Token side.  `cur` is the running token matrix as its consumers read it: un-normalised rows plus the
         // LayerNorm that belongs in front of them (applied on the fly by whoever reads, kernels/decoder.hip).
@@ -930,8 +899,7 @@ void SamModel::decode_chunk(float const* const* emb, float const* coords, float 
             k::TokenLinear qkv[3] = {lin({}, 256, L.self_attn.q, {}, sq_.get(), 0), lin({}, 256, L.self_attn.k, {}, sk_.get(), 0),
                                      lin({}, 256, L.self_attn.v, {}, sv_.get(), 0)};
             k::decoder_start(prompts, W.pe_gauss_.get(), W.pe_point_.get(), W.pe_not_a_point_.get(), W.iou_token_.get(),
-                             W.mask_tokens_.get(), tokens_.get(), qkv, 3, W.pe_no_mask_.get(), cached_side0 ? nullptr : keys_.get(),
-                             cached_side0 ? nullptr : keys_h_.get(), P, s);
+                             W.mask_tokens_.get(), tokens_.get(), qkv, 3, W.pe_no_mask_.get(), keys_.get(), keys_h_.get(), P, s);
         }
         for (int i = 0; i < 2; ++i) {
             DecoderLayer const& L = W.dec_[i];
@@ -942,11 +910,9 @@ void SamModel::decode_chunk(float const* const* emb, float const* coords, float 
             const k::TokenRows q1 = normed(tsa_.get(), L.ln1);
             // (2) tokens -> image: [K | Q of step 4 | V] = [(keys + pos) Wk | (keys + pos) Wq | keys Wv]; the query
             // projection runs inside the attention launch, the fold + output projection inside the MLP's first launch
-            const bool cached = cached_side0 && i == 0;      // block 0: the projections came with the embedding (encode())
-            if (!cached) img_gemm(L.img_kqv, L.pos_kqv);
+            img_gemm(L.img_kqv, L.pos_kqv);
             const k::TokenLinear tq = lin(rows_of(q1, true), 256, L.t2i_q, {}, nullptr, 0);
-            if (cached) k::token_to_image_partials(nullptr, &tq, side0, 0, 256, t2i_part_.get(), P, s);
-            else k::token_to_image_partials(nullptr, &tq, kqv_h_.get(), 384, kqv_h_.get() + 256, 384, t2i_part_.get(), P, s);
+            k::token_to_image_partials(nullptr, &tq, kqv_h_.get(), 384, kqv_h_.get() + 256, 384, t2i_part_.get(), P, s);
             const k::TokenRows q2 = normed(tt2i_.get(), L.ln2);
             // (3) token MLP
             k::token_merge_linear(t2i_part_.get(), lin({}, 128, L.t2i_o, q1, tt2i_.get(), 0), L.t2i_o_t.get(),
@@ -968,12 +934,8 @@ void SamModel::decode_chunk(float const* const* emb, float const* coords, float 
                 kv[n_ops++] = lin(rows_of(q3, true), 256, W.final_q_, {}, sq_.get(), 0);
             }
             k::token_linears(kv, n_ops, T, s);
-            if (cached)
-                k::image_update(side0, 128, prompts, W.pe_no_mask_.get(), tk_.get(), tv_.get(), L.i2t_o.w.get(), L.i2t_o.b.get(),
-                                L.ln4.w.get(), L.ln4.b.get(), kDecLnEps, keys_.get(), keys_h_.get(), P, s);
-            else
-                k::image_update(kqv_h_.get() + 128, 384, tk_.get(), tv_.get(), L.i2t_o.w.get(), L.i2t_o.b.get(), L.ln4.w.get(),
-                                L.ln4.b.get(), kDecLnEps, keys_.get(), keys_h_.get(), P, s);
+            k::image_update(kqv_h_.get() + 128, 384, tk_.get(), tv_.get(), L.i2t_o.w.get(), L.i2t_o.b.get(), L.ln4.w.get(),
+                            L.ln4.b.get(), kDecLnEps, keys_.get(), keys_h_.get(), P, s);
             cur = q3;
         }
         // final token -> image attention; its fold + output projection + norm_final_attn happen in output_heads

@@ -182,15 +182,7 @@ class SamModel {
 
     // Decoder for `count` prompts. emb[i]: device embedding of prompt i's image; coords [count][2][2],
     // labels [count][2] host arrays. Results stay on device: logits() [count][4][256][256], iou() [count][4].
-    // cached_side0: every emb[i] is an embedding buffer of a Segmentation handle (EmbeddingPool) behind which encode() left
-    // block 0's image-side projections of that image (image_side0): the decode skips their GEMM and the key initialisation.
-    // Same bits either way (tests/test_gpu_e2e.py).
-    void decode(float const* const* emb, float const* coords, float const* labels, int count, bool cached_side0 = false);
-    // Where the block-0 image-side projections of an embedding buffer live: f16 [4096][k::kImageSide0Cols] right behind the
-    // [4096][256] fp32 embedding (EmbeddingPool allocates both in one piece)
-    static constexpr size_t kEmbeddingBufferBytes = (size_t)kTokens * kEmbedDim * sizeof(float) + (size_t)kTokens * k::kImageSide0Cols * sizeof(half_t);
-    static half_t* image_side0(float* emb) { return reinterpret_cast<half_t*>(emb + (size_t)kTokens * kEmbedDim); }
-    static half_t const* image_side0(float const* emb) { return reinterpret_cast<half_t const*>(emb + (size_t)kTokens * kEmbedDim); }
+    void decode(float const* const* emb, float const* coords, float const* labels, int count);
     float const* logits() const { return logits_.get(); }
     // Diagnostic: the token-side workspaces as the last decode of ONE prompt left them (after synchronize()), one after
     // the other; names/sizes in decoder_state_layout().  What a parity or race hunt compares stage by stage.
@@ -248,7 +240,7 @@ class SamModel {
   private:
     void reserve_encoder(int batch);
     void reserve_decoder(int count);
-    void decode_chunk(float const* const* emb, float const* coords, float const* labels, int count, int first, bool cached_side0);
+    void decode_chunk(float const* const* emb, float const* coords, float const* labels, int count, int first);
     void gemm(k::GemmArgs const& a, Stage shape = ST_COUNT);     // shape: ST_GEMM_PATCH / _PROJ / _FC2 for the stage clocks
     template <typename F> void timed(Stage st, double work, F&& launch);
     void flush_events();

@@ -352,7 +352,7 @@ void SegmentationImpl::compute_mask(Point const* point, Region const* region, ui
             float const* emb = embedding_;
             {
                 roctx::Range rd("dlimg.decode");
-                model_.decode(&emb, coords, labels, 1, /*cached_side0=*/true);
+                model_.decode(&emb, coords, labels, 1);
             }
             if (is_single_mask) {
                 // single-mask decoder: best of the four by SamOnnxModel.select_masks, chosen on the device
@@ -437,7 +437,7 @@ void SegmentationImpl::compute_mask_batch(SegmentationImpl const* const* segs, i
                 Chunk& cur = chunks.back();
                 roctx::Range range("dlimg.compute_masks");
                 std::lock_guard<std::mutex> lock(model.mutex());
-                model.decode(emb.data(), cc.data(), ll.data(), n, /*cached_side0=*/true);
+                model.decode(emb.data(), cc.data(), ll.data(), n);
                 for (int j = 0; j < n; ++j) {
                     const int i = mine[base + j];
                     const Extent o = segs[i]->image_size_.original, r = segs[i]->image_size_.resized;
@@ -532,7 +532,7 @@ void SegmentationImpl::compute_mask_batch_device(SegmentationImpl const* const* 
                 chunks.push_back(Chunk{&model, &model.acquire_mask_slot()});
                 roctx::Range range("dlimg.compute_masks_device");
                 std::lock_guard<std::mutex> lock(model.mutex());
-                model.decode(emb.data(), cc.data(), ll.data(), n, /*cached_side0=*/true);
+                model.decode(emb.data(), cc.data(), ll.data(), n);
                 for (int j = 0; j < n; ++j) {
                     const int i = mine[base + j];
                     const Extent o = segs[i]->image_size_.original, r = segs[i]->image_size_.resized;

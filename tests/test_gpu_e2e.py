@@ -105,41 +105,6 @@ def test_repeated_queries_are_deterministic(api, session):
     assert np.array_equal(a, b)
 
 
-def test_cached_block0_image_side_gives_the_same_bits(api, session, monkeypatch):
-    """process() leaves block 0's image-side projections ([K | Q | V] of embedding + no_mask_embed, prompt-independent)
-    behind the embedding, and every decode on a handle uses them instead of recomputing them (r06).  The decode WITHOUT them
-    (DLIMGEDIT_DECODER_CACHE=0, the path the device-resident entry point takes) must give the same logits, IoU predictions,
-    token-side workspaces and masks bit for bit: one prompt, five prompts on one image in one call, a batch of images,
-    a resized image, multi-mask mode."""
-    env, _, _, img, seg, _ = session
-    tall = api.Segmentation.process(api.ImageView(synthetic_image(4, width=640, height=960), api.Channels.rgba), env)
-    batch = api.Segmentation.process_batch([api.ImageView(synthetic_image(i), api.Channels.rgba) for i in (5, 6, 7)], env)
-    five = [api.Point(120 + 170 * j, 900 - 190 * j) for j in range(5)]
-
-    def everything():
-        out = list(api.ext.get_logits(seg, point=api.Point(300, 700)))
-        out += list(api.ext.get_logits(seg, region=api.Region(api.Point(100, 200), api.Point(800, 900))))
-        out += [v for _, v in sorted(api.ext.decoder_state(seg, api.Point(640, 320)).items())]
-        out.append(seg.compute_mask(api.Point(300, 700)))
-        out += api.Segmentation.compute_mask_batch([seg] * 5, points=five)
-        out += api.Segmentation.compute_mask_batch(batch + [tall], points=[api.Point(400, 400)] * 4)
-        out.append(tall.compute_mask(api.Region(api.Point(50, 60), api.Point(600, 900))))
-        for m in seg.compute_masks(api.Point(512, 512)):
-            out += [m.image, np.float32(m.accuracy)]
-        return out
-
-    with_cache = everything()
-    monkeypatch.setenv("DLIMGEDIT_DECODER_CACHE", "0")
-    without = everything()
-    monkeypatch.delenv("DLIMGEDIT_DECODER_CACHE")
-    assert len(with_cache) == len(without) > 20
-    for a, b in zip(with_cache, without):
-        assert np.array_equal(np.asarray(a), np.asarray(b))
-    assert np.array_equal(np.asarray(everything()[0]), np.asarray(with_cache[0]))
-    for sg in batch + [tall]:
-        sg.close()
-
-
 def test_batch_entry_points(api, session):
     """process_images_for_segmentation / get_segmentation_masks equal the one-at-a-time calls."""
     env, *_ = session

@@ -8,7 +8,7 @@
 #   tools/ab_env.sh "DLIMGEDIT_TUNING_LIB=libdlimgedit_head.so" ""     a copy of another build (lib/libdlimgedit_head.so) / this one
 # Per run: images/s, every GEMM flavour's time alone on the chip and under the lanes (a change can hide in one and not in
 # the other), the decode and ABI figures when bench.py measured them.
-ROUNDS=3; BENCH="--steps 20 --warmup 5 --no-cpu-baseline"
+ROUNDS=3; BENCH="--steps 20 --warmup 5 --no-cpu-baseline --no-config-legs"
 while getopts "r:b:" o; do case $o in r) ROUNDS=$OPTARG;; b) BENCH=$OPTARG;; esac; done
 shift $((OPTIND - 1))
 mkdir -p gpurun_out/ab_env
