@@ -112,8 +112,7 @@ class EnvironmentImpl {
     // pass fills the chip by itself where a two-image pass does not (768 workgroups of global attention = three full
     // rounds of the 256 CUs instead of 1.5; 192-tile stream writers), so fewer passes have to share the chip to fill
     // it: 4 lanes x 2 images 866-886 images/s, 3 x 4 882-902 on the same boxes, 4 x 4 851-867 (five passes of a 20-request
-    // block over four lanes end 2 / 1 / 1 / 1).  The larger models are not sensitive (ViT-H 167-168 either way) and keep
-    // two images per pass.  step_lanes = 0: every lane.  DLIMGEDIT_COALESCE / DLIMGEDIT_STEP_LANES / DLIMGEDIT_STEP_DEPTH.
+    // block over four lanes end 2 / 1 / 1 / 1).  ViT-H: three, ViT-L: four per pass on two lanes (r06, ext_api.cpp step_queue_width).  step_lanes = 0: every lane.  DLIMGEDIT_COALESCE / DLIMGEDIT_STEP_LANES / DLIMGEDIT_STEP_DEPTH.
     int coalesce = 0;                                  // 0 = chosen from the model when its lanes are created
     int step_lanes = -1;                               // -1 = likewise
     int step_depth = 2;

@@ -236,15 +236,22 @@ void run_device_steps(EnvironmentImpl& env, int lane, EnvironmentImpl::PendingSt
 // Forgets the passes that have finished and returns the lanes requests are spread over.
 // lanes the step queue deals its passes to, and its pass width: the environment's settings, or the model's defaults
 // (environment.hpp: ViT-B four images per pass on three lanes, larger models two images on every lane)
+// (defaults by model width, measured on MI355X with the official 20-step block and with 50-step blocks: ViT-B four images
+// per pass on three of its four lanes (r05); ViT-H THREE per pass on TWO of its three lanes (r06: 168.3-168.8 -> 171.1-171.2
+// images/s on one box, 166.6-167.0 -> 169.9-170.6 on another; 2 x 2: +0.7 %, 4 / 5 / 6 / 10 per pass and one or three lanes:
+// no better than the old two per pass on every lane) -- three images give its N = 1280 stream writers 240 tiles of the 256
+// CUs where two give 160; ViT-L FOUR per pass on two lanes (256 tiles for its N = 1024 stream writers: 333.6-335.8 -> 342.5-346.0))
 int step_queue_lanes(EnvironmentImpl& env) {
     const int lanes = std::max(1, env.effective_lane_count(0));
     int want = env.step_lanes;
-    if (want < 0) want = env.lane(0, 0).geometry().embed_dim <= 768 ? 3 : 0;
+    const int width = env.lane(0, 0).geometry().embed_dim;
+    if (want < 0) want = width <= 768 ? 3 : 2;
     return want > 0 ? std::min(lanes, want) : lanes;
 }
 int step_queue_width(EnvironmentImpl& env) {
     if (env.coalesce > 0) return env.coalesce;
-    return env.lane(0, 0).geometry().embed_dim <= 768 ? 4 : 2;
+    const int width = env.lane(0, 0).geometry().embed_dim;
+    return width >= 1280 ? 3 : 4;
 }
 
 int retire_device_steps(EnvironmentImpl& env) {

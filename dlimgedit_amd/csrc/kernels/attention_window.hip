@@ -138,7 +138,11 @@ __global__ __launch_bounds__(448, 4) void attention_window_kernel(const half_t* 
     // (head dimension 80: the last two of a thread's five pieces are requested after the rel-pos products, when the
     // tables' fragments are dead -- with all five in front the kernel does not fit 128 registers, and a spilled load
     // result is a wait for that load in the middle of the request phase: 12 k cycles measured)
+#if defined(DLIMG_TUNING) && defined(DLIMG_WINDOW_KV_EARLY)      // A/B of the split, tuning build only
+    constexpr int KV_EARLY = HD == 64 ? KV_IT : DLIMG_WINDOW_KV_EARLY;
+#else
     constexpr int KV_EARLY = HD == 64 ? KV_IT : 3;
+#endif
     half8_t kreg[KV_IT], vreg[KV_IT];
     auto request_kv = [&](int it) {
         const int idx = tid + it * 448;

@@ -311,3 +311,48 @@ def test_step_queue_with_and_without_enqueue_threads(model_dirs, workers, monkey
     finally:
         for p in ptrs + mptrs:
             ext.device_free(env, p)
+
+
+def test_concurrent_callers_of_a_multi_replica_environment_keep_their_own_helpers(model_dirs, monkeypatch):
+    """A call that spans several replicas feeds the first from the calling thread and the others from helper threads that
+    thread keeps from call to call (csrc/segmentation.cpp, for_each_replica; r06).  Three host threads, each making several
+    batch calls on ONE environment with three replicas (GPU 0 listed three times), must get the answers of a one-replica
+    environment bit for bit -- helpers are per caller, nobody waits in anybody's queue, and a caller thread that ends takes
+    its helpers with it."""
+    from dlimgedit_amd import api
+    mdir, _, _ = model_dirs("vit_test")
+    one = api.Environment(api.Options(api.Backend.gpu, mdir))
+    monkeypatch.setenv("DLIMGEDIT_DEVICES", "0,0,0")
+    three = api.Environment(api.Options(api.Backend.gpu, mdir))
+    monkeypatch.delenv("DLIMGEDIT_DEVICES")
+    assert api.ext.replica_count(three) == 3
+    imgs = [synthetic_image(80 + i) for i in range(7)]
+    views = [api.ImageView(im, api.Channels.rgba) for im in imgs]
+    pts = [api.Point(90 + 120 * i, 950 - 110 * i) for i in range(7)]
+    ref_segs = api.Segmentation.process_batch(views, one)
+    want_emb = [api.ext.get_embedding(s) for s in ref_segs]
+    want_mask = api.Segmentation.compute_mask_batch(ref_segs, points=pts)
+    errors = []
+
+    def caller(k):
+        try:
+            for round_ in range(3):
+                segs = api.Segmentation.process_batch(views, three)
+                used = {api.ext.segmentation_device(s)[0] for s in segs}
+                assert used == {0, 1, 2}
+                masks = api.Segmentation.compute_mask_batch(segs, points=pts)
+                for s, e, m, w in zip(segs, want_emb, masks, want_mask):
+                    assert np.array_equal(api.ext.get_embedding(s), e) and np.array_equal(m, w), (k, round_)
+                for s in segs:
+                    s.close()
+        except Exception as ex:                  # noqa: BLE001 -- reported by the main thread
+            errors.append(repr(ex))
+
+    threads = [threading.Thread(target=caller, args=(k,)) for k in range(3)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+    for s in ref_segs:
+        s.close()
+    three.close()
+    one.close()

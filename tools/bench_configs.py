@@ -73,6 +73,20 @@ with tempfile.TemporaryDirectory() as d:
     print(f"{variant}: config 5 share (mixed resolution -> device resize, 5 prompts/image on the cached embedding), "
           f"{lanes} threads: {r:8.1f} img/s = {5 * r:8.1f} masks/s")
 
+    # the same share as ONE batch per call, the form BASELINE config 5 names (16 images per GPU): slot 13 with 16 mixed-resolution
+    # images, then slot 14 with their 80 prompts (bench.py's `configs.*.config5_share`)
+    sizes16 = [sizes[i % len(sizes)] for i in range(16)]
+    mixed16 = [api.ImageView(synthetic_image(10 + i, width=w, height=h), api.Channels.rgba) for i, (w, h) in enumerate(sizes16)]
+    pts80 = [api.Point(int(w * fx), int(h * fy)) for (w, h) in sizes16 for fx, fy in ((.5, .5), (.25, .33), (.75, .2), (.6, .8), (.1, .9))]
+    def mixed16_batch(_):
+        segs = api.Segmentation.process_batch(mixed16, env)
+        api.Segmentation.compute_mask_batch([sg for sg in segs for _ in range(5)], points=pts80)
+        return 16
+    for nt in sorted({1, 2, 3, lanes}):
+        r = run_threads(nt, mixed16_batch)
+        print(f"{variant}: config 5 share as batches (16 mixed-resolution images per call through slot 13, 80 prompts through slot 14), "
+              f"{nt} thread(s): {r:8.1f} img/s = {5 * r:8.1f} masks/s")
+
     # the decode half of config 5 alone: prompts on embeddings that are already cached (the interactive use of the library)
     cached = [api.Segmentation.process(v, env) for v in mixed]
     def prompts_on_cached(i):
