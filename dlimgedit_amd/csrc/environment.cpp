@@ -147,8 +147,17 @@ int EnvironmentImpl::device_count() noexcept {
     return count;
 }
 
+// A consumer of the reference that default-constructs Options asks for Backend::cpu (the reference's default,
+// /root/reference/src/include/dlimgedit/dlimgedit.hpp:91) and cannot be recompiled by whoever swaps the library in.  This
+// build has no CPU execution path and will not pretend to: the request is refused -- unless the DEPLOYER says, outside the
+// consumer, that such requests are to run on the GPU: DLIMGEDIT_CPU_REQUESTS_ON_GPU=1.  Read per call (tests switch it).
+static bool cpu_requests_run_on_gpu() noexcept {
+    const char* e = std::getenv("DLIMGEDIT_CPU_REQUESTS_ON_GPU");
+    return e && std::atoi(e) != 0;
+}
+
 bool EnvironmentImpl::is_supported(dlimg_Backend backend) noexcept {
-    if (backend != dlimg_gpu) return false;   // no CPU execution path in this build
+    if (backend != dlimg_gpu && !(backend == dlimg_cpu && cpu_requests_run_on_gpu())) return false;   // no CPU execution path in this build
     static const bool ok = [] {
         if (device_count() <= 0) return false;
         hipDeviceProp_t prop;
@@ -192,8 +201,10 @@ EnvironmentImpl::EnvironmentImpl(dlimg_Options const& options) : backend(options
     if (ec || !fs::exists(p)) throw Exception(std::string("Model path ") + dir + " does not exist");
     if (!fs::is_directory(p)) throw Exception(std::string("Model path ") + dir + " is not a directory");
     model_directory = p;
+    if (backend == dlimg_cpu && cpu_requests_run_on_gpu()) backend = dlimg_gpu;      // the deployer's decision, not the consumer's
     if (backend != dlimg_gpu)
-        throw Exception("The CPU backend is not available in the MI355X build of dlimgedit; use Backend::gpu");
+        throw Exception("The CPU backend is not available in the MI355X build of dlimgedit; use Backend::gpu (a deployer who "
+                        "cannot change the consumer sets DLIMGEDIT_CPU_REQUESTS_ON_GPU=1: Backend::cpu requests then run on the GPU)");
     if (!is_supported(dlimg_gpu)) throw Exception("No supported GPU (gfx950) found for Backend::gpu");
     // Device list: DLIMGEDIT_DEVICES ("0,1,2" or "all") wins over DLIMGEDIT_DEVICE (one index); default device 0.
     std::vector<int> devices;

@@ -139,6 +139,21 @@ def test_environment_errors_are_reported_through_last_error(api, tmp_path):
         api.Environment(api.Options(api.Backend.cpu, str(tmp_path)))
 
 
+def test_cpu_requests_can_be_sent_to_the_gpu_by_the_deployer(api, tmp_path, monkeypatch):
+    """The reference's default Options ask for Backend::cpu (/root/reference/src/include/dlimgedit/dlimgedit.hpp:91); this build
+    has no CPU path and refuses -- unless the deployer, who cannot recompile the consumer, sets DLIMGEDIT_CPU_REQUESTS_ON_GPU=1:
+    then such a request is a GPU request (here, without a GPU, it gets the GPU path's own answer, not the CPU refusal)."""
+    monkeypatch.setenv("DLIMGEDIT_CPU_REQUESTS_ON_GPU", "1")
+    assert api.Environment.is_supported(api.Backend.cpu) == api.Environment.is_supported(api.Backend.gpu)
+    if not api.Environment.is_supported(api.Backend.gpu):
+        with pytest.raises(api.Error, match="No supported GPU"):
+            api.Environment(api.Options(api.Backend.cpu, str(tmp_path)))
+    monkeypatch.setenv("DLIMGEDIT_CPU_REQUESTS_ON_GPU", "0")
+    assert api.Environment.is_supported(api.Backend.cpu) is False
+    with pytest.raises(api.Error, match="CPU backend is not available"):
+        api.Environment(api.Options(api.Backend.cpu, str(tmp_path)))
+
+
 def test_image_file_slots_work_without_a_gpu(api, tmp_path):
     """load_image / save_image are host code (PNG; tests/test_image_io.py has the details)."""
     import numpy as np

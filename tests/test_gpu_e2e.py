@@ -160,6 +160,22 @@ def test_folded_and_separate_layernorm_agree(api, session, model_dirs, monkeypat
              IOU_BAR)
 
 
+def test_default_options_consumer_runs_when_the_deployer_allows_it(api, session, model_dirs, monkeypatch):
+    """A consumer that default-constructs Options (Backend::cpu, the reference's default) gets the same masks as a Backend::gpu
+    consumer once the deployer has set DLIMGEDIT_CPU_REQUESTS_ON_GPU=1; without it the request is refused by name."""
+    env, _, _, img, seg, _ = session
+    mdir, _, _ = model_dirs("vit_test")
+    with pytest.raises(api.Error, match="CPU backend is not available"):
+        api.Environment(api.Options(api.Backend.cpu, mdir))
+    monkeypatch.setenv("DLIMGEDIT_CPU_REQUESTS_ON_GPU", "1")
+    cpu_env = api.Environment(api.Options(api.Backend.cpu, mdir))
+    other = api.Segmentation.process(api.ImageView(img, api.Channels.rgba), cpu_env)
+    assert np.array_equal(api.ext.get_embedding(other), api.ext.get_embedding(seg))
+    assert np.array_equal(other.compute_mask(api.Point(300, 400)), seg.compute_mask(api.Point(300, 400)))
+    other.close()
+    cpu_env.close()
+
+
 def test_error_paths(api, session, tmp_path):
     env, *_ = session
     with pytest.raises(api.Error, match="does not exist"):
