@@ -26,9 +26,11 @@ DLIMGEDIT_SAM_MODEL=$MODEL timeout -k 10 250 rocprofv3 --kernel-trace -d $O/ktb 
   grep "images/s" $O/burst.log
   python3 $R/tools/trace_lanes.py $O/ktb/ktb_results.db 2>&1 | tail -5
   python3 $R/tools/lanes_summary.py $O/ktb/ktb_results.db 20 $FLOP; } > $S/lanes_summary.txt 2>&1
-# the timed region alone (bursts + synchronize): no blit copies there -- the one-workgroup __amd_rocclr_copyBuffer launches of the
-# bench trace are the set-up of the hbm_kernels timing loop (16-byte IoU vectors, 256 KB logit planes of its 768 MB ring)
-python3 $R/tools/kernel_stats.py $O/ktb/ktb_results.db 40 > $S/kernel_stats_timed_region.txt 2>&1
+# the burst process as a whole (model load + 8 bursts of 20 requests, no hbm_kernels leg, no ABI legs): its only blit copies
+# (__amd_rocclr_copyBuffer) are the ~170 weight tensors of the model load; the per-block table of lanes_summary.txt -- the
+# timed region proper -- has none.  The one-workgroup copies of the bench trace are the set-up of the hbm_kernels timing loop
+# (16-byte IoU vectors, 256 KB logit planes of its 768 MB ring) and the model load.
+python3 $R/tools/kernel_stats.py $O/ktb/ktb_results.db 40 > $S/kernel_stats_burst_process.txt 2>&1
 python3 $R/tools/kernel_stats.py $O/kt1/kt1_results.db 40 > $S/kernel_stats_single_lane.txt
 python3 $R/tools/kernel_stats.py $O/kt1/kt1_results.db 60 --by-grid > $S/kernel_stats_single_lane_by_grid.txt 2>&1
 python3 $R/tools/pmc_traffic.py $O/pmc_fetch/fetch_results.db $O/pmc_write/write_results.db $S/hbm_traffic_pmc.json "$B" $DEPTH > $S/traffic.log 2>&1
