@@ -265,7 +265,14 @@ LaneWorker& EnvironmentImpl::lane_worker(int replica, int lane) {
     if ((int)workers_.size() < replica_count()) workers_.resize(replica_count());
     auto& row = workers_.at(replica);
     if ((int)row.size() <= lane) row.resize(lane + 1);
-    if (!row[lane]) row[lane] = std::make_unique<LaneWorker>();
+    if (!row[lane]) {
+        row[lane] = std::make_unique<LaneWorker>();
+        // several GPUs in one environment: a lane's enqueue thread works next to its GPU (first task of the new thread)
+        if (replica_count() > 1) {
+            const int device = device_of(replica);
+            row[lane]->post([device] { (void)bind_thread_near_device(device); });
+        }
+    }
     return *row[lane];
 }
 

@@ -1381,8 +1381,11 @@ int gemm_pick_tile(const GemmArgs& a) {
 #ifdef DLIMG_TUNING     // A/B switches of the tuning build only; the product's choice is not steerable from outside
     static const bool use_pp128 = [] { const char* e = std::getenv("DLIMGEDIT_GEMM_PP128"); return !e || std::atoi(e) != 0; }();
     static const bool batch_pp = [] { const char* e = std::getenv("DLIMGEDIT_GEMM_BATCH_PP"); return !e || std::atoi(e) != 0; }();
+    // r06 A/B (the form it proposes): proj -- the stream writer with K = N -- on the 128-row tile, whose
+    // 64 spare registers take the residual before the K loop, while fc2 keeps the 256-row tile
+    static const bool proj128 = [] { const char* e = std::getenv("DLIMGEDIT_GEMM_PROJ128"); return e && std::atoi(e) != 0; }();
 #else
-    constexpr bool use_pp128 = true, batch_pp = true;
+    constexpr bool use_pp128 = true, batch_pp = true, proj128 = false;
 #endif
     if (use_pp128 && shared && forced < 0 && unit % 128 == 0 && a.N % 256 == 0 && (unit / 128) * (a.N / 256) >= 64 &&
         !wraps_inside(128)) {
@@ -1390,6 +1393,7 @@ int gemm_pick_tile(const GemmArgs& a) {
         // -- RowStats, threads per row -- so a consumer that lands in this branch keeps tile 10 whatever the pass looks like;
         // ViT-B / L / H consumers never do: their N gives >= 64 tiles of 256 x 256)
         if (a.ln_stats) return 10;
+        if (proj128 && a.resid_h && a.K == a.N) return 10;
         if (batch_pp && a.M % 256 == 0 && (a.M / 256) * (a.N / 256) >= 96 && !wraps_inside(256)) return 9;
         // one image with the GPU to itself: 64-row tiles while they still fit the chip in one round (ViT-B's patch / proj /
         // fc2: 96 -> 192 workgroups; ViT-H's 160 would become 320, more than one round: stays)
