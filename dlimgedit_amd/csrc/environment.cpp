@@ -105,10 +105,16 @@ int bind_thread_near_device(int device) noexcept {
         if (node.empty() || std::atoi(node.c_str()) < 0) return 0;
         const std::vector<int> cpus = parse_cpu_list(read_line("/sys/devices/system/node/node" + node + "/cpulist"));
         if (cpus.empty()) return 0;
-        cpu_set_t allowed, want;
-        CPU_ZERO(&allowed);
+        // the CPUs the PROCESS may use, captured the first time any thread asks (a thread that was bound near one GPU before
+        // must not intersect the next GPU's node with its own narrowed mask)
+        static cpu_set_t process_allowed;
+        static const bool have_allowed = [] {
+            CPU_ZERO(&process_allowed);
+            return sched_getaffinity(0, sizeof(process_allowed), &process_allowed) == 0;
+        }();
+        if (!have_allowed) return 0;
+        cpu_set_t allowed = process_allowed, want;
         CPU_ZERO(&want);
-        if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return 0;
         int n = 0;
         for (int c : cpus)
             if (c < CPU_SETSIZE && CPU_ISSET(c, &allowed)) {
