@@ -31,7 +31,7 @@ model = sys.argv[1] if len(sys.argv) > 1 else "vit_b"
 seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 3.0
 cfg = get_config(model)
 D, F, H, hd = cfg.embed_dim, cfg.mlp_dim, cfg.num_heads, cfg.head_dim
-IMAGES = 4 if D <= 768 else 2                      # images per pass of the step queue (environment.hpp)
+IMAGES = 4 if D <= 1024 else 3                     # images per pass of the step queue (ext_api.cpp, step_queue_width)
 M = IMAGES * 4096
 n_glob = len(cfg.global_attn_indexes)
 n_win = cfg.depth - n_glob
@@ -112,16 +112,21 @@ import json  # noqa: E402
 steps = 3000 if D <= 768 else 600
 cmd = [sys.executable, str(Path(__file__).resolve().parent.parent / "bench.py"), "--model", model, "--steps", str(steps), "--warmup", "5",
        "--repeats", "3", "--no-cpu-baseline", "--no-abi-path", "--no-config-legs"]
+# sampled from start to end: model load and warm-up draw far less than the timed blocks, so the steady state is read from the
+# samples within 10 % of the highest power seen (their median, with the clock samples taken at the same moments)
 proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
-time.sleep(18 if D <= 768 else 75)                 # model load and warm-up are over, the timed blocks are running
 sampler.start()
-time.sleep(5.0)
-w, wmax, mhz, n = sampler.stop()
-out, _ = proc.communicate(timeout=600)
+out, _ = proc.communicate(timeout=900)
+sampler._stop.set()
+sampler._t.join()
+pairs = list(zip(sampler.power, sampler.sclk))
 line = [ln for ln in out.splitlines() if ln.startswith("{")]
-if line:
+if line and pairs:
+    top = max(p for p, _ in pairs)
+    steady = [(p, c) for p, c in pairs if p >= 0.9 * top]
+    w, wmax, mhz, n = statistics.median(p for p, _ in steady), top, statistics.median(c for _, c in steady), len(steady)
     d = json.loads(line[-1])
     print(f"steady state ({' '.join(cmd[1:])}): {d['value']:.1f} images/s, {w:.0f} W (max {wmax:.0f}), sclk {mhz:.0f} MHz "
-          f"[{n} samples] = {w / d['value'] * 1e3:.0f} mJ per image; chip_frac {d['roofline']['chip_frac']:.3f}")
+          f"[{n} of {len(pairs)} samples within 10 % of the maximum] = {w / d['value'] * 1e3:.0f} mJ per image; chip_frac {d['roofline']['chip_frac']:.3f}")
 else:
     print("steady state: the bench printed no line")
