@@ -215,6 +215,26 @@ def test_reference_wrapper_consumer_end_to_end(api, session, model_dirs, tmp_pat
     assert np.allclose(acc, want, atol=1e-5)
 
 
+@pytest.mark.parametrize("n_prompts", [2, 5, 6, 7])
+def test_masks_written_straight_to_host_memory_equal_the_copied_ones(api, session, n_prompts):
+    """Up to six masks of a call leave as one post-processing launch each, straight into pinned host memory (while the other
+    lanes are idle; more go through a device buffer and piecewise copies: csrc/sam_model.cpp, enqueue_masks).  Either way the
+    caller gets the masks of one-at-a-time queries, bit for bit -- on 1024 x 1024 and on a 1800 x 1200 image (2.1 MB masks at
+    their own resolution, staging offsets padded to 256 bytes), single and multi-mask mode."""
+    env, _, _, _, seg, _ = session
+    wide = api.Segmentation.process(api.ImageView(synthetic_image(31, width=1800, height=1200, channels=3), api.Channels.rgb), env)
+    for handle, (w, h) in ((seg, (1024, 1024)), (wide, (1800, 1200))):
+        pts = [api.Point(37 + (w - 80) * k // n_prompts, h - 45 - (h - 90) * k // n_prompts) for k in range(n_prompts)]
+        together = api.Segmentation.compute_mask_batch([handle] * n_prompts, points=pts)
+        for p, m in zip(pts, together):
+            assert m.shape == (h, w) and np.array_equal(m, handle.compute_mask(p))
+    three = wide.compute_masks(api.Point(900, 600))
+    again = wide.compute_masks(api.Point(900, 600))
+    assert all(np.array_equal(a.image, b.image) and a.accuracy == b.accuracy for a, b in zip(three, again))
+    assert all(set(np.unique(m.image)) <= {0, 255} for m in three)
+    wide.close()
+
+
 @pytest.mark.parametrize("w,h,channels,point", [(1800, 1200, 3, (486, 722)), (512, 512, 4, (320, 210)),
                                                 (640, 960, 4, (100, 800))])
 def test_non_1024_images_end_to_end(api, session, w, h, channels, point):
