@@ -591,6 +591,12 @@ def main() -> None:
             "achieved": dom.get("gbs", 0.0) if hbm_bound else dom["tflops"],
             "peak": HBM_PEAK_GBS if hbm_bound else MFMA_F16_PEAK_TFLOPS, "unit": "GB/s" if hbm_bound else "TFLOP/s",
             "frac": dom["frac"], "traffic": traffic, "traffic_source": traffic_source,
+            "traffic_note": "FETCH_SIZE counts the L2's requests to the fabric, Infinity-Cache hits included (MI355X_MICROARCH.md): for a "
+                            "LayerNorm-folded consumer (qkv, fc1) it is 4-5 x the algorithmic reads because every round of 32 concurrent "
+                            "tiles of an XCD fetches its row and column panels again -- 100 MB of output stream through the 4 MB L2 "
+                            "between rounds -- while the operands themselves (25 MB of activations, < 5 MB of weights) stay in the "
+                            "256 MB Infinity Cache; the model (panels per round x 393 KB x 8 XCDs) reproduces the counters within 4 % "
+                            "(LABNOTES r06).  WRITE_SIZE equals the algorithmic output.",
             "bound_rule": f"arithmetic intensity of the launch (algorithmic FLOPs / algorithmic bytes, DESIGN.md section 6) against the "
                           f"ridge {ridge:.0f} FLOP/B = {MFMA_F16_PEAK_TFLOPS:.0f} TFLOP/s : {HBM_PEAK_GBS / 1e3:.0f} TB/s; every shape "
                           "carries both fractions in per_kernel",
