@@ -439,16 +439,28 @@ __global__ __launch_bounds__(512, 2) void attention_global_kernel(const half_t* 
 
     l += swap_halves(l);
     const float inv_l = 1.0f / l;
+    // Result: lane = query; registers o[dt][4 g4 ..] = columns dt * 32 + 8 g4 + 4 hi .. + 3, i.e. the two lanes of a query (hi =
+    // 0 / 1) hold alternate runs of four columns: 8-byte stores, 16 per lane.  r06: the two lanes trade runs first
+    // (v_permlane32_swap: the lower lane's odd run against the upper lane's even run, cdna_hip_programming.md T21), so each
+    // stores whole 16-byte pieces -- half the store instructions, and 16 bytes is the width at which a write-through result
+    // store (store16_result) costs what a plain one does.
     half_t* orow = out + ((size_t)img * TOKENS + qtok) * D + head * HD;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const int d0 = dt * 32 + 8 * g4 + 4 * hi;
-            if (d0 < HD) {
-                half4_t v = {(half_t)(o[dt][g4 * 4 + 0] * inv_l), (half_t)(o[dt][g4 * 4 + 1] * inv_l),
-                             (half_t)(o[dt][g4 * 4 + 2] * inv_l), (half_t)(o[dt][g4 * 4 + 3] * inv_l)};
-                *reinterpret_cast<half4_t*>(orow + d0) = v;
+        for (int j = 0; j < 2; ++j) {
+            if (dt * 32 + 16 * j < HD) {         // (compile-time; head dimension 80: the last tile has one such pair)
+                const int e = 8 * j, od = 8 * j + 4;          // first registers of the even (g4 = 2 j) and odd (g4 = 2 j + 1) run
+                const half2_t e01 = {(half_t)(o[dt][e + 0] * inv_l), (half_t)(o[dt][e + 1] * inv_l)};
+                const half2_t e23 = {(half_t)(o[dt][e + 2] * inv_l), (half_t)(o[dt][e + 3] * inv_l)};
+                const half2_t o01 = {(half_t)(o[dt][od + 0] * inv_l), (half_t)(o[dt][od + 1] * inv_l)};
+                const half2_t o23 = {(half_t)(o[dt][od + 2] * inv_l), (half_t)(o[dt][od + 3] * inv_l)};
+                // lanes 0-31 keep their even run and receive the upper lane's even run in place of their odd one;
+                // lanes 32-63 receive the lower lane's odd run in place of their even one and keep their odd run
+                const auto s0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, e01), __builtin_bit_cast(unsigned, o01), false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, e23), __builtin_bit_cast(unsigned, o23), false, false);
+                const uint4_t piece = {s0[0], s1[0], s0[1], s1[1]};
+                store16_result(orow + dt * 32 + 16 * j + 8 * hi, piece);
             }
         }
     }

@@ -375,7 +375,7 @@ __global__ __launch_bounds__(448, 4) void attention_window_kernel(const half_t* 
             const WinSlot os = win_slot(wave * 32 + row, wy, wx);
             if (!os.dummy && !os.pad) {
                 const float4_t v = *reinterpret_cast<const float4_t*>(slab + row * ROWB + ch * 16);
-                *reinterpret_cast<float4_t*>(out + ((size_t)img * 4096 + os.token) * D + head * HD + ch * 8) = v;
+                store16_result(out + ((size_t)img * 4096 + os.token) * D + head * HD + ch * 8, v);
             }
         }
     }

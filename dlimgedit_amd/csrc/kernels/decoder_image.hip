@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void image_update_kernel(ImageUpdate a) {
         f32x4 y;
 #pragma unroll
         for (int r = 0; r < 4; ++r) y[r] = acc[jt][r] * rstd * wv[r] + bv[r];
-        *reinterpret_cast<f32x4*>(a.keys + row * DIM + jt * 16 + 4 * g) = y;
+        store16_result(a.keys + row * DIM + jt * 16 + 4 * g, y);
         *reinterpret_cast<half4_t*>(a.keys_h + row * DIM + jt * 16 + 4 * g) =
             half4_t{(half_t)y[0], (half_t)y[1], (half_t)y[2], (half_t)y[3]};
     }

@@ -157,6 +157,26 @@ DLIMG_DEVICE int xcd_remap(int bid, int nwg) {
     return base + k;
 }
 
+// 16-byte store of a RESULT: bytes that no workgroup of this launch reads again and that the next kernel reads from wherever
+// it runs.  Write-through (`sc1`): the line does not stay behind in the XCD's L2 (MI355X_MICROARCH.md, "stores of each
+// flavour") -- a kernel that writes 25-100 MB otherwise ends with up to 32 MB of dirty lines that the kernel boundary has to
+// write back (MI355X_MICROARCH.md, price list, "boundary": + B / 6 TB/s) and that push the operand panels of its later
+// workgroups out of the L2.  r06, measured alone on the chip: fc1 85.9 -> 82.0 us per four-image launch, qkv's fetch traffic
+// 114 -> 103 MB.  Only for 16-byte accesses (narrower sc1 stores are one fabric write each, 2.7-12 x the time per byte).
+// The store is an asm statement: the compiler's memory counter does not see it; nothing in a kernel waits for a result store.
+template <typename V>
+DLIMG_DEVICE void store16_result(void* p, V v) {
+    static_assert(sizeof(V) == 16, "16-byte results only");
+#if defined(DLIMG_TUNING) && defined(DLIMG_PLAIN_STORES)      // A/B: the plain store
+    *reinterpret_cast<V*>(p) = v;
+#else
+    // (s_nop 1 inside the statement: a store of more than 8 bytes reads its data registers up to two states after it issues, and
+    // the compiler pads that hazard only for its own stores -- cdna_hip_programming.md 5.7 item 1; without it the next
+    // instruction may overwrite the data: fc1's epilogue did, the parity tests caught it)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(__builtin_bit_cast(float4_t, v)) : "memory");
+#endif
+}
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreJobs jobs) {
         half8_t o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = (half_t)v[c][i];
-        *reinterpret_cast<half8_t*>(dst + c * 256) = o;
+        store16_result(dst + c * 256, o);
     }
 }
 
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] = gelu_erf(y[e]);
             }
-            if (out_f32) reinterpret_cast<float4_t*>(out_f32 + (size_t)row * D)[c4] = y;
+            if (out_f32) store16_result(out_f32 + (size_t)row * D + (size_t)c4 * 4, y);
             if (out_h) {
                 half4_t h = {(half_t)y[0], (half_t)y[1], (half_t)y[2], (half_t)y[3]};
                 reinterpret_cast<half4_t*>(out_h + (size_t)row * D)[c4] = h;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void add_cast_kernel(const float* __restrict__
             float4_t u = *reinterpret_cast<const float4_t*>(b + (i * 4) % b_mod);
             v += u;
         }
-        if (out_f32) reinterpret_cast<float4_t*>(out_f32)[i] = v;
+        if (out_f32) store16_result(out_f32 + i * 4, v);
         if (out_h) {
             half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
             reinterpret_cast<half4_t*>(out_h)[i] = o;
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const half_t* __restrict
         half8_t v = zero_h8();
         if (yy >= 0 && yy < 64 && xx >= 0 && xx < 64)
             v = *reinterpret_cast<const half8_t*>(in + (((size_t)b * 4096 + yy * 64 + xx) * C) + ch * 8);
-        *reinterpret_cast<half8_t*>(out + (tok * 9 + tap) * C + ch * 8) = v;
+        store16_result(out + (tok * 9 + tap) * C + ch * 8, v);
     }
 }
 

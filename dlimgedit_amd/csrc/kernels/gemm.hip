@@ -728,7 +728,8 @@ DLIMG_DEVICE void pp_epilogue(const k::GemmArgs& a, float4v (&acc)[NI][4], char*
                 const int r = kk * 8 + rd_row;
                 const float4_t piece16 = *reinterpret_cast<const float4_t*>(sl + r * 128 + ((rd_chunk ^ (r & 7)) << 4));
                 const size_t m = (size_t)(m0 + row_base + i * 16 + r);
-                *reinterpret_cast<float4_t*>(a.out_h + m * a.ldc16 + n0 + wc * 64 + rd_chunk * 8) = piece16;
+                half_t* const dst = a.out_h + m * a.ldc16 + n0 + wc * 64 + rd_chunk * 8;
+                store16_result(dst, piece16);
             }
         }
     } else {
@@ -805,16 +806,16 @@ DLIMG_DEVICE void pp_epilogue(const k::GemmArgs& a, float4v (&acc)[NI][4], char*
                         const HiLo4 p0 = hilo_split(v0), p1 = hilo_split(v1);
                         const uint2_t h0 = __builtin_bit_cast(uint2_t, p0.h), h1 = __builtin_bit_cast(uint2_t, p1.h);
                         const uint2_t l0 = __builtin_bit_cast(uint2_t, p0.l), l1 = __builtin_bit_cast(uint2_t, p1.l);
-                        *reinterpret_cast<uint4_t*>(a.out_h + m * a.ldc16 + col) = uint4_t{h0[0], h0[1], h1[0], h1[1]};
-                        *reinterpret_cast<uint4_t*>(a.out_l + m * a.ldc16 + col) = uint4_t{l0[0], l0[1], l1[0], l1[1]};
+                        store16_result(a.out_h + m * a.ldc16 + col, uint4_t{h0[0], h0[1], h1[0], h1[1]});
+                        store16_result(a.out_l + m * a.ldc16 + col, uint4_t{l0[0], l0[1], l1[0], l1[1]});
                     } else {
-                        *reinterpret_cast<float4_t*>(a.out_f32 + m * a.ldc32 + col) = v0;
-                        *reinterpret_cast<float4_t*>(a.out_f32 + m * a.ldc32 + col + 4) = v1;
+                        store16_result(a.out_f32 + m * a.ldc32 + col, v0);
+                        store16_result(a.out_f32 + m * a.ldc32 + col + 4, v1);
                     }
                     if (HAS_H && !kNoCopyWrite) {
                         const half8_t h = {(half_t)v0[0], (half_t)v0[1], (half_t)v0[2], (half_t)v0[3],
                                            (half_t)v1[0], (half_t)v1[1], (half_t)v1[2], (half_t)v1[3]};
-                        *reinterpret_cast<half8_t*>(a.out_h + m * a.ldc16 + col) = h;
+                        store16_result(a.out_h + m * a.ldc16 + col, h);
                     }
                     if (EPI == EPI_STATS) {
                         // the row's 64 columns of this wave are in 8 adjacent lanes: (sum, squared deviations)
