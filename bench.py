@@ -699,6 +699,16 @@ def main() -> None:
             seg.close()
             return 1
 
+        # slot 3 alone, one thread: process() returns once its pass is enqueued (csrc/segmentation.hpp), so a loop over images
+        # keeps the lanes fed by itself; a handle is closed (which waits for its pass) eight images later
+        open_handles = []
+
+        def process_only():
+            open_handles.append(api.Segmentation.process(view, env))
+            if len(open_handles) > 8:
+                open_handles.pop(0).close()
+            return 1
+
         views8 = [api.ImageView(synthetic_image(100 + i), api.Channels.rgba) for i in range(8)]
         pts8 = [api.Point(512, 512)] * 8
 
@@ -749,7 +759,10 @@ def main() -> None:
             f"slots_3_4_{lanes}_threads": rate(one_image, lanes),
             "slots_13_14_batch8_one_thread": rate(batch8, 1),
             "slots_13_14_batch8_two_threads": rate(batch8, 2),
+            "slot_3_only_one_thread": rate(process_only, 1),
         }
+        for sg in open_handles:
+            sg.close()
 
     # ---- BASELINE.json configs 3-5 at one GPU's share and the ViT-H model, in the driver's own run: the
     # headline above is configs[1]; these legs are short (--leg-seconds each) and run after it, rank 0, N = 1 only

@@ -380,6 +380,12 @@ SamModel::SamModel(std::shared_ptr<SamWeights const> weights, int lane_index, in
 
 SamModel::~SamModel() {
     if (stream_) (void)hipStreamSynchronize(stream_);
+    for (auto& d : flag_owner_) {                // handles that outlive their lane find their pass settled
+        try {
+            if (d) d->settle();
+        } catch (...) {
+        }
+    }
     for (auto& p : pending_) {
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
@@ -496,6 +502,27 @@ void SamModel::wait_and_recycle(hipEvent_t e) {
         done_pool_.push_back(e);
     }
     HIP_CHECK(err);
+}
+
+std::shared_ptr<SamModel::DeferredPass> SamModel::defer_last_pass() {
+    DLIMG_ASSERT(pass_flag_ != nullptr);
+    auto d = std::make_shared<DeferredPass>();
+    d->lane = this;
+    d->done_ = completion();
+    d->flag_ = pass_flag_;
+    flag_owner_[pass_flag_ - pass_flags_] = d;
+    return d;
+}
+
+bool SamModel::DeferredPass::settle() {
+    std::lock_guard<std::mutex> lock(mutex_);
+    if (!settled_) {
+        settled_ = true;                         // the event goes back to the lane whatever the wait reports
+        lane->wait_and_recycle(done_);
+        overflowed_ = *flag_ != 0;
+        *const_cast<volatile int*>(flag_) = 0;
+    }
+    return overflowed_;
 }
 
 bool SamModel::poll_and_recycle(hipEvent_t e) {
@@ -796,7 +823,12 @@ void SamModel::encode(int batch, float* const* emb_dst) {
         HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&pass_flags_), kPassFlags * sizeof(int), hipHostMallocDefault));
         std::memset(pass_flags_, 0, kPassFlags * sizeof(int));
     }
-    pass_flag_ = pass_flags_ + (pass_counter_++ % kPassFlags);
+    const unsigned flag_slot = pass_counter_++ % kPassFlags;
+    if (flag_owner_[flag_slot]) {                // a deferred pass of kPassFlags passes ago still reports through this flag
+        flag_owner_[flag_slot]->settle();
+        flag_owner_[flag_slot].reset();
+    }
+    pass_flag_ = pass_flags_ + flag_slot;
     *pass_flag_ = 0;
     timed(ST_LAYERNORM, (double)M * kEmbedDim * 8, [&] {
         k::layernorm(neck_f32_.get(), W.neck_ln2_.w.get(), W.neck_ln2_.b.get(), kLnEps, M, kEmbedDim, k::ACT_NONE,

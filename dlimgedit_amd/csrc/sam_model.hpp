@@ -231,6 +231,23 @@ class SamModel {
     // kPassFlags further passes of this lane.
     static constexpr int kPassFlags = 64;
     const volatile int* last_pass_flag() const { return pass_flag_; }
+    // An encoder pass nobody has waited for yet: SegmentationImpl::process hands the caller's thread back once the pass is
+    // enqueued, and the first request that needs the embedding is queued on the SAME lane behind it (stream order), so the
+    // GPU goes from the encoder's last kernel to the decoder's first without a round trip through the host.  Whoever gets
+    // there first settles it -- the handle (first mask query, re-use, destruction) or this lane, before it re-uses the
+    // pass's flag; settle() is idempotent and callable from any thread without mutex().
+    struct DeferredPass {
+        SamModel* lane = nullptr;
+        bool settle();                    // waits for the pass; true when it reported non-finite values
+      private:
+        friend class SamModel;
+        std::mutex mutex_;
+        hipEvent_t done_ = nullptr;
+        const volatile int* flag_ = nullptr;
+        bool settled_ = false, overflowed_ = false;
+    };
+    // Under mutex(), right after encode(): completion() + last_pass_flag() of that pass as one object.
+    std::shared_ptr<DeferredPass> defer_last_pass();
     void wait_and_recycle(hipEvent_t e);      // no mutex needed
     bool poll_and_recycle(hipEvent_t e);      // no mutex needed: true (and the event is taken back) once it has completed
 
@@ -308,6 +325,7 @@ class SamModel {
     int* pass_flags_ = nullptr;          // [kPassFlags] pinned, host-visible; pass_flag_ = the slot of the pass enqueued last
     int* pass_flag_ = nullptr;
     unsigned pass_counter_ = 0;
+    std::shared_ptr<DeferredPass> flag_owner_[kPassFlags];   // deferred passes by the flag they report through
     std::vector<hipEvent_t> done_pool_;   // completion() events, guarded by done_mutex_ (taken without mutex_)
 };
 

@@ -51,12 +51,58 @@ void check_image(dlimg_ImageView const& image) {
     DLIMG_ASSERT(image.stride >= image.width * channel_bytes(c));
 }
 
+namespace {
+constexpr const char* kOverflowMessage =
+    "the image encoder produced non-finite values: an activation left the f16 range (65504) of this build's MFMA operands "
+    "and residual stream -- the embedding is refused (no masks are computed from it)";
+
+// process() of one image leaves the wait to the first call that needs the embedding (segmentation.hpp)
+bool deferred_process() {
+    const char* e = std::getenv("DLIMGEDIT_SYNC_PROCESS");       // read per call: a deployer's switch, and the tests'
+    return !(e && std::atoi(e) != 0);
+}
+}  // namespace
+
 SegmentationImpl::SegmentationImpl(EnvironmentImpl& env) : env_(env) {
     env.load_all();     // loads the model (and reports a missing weight file) at the same point as the reference
 }
 
 SegmentationImpl::~SegmentationImpl() {
+    forget_pending();                            // the pass still writes the buffer that goes back to the pool
     if (pool_) pool_->give(embedding_);
+}
+
+std::shared_ptr<SamModel::DeferredPass> SegmentationImpl::pending() const {
+    std::lock_guard<std::mutex> lock(pending_mutex_);
+    return pending_;
+}
+
+void SegmentationImpl::settle() const {
+    if (auto p = pending()) {
+        std::exception_ptr failed;
+        try {
+            if (p->settle()) invalid_ = true;
+        } catch (...) {
+            invalid_ = true;                     // the wait itself failed: nothing is known about the embedding
+            failed = std::current_exception();
+        }
+        {
+            std::lock_guard<std::mutex> lock(pending_mutex_);
+            if (pending_ == p) pending_.reset();
+        }
+        if (failed) std::rethrow_exception(failed);
+    }
+    if (invalid_) throw Exception(kOverflowMessage);
+}
+
+void SegmentationImpl::forget_pending() noexcept {
+    try {
+        if (auto p = pending()) p->settle();
+    } catch (...) {
+    }
+    std::lock_guard<std::mutex> lock(pending_mutex_);
+    pending_.reset();
+    invalid_ = false;
 }
 
 float* SegmentationImpl::embedding_storage(int replica) {
@@ -144,9 +190,6 @@ template <typename F> void for_each_replica(EnvironmentImpl& env, std::vector<in
 // overflow: the pass's report (SamModel::last_pass_flag), read once its event has been waited for
 struct Waiting { SamModel* model; hipEvent_t done; const volatile int* overflow; };
 
-constexpr const char* kOverflowMessage =
-    "the image encoder produced non-finite values: an activation left the f16 range (65504) of this build's MFMA operands "
-    "and residual stream -- the embedding is refused (no masks are computed from it)";
 
 // Error paths: a request that threw half-way may have queued kernels or copies that still write into buffers the
 // caller is about to hand back (pooled embedding buffers, mask staging slots).  Everything queued on that lane runs
@@ -193,8 +236,10 @@ void SegmentationImpl::process_batch(EnvironmentImpl& env, SegmentationImpl* con
     if (count <= 0) return;
     for (int i = 0; i < count; ++i) {
         check_image(images[i]);
+        segs[i]->forget_pending();               // a handle processed again: its earlier pass writes the same buffer
         segs[i]->image_size_.set(Extent{images[i].width, images[i].height});
     }
+    const bool defer = count == 1 && deferred_process();
     const int G = env.replica_count();
     std::vector<int> replica_of(count), used;
     for (int i = 0; i < count; ++i) {
@@ -237,7 +282,7 @@ void SegmentationImpl::process_batch(EnvironmentImpl& env, SegmentationImpl* con
                                  : alone      ? std::min<size_t>(4, spread)
                                               : std::min<size_t>(4, std::max(spread, (mine.size() + 1) / 2));
             // One pass: the chunk's images staged (host copy + upload) and encoded on `model`; returns the event behind it.
-            struct Queued { hipEvent_t done; const volatile int* overflow; };
+            struct Queued { hipEvent_t done; const volatile int* overflow; std::shared_ptr<SamModel::DeferredPass> deferred; };
             auto run_chunk = [&](SamModel& model, size_t base, int n) {
                 std::vector<float*> emb(n);
                 for (int j = 0; j < n; ++j) emb[j] = segs[mine[base + j]]->embedding_storage(replica);
@@ -255,8 +300,9 @@ void SegmentationImpl::process_batch(EnvironmentImpl& env, SegmentationImpl* con
                     roctx::Range r("dlimg.encode");
                     model.encode(n, emb.data());
                 }
+                if (defer) return Queued{nullptr, nullptr, model.defer_last_pass()};
                 const volatile int* overflow = model.last_pass_flag();
-                return Queued{model.completion(), overflow};
+                return Queued{model.completion(), overflow, nullptr};
             };
             const size_t chunks = (mine.size() + chunk - 1) / chunk;
             if (chunks > 1 && alone && env.use_step_workers) {
@@ -301,8 +347,14 @@ void SegmentationImpl::process_batch(EnvironmentImpl& env, SegmentationImpl* con
                     SamModel& model = env.next_lane(replica);
                     enqueueing = &model;
                     const Queued q = run_chunk(model, base, n);
-                    waiting.push_back(Waiting{&model, q.done, q.overflow});
                     enqueueing = nullptr;
+                    if (q.deferred) {
+                        // the caller's thread goes back now; the first mask query is queued behind the pass and waits
+                        std::lock_guard<std::mutex> lock(segs[mine[base]]->pending_mutex_);
+                        segs[mine[base]]->pending_ = q.deferred;
+                    } else {
+                        waiting.push_back(Waiting{&model, q.done, q.overflow});
+                    }
                 }
             }
         } catch (...) {
@@ -312,8 +364,8 @@ void SegmentationImpl::process_batch(EnvironmentImpl& env, SegmentationImpl* con
             try { wait_all(waiting); } catch (...) {}
             throw;
         }
-        // process() is synchronous in the reference (Ort::Session::Run returns when the result is
-        // there); errors of this call must surface in this call.
+        // process() is synchronous in the reference (Ort::Session::Run returns when the result is there).  A batch is
+        // waited for here and its errors surface in this call; one image is left to its first query (segmentation.hpp).
         const auto t1 = std::chrono::steady_clock::now();
         wait_all(waiting);
         if (trace) {
@@ -329,6 +381,7 @@ void SegmentationImpl::compute_mask(Point const* point, Region const* region, ui
                                     float out_accuracy[3]) const {
     DLIMG_ASSERT(point || region);
     DLIMG_ASSERT(embedding_ != nullptr);
+    if (invalid_) throw Exception(kOverflowMessage);
     float coords[4], labels[2];
     pack_prompt(image_size_, point, region, coords, labels);
     const bool is_single_mask = out_masks[1] == nullptr;
@@ -339,7 +392,10 @@ void SegmentationImpl::compute_mask(Point const* point, Region const* region, ui
     }
 
     HIP_CHECK(hipSetDevice(env_.device_of(replica_)));
-    SamModel& model_ = env_.next_lane(replica_);
+    // an encoder pass nobody has waited for yet: the decoder goes onto ITS lane, behind it in stream order, and the wait
+    // for the masks is the wait for both (any number of threads may do so at once: the lane's mutex orders their requests)
+    const std::shared_ptr<SamModel::DeferredPass> behind = pending();
+    SamModel& model_ = behind ? *behind->lane : env_.next_lane(replica_);
     const Extent o = image_size_.original, r = image_size_.resized;
     k::PostJob jobs[3];
     int n_jobs = 0;
@@ -373,6 +429,7 @@ void SegmentationImpl::compute_mask(Point const* point, Region const* region, ui
         throw;
     }
     model_.release_mask_slot(slot);
+    if (behind) settle();                        // has completed; an embedding with non-finite values: no masks, the error
     if (!is_single_mask)
         for (int i = 0; i < 3; ++i) out_accuracy[i] = iou[i + 1];
 }
@@ -390,6 +447,7 @@ void SegmentationImpl::compute_mask_batch(SegmentationImpl const* const* segs, i
     for (int i = 0; i < count; ++i) {
         DLIMG_ASSERT(&segs[i]->env_ == &env);
         DLIMG_ASSERT(segs[i]->embedding_ != nullptr && out_masks[i] != nullptr);
+        segs[i]->settle();                       // prompts of a batch go to any lane: the embeddings are complete first
         if (points) {
             Point p{points[i * 2], points[i * 2 + 1]};
             pack_prompt(segs[i]->image_size_, &p, nullptr, &coords[i * 4], &labels[i * 2]);
@@ -482,6 +540,7 @@ void SegmentationImpl::compute_mask_batch_device(SegmentationImpl const* const* 
     for (int i = 0; i < count; ++i) {
         DLIMG_ASSERT(&segs[i]->env_ == &env);
         DLIMG_ASSERT(segs[i]->embedding_ != nullptr);
+        segs[i]->settle();
         if (points) {
             Point p{points[i * 2], points[i * 2 + 1]};
             pack_prompt(segs[i]->image_size_, &p, nullptr, &coords[i * 4], &labels[i * 2]);

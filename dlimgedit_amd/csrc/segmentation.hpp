@@ -58,7 +58,7 @@ class SegmentationImpl {
 
     Extent extent() const { return image_size_.original; }
     ResizeLongestSide const& geometry() const { return image_size_; }
-    float const* embedding() const { return embedding_; }
+    float const* embedding() const { settle(); return embedding_; }       // complete when this returns
     ~SegmentationImpl();
     SegmentationImpl(SegmentationImpl const&) = delete;
     SegmentationImpl& operator=(SegmentationImpl const&) = delete;
@@ -73,6 +73,18 @@ class SegmentationImpl {
     ResizeLongestSide image_size_;
     float* embedding_ = nullptr;        // [4096][256] fp32, resident on the replica's GPU
     std::shared_ptr<EmbeddingPool> pool_;   // where embedding_ came from and goes back to
+
+    // process() of ONE image returns once its encoder pass is enqueued (the pixels have been copied by then; argument
+    // errors have been reported).  The pass is waited for by the first call that needs its result: compute_mask queues its
+    // decoder on the same lane behind the encoder and waits once, for both; everything else settles first.  A pass that
+    // reported non-finite values makes every query of this handle fail with the message process() would have thrown.
+    // DLIMGEDIT_SYNC_PROCESS=1: process() waits itself, as in the reference (Ort::Session::Run).
+    mutable std::mutex pending_mutex_;
+    mutable std::shared_ptr<SamModel::DeferredPass> pending_;
+    mutable std::atomic<bool> invalid_{false};
+    std::shared_ptr<SamModel::DeferredPass> pending() const;
+    void settle() const;                    // waits for a deferred pass; throws when the embedding is not usable
+    void forget_pending() noexcept;         // the same without the verdict: the embedding is about to be replaced or freed
 };
 
 // Validates an image view the way the entry points need it; throws on nonsense.

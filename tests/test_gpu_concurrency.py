@@ -356,3 +356,64 @@ def test_concurrent_callers_of_a_multi_replica_environment_keep_their_own_helper
         s.close()
     three.close()
     one.close()
+
+
+def test_process_leaves_the_wait_to_the_first_query(setup, monkeypatch):
+    """process() of one image returns once its encoder pass is enqueued (csrc/segmentation.hpp); whatever needs the embedding
+    first waits for it -- a mask query on the pass's own lane, behind it in stream order.  Bits are those of a process() that
+    waits itself (DLIMGEDIT_SYNC_PROCESS=1, the reference's behaviour), whichever call comes first and from however many
+    threads at once; a handle destroyed straight away leaves nothing behind; more passes than a lane has report flags (64)
+    may stay unqueried."""
+    api, env = setup
+    views = [api.ImageView(synthetic_image(40 + i), api.Channels.rgba) for i in range(3)]
+    pt = api.Point(300, 700)
+    monkeypatch.setenv("DLIMGEDIT_SYNC_PROCESS", "1")
+    want = []
+    for v in views:
+        seg = api.Segmentation.process(v, env)
+        want.append((api.ext.get_embedding(seg), seg.compute_mask(pt), seg.compute_mask(api.Region(api.Point(100, 100), api.Point(900, 800)))))
+        seg.close()
+    monkeypatch.delenv("DLIMGEDIT_SYNC_PROCESS")
+
+    for first in ("mask", "embedding", "batch", "region"):
+        for v, (emb, mask, box) in zip(views, want):
+            seg = api.Segmentation.process(v, env)
+            if first == "mask":
+                assert np.array_equal(seg.compute_mask(pt), mask)
+            elif first == "embedding":
+                assert np.array_equal(api.ext.get_embedding(seg), emb)
+            elif first == "batch":
+                assert np.array_equal(api.Segmentation.compute_mask_batch([seg, seg], points=[pt, pt])[1], mask)
+            else:
+                assert np.array_equal(seg.compute_mask(api.Region(api.Point(100, 100), api.Point(900, 800))), box)
+            assert np.array_equal(seg.compute_mask(pt), mask) and np.array_equal(api.ext.get_embedding(seg), emb)
+            seg.close()
+
+    # several threads query a handle whose pass nobody has waited for
+    for _ in range(3):
+        seg = api.Segmentation.process(views[1], env)
+        got, errors = [None] * 4, []
+
+        def worker(i, seg=seg, got=got, errors=errors):
+            try:
+                got[i] = seg.compute_mask(pt)
+            except Exception as e:       # noqa: BLE001
+                errors.append(e)
+        ts = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert not errors, errors
+        assert all(np.array_equal(g, want[1][1]) for g in got)
+        seg.close()
+
+    # handles dropped unqueried: their pass is waited for before the embedding buffer goes back to the pool
+    for _ in range(10):
+        api.Segmentation.process(views[2], env).close()
+
+    # more unqueried passes than a lane has flags: the lane settles the old ones itself before their flag is used again
+    lanes = api.ext.lane_count(env)
+    held = [api.Segmentation.process(views[i % 3], env) for i in range(64 * lanes + 2 * lanes + 1)]
+    for i, seg in enumerate(held):
+        if i % 17 == 0 or i >= len(held) - 2:
+            assert np.array_equal(seg.compute_mask(pt), want[i % 3][1])
+        seg.close()

@@ -448,11 +448,13 @@ def test_the_reference_s_truck_case_on_its_own_photograph(api, session):
     seg.close()
 
 
-def test_values_beyond_the_f16_range_are_reported_not_decoded(api, model_dirs, tmp_path):
+def test_values_beyond_the_f16_range_are_reported_not_decoded(api, model_dirs, tmp_path, monkeypatch):
     """No real checkpoint has run on this build, and its MFMA operands and residual stream are f16 (65504): a weight
     beyond that is refused by name when the model is loaded; an ACTIVATION beyond it -- here a positional-embedding channel
-    at 1e5, far inside fp32 -- turns into an infinity somewhere in the encoder, and process() says so instead of handing
-    out an embedding whose masks would be NaN patterns.  The environment keeps working afterwards."""
+    at 1e5, far inside fp32 -- turns into an infinity somewhere in the encoder, and the handle says so instead of handing
+    out masks that would be NaN patterns: process() of one image leaves the wait for its pass to the first call that needs
+    the embedding (csrc/segmentation.hpp), so that call reports it, and every later one on the handle; a batch is waited
+    for by process_batch() itself.  The environment keeps working afterwards."""
     from dlimgedit_amd import weights as W
     _, params, cfg = model_dirs("vit_test")
     img = api.ImageView(synthetic_image(0), api.Channels.rgba)
@@ -473,8 +475,20 @@ def test_values_beyond_the_f16_range_are_reported_not_decoded(api, model_dirs, t
     d2 = tmp_path / "hot"
     W.save_weights(d2 / "segmentation" / W.weight_file_name(cfg), cfg, hot)
     env = api.Environment(api.Options(api.Backend.gpu, str(d2)))
+    seg = api.Segmentation.process(img, env)
+    for _ in range(2):
+        with pytest.raises(api.Error, match="non-finite values: an activation left the f16 range"):
+            seg.compute_mask(api.Point(512, 512))
+    with pytest.raises(api.Error, match="non-finite values"):
+        api.Segmentation.compute_mask_batch([seg], points=[api.Point(512, 512)])
+    with pytest.raises(api.Error, match="non-finite values"):
+        api.ext.get_embedding(seg)
+    seg.close()
+    api.Segmentation.process(img, env).close()          # never queried: nothing to report, nothing left behind
+    monkeypatch.setenv("DLIMGEDIT_SYNC_PROCESS", "1")   # the deployer's switch: process() waits itself, as the reference's does
     with pytest.raises(api.Error, match="non-finite values: an activation left the f16 range"):
         api.Segmentation.process(img, env)
+    monkeypatch.delenv("DLIMGEDIT_SYNC_PROCESS")
     with pytest.raises(api.Error, match="non-finite values"):
         api.Segmentation.process_batch([img, img, img], env)
     # a flag has an owner (r06): the reports above belonged to process() / process_batch() and were consumed there -- a
