@@ -1,5 +1,11 @@
+"""process() that waits for its encoder pass itself (DLIMGEDIT_SYNC_PROCESS=1, the reference's timing) against the default,
+which leaves the wait to the first query of the handle (csrc/segmentation.hpp): one synchronous caller of slots 3 + 4, three
+interleaved rounds of 3 s, then slot 3 alone in a loop from one thread.  ViT-B, synthetic weights, host buffers in and out.
+    gpurun -- 'python3 tools/defer_probe.py > gpurun_out/defer_probe.txt'"""
 import sys, time, tempfile, os
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 from conftest import synthetic_image
 from dlimgedit_amd import api, weights as W
 from dlimgedit_amd.sam_config import get_config

@@ -12,4 +12,5 @@ timeout -k 10 300 python3 tools/bench_configs.py vit_b > $F/configs_vit_b.txt 2>
 timeout -k 10 400 python3 tools/bench_configs.py vit_h > $F/configs_vit_h.txt 2>&1 && echo "configs vit_h ok" &&
 timeout -k 10 300 python3 bench.py --gpus 2 --rehearse-gloo --steps 10 --warmup 2 --repeats 5 > $F/bench_gpus2_rehearsal.json 2> $F/rehearsal.err && echo "rehearsal ok" &&
 timeout -k 10 300 python3 tools/power_kernels.py vit_b 3 > $F/power_kernels_vit_b.txt 2>&1 && echo "power ok" &&
+timeout -k 10 200 python3 tools/defer_probe.py > $F/defer_probe.txt 2>&1 && echo "defer probe ok" &&
 bash tools/collect_profiles.sh vit_b

@@ -19,4 +19,5 @@ cp $S/kernel_stats_rocprofv3.csv profiles/${R}_bench_vit_b_b1_kernel_stats.csv
 cp $S/bench_under_kernel_trace.json profiles/${R}_bench_under_kernel_trace.json
 cp $S/kernel_stats_burst_process.txt profiles/${R}_kernel_stats_burst_process.txt
 cp $F/power_kernels_vit_b.txt profiles/${R}_power_kernels_vit_b.txt
+cp $F/defer_probe.txt profiles/${R}_defer_probe.txt
 { echo "# name	value	tolerance (last GPU suite run of the round; every value the parity tests checked)"; cat gpurun_out/parity_margins.txt; } > profiles/${R}_parity_margins.txt
