@@ -5,11 +5,14 @@
 //
 //   abi_consumer <libdlimgedit.so> probe
 //   abi_consumer <libdlimgedit.so> run <model_dir> <rgba.raw> <w> <h> <px> <py> <out_mask.raw>
+//   abi_consumer <libdlimgedit.so> loop <model_dir> <rgba.raw> <w> <h> <px> <py> <seconds>
+//       the consumer's natural loop -- process(image), compute_mask(point), one thread -- for <seconds>; prints its rate
 #define DLIMGEDIT_LOAD_DYNAMIC
 #include <dlimgedit/dlimgedit.hpp>
 
 #include <dlfcn.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -70,6 +73,42 @@ int main(int argc, char** argv) {
             std::printf("accuracy=%.6f %.6f %.6f\n", masks[0].accuracy, masks[1].accuracy, masks[2].accuracy);
             std::ofstream out(argv[9], std::ios::binary);
             out.write(reinterpret_cast<const char*>(mask.pixels()), std::streamsize(mask.size()));
+        } catch (dlimg::Exception const& e) {
+            std::fprintf(stderr, "dlimg::Exception: %s\n", e.what());
+            return 3;
+        }
+        return 0;
+    }
+    if (mode == "loop") {
+        if (argc != 10) return fail("loop needs <model_dir> <rgba.raw> <w> <h> <px> <py> <seconds>");
+        const int w = std::atoi(argv[5]), h = std::atoi(argv[6]);
+        const dlimg::Point point{std::atoi(argv[7]), std::atoi(argv[8])};
+        const double seconds = std::atof(argv[9]);
+        std::vector<uint8_t> pixels(size_t(w) * h * 4);
+        std::ifstream in(argv[4], std::ios::binary);
+        if (!in.read(reinterpret_cast<char*>(pixels.data()), std::streamsize(pixels.size()))) return fail("short image file");
+        try {
+            dlimg::Options opts;
+            opts.backend = dlimg::Backend::gpu;
+            opts.model_directory = argv[3];
+            dlimg::Environment env(opts);
+            auto view = dlimg::ImageView(pixels.data(), dlimg::Extent{w, h}, dlimg::Channels::rgba);
+            using clock = std::chrono::steady_clock;
+            auto elapsed = [](clock::time_point a) { return std::chrono::duration<double>(clock::now() - a).count(); };
+            size_t set_pixels = 0;
+            for (int i = 0; i < 5; ++i) {               // model load, workspaces, first launches
+                dlimg::Image mask = dlimg::Segmentation::process(view, env).compute_mask(point);
+                set_pixels = 0;
+                for (size_t j = 0; j < mask.size(); ++j) set_pixels += mask.pixels()[j] != 0;
+            }
+            long images = 0;
+            const auto t0 = clock::now();
+            while (elapsed(t0) < seconds) {
+                auto seg = dlimg::Segmentation::process(view, env);
+                dlimg::Image mask = seg.compute_mask(point);
+                ++images;
+            }
+            std::printf("images_per_s=%.2f images=%ld set_pixels=%zu\n", double(images) / elapsed(t0), images, set_pixels);
         } catch (dlimg::Exception const& e) {
             std::fprintf(stderr, "dlimg::Exception: %s\n", e.what());
             return 3;
