@@ -250,6 +250,12 @@ class Image:
             _api.destroy_image(ptr)
 
 
+def _mask_image(extent: Extent) -> np.ndarray:
+    """A result mask as the reference's wrapper makes it -- `Image(extent(), Channels::mask)`, i.e. memory from the library's
+    create_image (dlimgedit.impl.hpp:84-88) -- seen as an (h, w) array that keeps the Image alive."""
+    return Image(extent, Channels.mask).pixels().reshape(extent.height, extent.width)
+
+
 # ---------------------------------------------------------------------------------------------
 # Environment / Segmentation
 
@@ -329,7 +335,7 @@ class Segmentation:
 
     def _query(self, point, region, n_masks):
         e = self.extent()
-        masks = [np.empty((e.height, e.width), dtype=np.uint8) for _ in range(n_masks)]
+        masks = [_mask_image(e) for _ in range(n_masks)]
         ptrs = (C.c_void_p * 3)(*([m.ctypes.data for m in masks] + [None] * (3 - n_masks)))
         acc = (C.c_float * 3)(0.0, 0.0, 0.0)
         p = (C.c_int * 2)(point.x, point.y) if point is not None else None
@@ -355,7 +361,7 @@ class Segmentation:
                            regions: Optional[Sequence[Region]] = None) -> list:
         n = len(segs)
         handles = (C.c_void_p * n)(*[s._handle for s in segs])
-        outs = [np.empty((s.extent().height, s.extent().width), dtype=np.uint8) for s in segs]
+        outs = [_mask_image(s.extent()) for s in segs]
         ptrs = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
         p = r = None
         if points is not None:
@@ -423,6 +429,7 @@ class ext:
                 "dlimg_amd_synchronize": ([vp], ci),
                 "dlimg_amd_lane_count": ([vp], ci),
                 "dlimg_amd_queue_config": ([vp, C.POINTER(ci)], ci),
+                "dlimg_amd_image_memory": ([vp, C.c_size_t, C.POINTER(ci)], ci),
                 "dlimg_amd_replica_count": ([vp], ci),
                 "dlimg_amd_segmentation_device": ([vp, C.POINTER(ci), C.POINTER(ci)], ci),
                 "dlimg_amd_get_segmentation_masks_device": ([C.POINTER(vp), ci, C.POINTER(ci), C.POINTER(ci), ci, vp,
@@ -474,6 +481,7 @@ class ext:
                "dlimg_amd_get_logits", "dlimg_amd_decoder_state", "dlimg_amd_device_alloc", "dlimg_amd_device_free",
                "dlimg_amd_copy_to_device", "dlimg_amd_copy_to_host", "dlimg_amd_encode_and_mask",
                "dlimg_amd_encode_only", "dlimg_amd_synchronize", "dlimg_amd_lane_count", "dlimg_amd_queue_config",
+               "dlimg_amd_image_memory",
                "dlimg_amd_replica_count", "dlimg_amd_segmentation_device", "dlimg_amd_get_segmentation_masks_device",
                "dlimg_amd_set_profiling", "dlimg_amd_take_stage_stats", "dlimg_amd_birefnet_prepare_image",
                "dlimg_amd_birefnet_process_mask", "dlimg_amd_resize_mask")
@@ -621,6 +629,13 @@ class ext:
         _check(cls._l().dlimg_amd_queue_config(env.handle(), out))
         return {"coalesce": out[0], "step_depth": out[1], "lanes": out[2], "lanes_in_use": out[3],
                 "one_image_passes": out[4], "one_image_passes_alone": out[5]}
+
+    @classmethod
+    def image_memory_is_pinned(cls, array: np.ndarray) -> bool:
+        """True when the array's bytes lie in pinned image memory of the library (read / written in place by the GPU)."""
+        out = C.c_int(0)
+        _check(cls._l().dlimg_amd_image_memory(array.ctypes.data, array.nbytes, C.byref(out)))
+        return bool(out.value)
 
     @classmethod
     def replica_count(cls, env) -> int:

@@ -49,6 +49,7 @@ SOURCES = [
     "kernels/objects.hip",
     "resize_tables.cpp",
     "image_io.cpp",
+    "image_memory.cpp",
     "jpeg_decode.cpp",
     "weights.cpp",
     "sam_model.cpp",

@@ -1,11 +1,14 @@
 // C-ABI boundary: dlimg_init() and the function table.
 // Counterpart of /root/reference/src/dlimgedit.cpp (table order :102-117, try_ trampoline :26-40).
 #include "environment.hpp"
+#include "image_memory.hpp"
 #include "segmentation.hpp"
 
 #include <dlimgedit/dlimgedit.h>
 
+#include <cstring>
 #include <new>
+#include <string>
 #include <vector>
 
 namespace dlimg {
@@ -96,7 +99,15 @@ dlimg_Result segment_objects(dlimg_ImageView const*, uint8_t*, dlimg_Environment
 dlimg_Result load_image(char const* filepath, int* out_extent, int* out_channels, uint8_t** out_pixels) {
     return guarded([&] {
         DLIMG_ASSERT(filepath != nullptr && out_extent != nullptr && out_channels != nullptr && out_pixels != nullptr);
-        *out_pixels = load_image_file(filepath, out_extent, out_channels);
+        // the decoder's buffer moves into the library's image memory (csrc/image_memory.hpp): one allocator behind
+        // destroy_image, and pixels that process() can send to the GPU from where they lie
+        uint8_t* decoded = load_image_file(filepath, out_extent, out_channels);
+        const size_t bytes = (size_t)out_extent[0] * out_extent[1] * *out_channels;
+        uint8_t* pixels = image_alloc(bytes);
+        if (pixels) std::memcpy(pixels, decoded, bytes);
+        delete[] decoded;
+        if (!pixels) throw Exception(std::string("Failed to load image ") + filepath + ": out of memory");
+        *out_pixels = pixels;
     });
 }
 
@@ -109,10 +120,10 @@ dlimg_Result save_image(dlimg_ImageView const* image, char const* filepath) {
 
 uint8_t* create_image(int w, int h, int channels) {
     if (w <= 0 || h <= 0 || channels <= 0) return nullptr;
-    return new (std::nothrow) uint8_t[(size_t)w * h * channels];
+    return image_alloc((size_t)w * h * channels);
 }
 
-void destroy_image(uint8_t const* pixels) { delete[] pixels; }
+void destroy_image(uint8_t const* pixels) { image_free(pixels); }
 
 char const* last_error() { return last_error_.c_str(); }
 

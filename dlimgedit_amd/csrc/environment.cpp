@@ -1,4 +1,5 @@
 #include "environment.hpp"
+#include "image_memory.hpp"
 
 #include <algorithm>
 #include <cctype>
@@ -254,6 +255,7 @@ EnvironmentImpl::EnvironmentImpl(dlimg_Options const& options) : backend(options
         step_depth = v < 1 ? 1 : (v > 64 ? 64 : v);
     }
     single_lane_.store(forced_single_lane_);
+    image_memory_use_pinned();       // images and masks the library allocates from now on can be reached by the GPU in place
     for (int d : devices) {
         if (d < 0 || d >= device_count())
             throw Exception("GPU index " + std::to_string(d) + " (DLIMGEDIT_DEVICE / DLIMGEDIT_DEVICES) is out of range: " +

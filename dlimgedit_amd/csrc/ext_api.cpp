@@ -2,6 +2,7 @@
 // gather, stage clocks, getters, and the library-side kernels of segment_objects.  (The single-kernel test hooks and the
 // benchmark hooks are in test_hooks.cpp, which only the test and tuning libraries contain.)
 #include "ext_common.hpp"
+#include "image_memory.hpp"
 #include "step_queue.hpp"
 #include "resize_tables.hpp"
 
@@ -419,6 +420,13 @@ DLIMG_API int dlimg_amd_queue_config(dlimg_Environment env, int* out) {
         LaneBoard const* board = e.lane(0, 0).board();
         out[4] = board ? (int)std::min<long>(board->passes(), 0x7fffffff) : 0;
         out[5] = board ? (int)std::min<long>(board->alone_passes(), 0x7fffffff) : 0;
+    });
+}
+
+DLIMG_API int dlimg_amd_image_memory(void const* pixels, size_t bytes, int* out_pinned) {
+    return guarded([&] {
+        DLIMG_ASSERT(out_pinned != nullptr);
+        *out_pinned = image_memory_is_pinned(pixels, bytes) ? 1 : 0;
     });
 }
 

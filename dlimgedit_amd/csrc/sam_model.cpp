@@ -1,4 +1,5 @@
 #include "sam_model.hpp"
+#include "image_memory.hpp"
 #include "mask_pieces.hpp"
 
 #include <algorithm>
@@ -376,6 +377,7 @@ SamModel::SamModel(std::shared_ptr<SamWeights const> weights, int lane_index, in
         }
     }
     for (auto& st : stage_) HIP_CHECK(hipEventCreateWithFlags(&st.copied, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&caller_copied_, hipEventDisableTiming));
 }
 
 SamModel::~SamModel() {
@@ -394,6 +396,7 @@ SamModel::~SamModel() {
     for (auto e : done_pool_) (void)hipEventDestroy(e);
     for (auto& st : stage_)
         if (st.copied) (void)hipEventDestroy(st.copied);
+    if (caller_copied_) (void)hipEventDestroy(caller_copied_);
     for (auto& m : mask_slots_) {
         if (m->done) (void)hipEventDestroy(m->done);
         for (auto e : m->piece_done) (void)hipEventDestroy(e);
@@ -618,11 +621,20 @@ void SamModel::upload_image(int slot, int batch, uint8_t const* pixels, int w, i
     // resize happens, segmentation.cpp:81-106; honouring the stride is identical for packed views).
     // In pieces of ~1 MiB: piece i crosses PCIe while the host packs piece i + 1 into the pinned area (a 4 MiB image:
     // 0.30 -> ~0.2 ms of a synchronous caller's 2.6 ms per image; one piece for small images)
+    uint8_t* dev = img_dev_.get() + slot * slot_bytes;
+    if ((size_t)stride == row && image_memory_is_pinned(pixels, row * h)) {
+        // pixels the library allocated itself (an Image of the consumer: load_image / create_image) are pinned: one copy
+        // command from where they lie, no packing pass
+        HIP_CHECK(hipMemcpyAsync(dev, pixels, row * h, hipMemcpyHostToDevice, stream_));
+        HIP_CHECK(hipEventRecord(caller_copied_, stream_));
+        caller_copy_pending_ = true;
+        preprocess_device_image(slot, batch, dev, w, h, (int)row, channels);
+        return;
+    }
     ImageStage& st = stage_[stage_seq_++ % kStageRing];
     HIP_CHECK(hipEventSynchronize(st.copied));       // the copy that last read this entry has run
     st.pin.reserve(row * h);                         // (re-allocation is safe for the same reason)
     uint8_t* pin = static_cast<uint8_t*>(st.pin.get());
-    uint8_t* dev = img_dev_.get() + slot * slot_bytes;
     const int pieces = (int)std::min<size_t>(8, std::max<size_t>(1, row * h / (1u << 20)));
     for (int p = 0; p < pieces; ++p) {
         const int y0 = (int)((long)h * p / pieces), y1 = (int)((long)h * (p + 1) / pieces);
@@ -635,6 +647,12 @@ void SamModel::upload_image(int slot, int batch, uint8_t const* pixels, int w, i
     }
     HIP_CHECK(hipEventRecord(st.copied, stream_));
     preprocess_device_image(slot, batch, dev, w, h, (int)row, channels);
+}
+
+void SamModel::wait_caller_copies() {
+    if (!caller_copy_pending_) return;
+    caller_copy_pending_ = false;
+    HIP_CHECK(hipEventSynchronize(caller_copied_));
 }
 
 std::shared_ptr<SamModel::AxisDev const> SamModel::axis_table(int in_size, int out_size) {
@@ -690,10 +708,16 @@ void SamModel::upload_and_resize_image(int slot, int batch, uint8_t const* pixel
         HIP_CHECK(hipStreamSynchronize(stream_));
     resize_src_.reserve(row * h);
     resize_tmp_.reserve((size_t)h * rw * bytes);
-    hipEvent_t copied = nullptr;
-    uint8_t* pin = stage_rows(pixels, row, h, stride, &copied);
-    HIP_CHECK(hipMemcpyAsync(resize_src_.get(), pin, row * h, hipMemcpyHostToDevice, stream_));
-    HIP_CHECK(hipEventRecord(copied, stream_));
+    if ((size_t)stride == row && image_memory_is_pinned(pixels, row * h)) {
+        HIP_CHECK(hipMemcpyAsync(resize_src_.get(), pixels, row * h, hipMemcpyHostToDevice, stream_));     // as upload_image
+        HIP_CHECK(hipEventRecord(caller_copied_, stream_));
+        caller_copy_pending_ = true;
+    } else {
+        hipEvent_t copied = nullptr;
+        uint8_t* pin = stage_rows(pixels, row, h, stride, &copied);
+        HIP_CHECK(hipMemcpyAsync(resize_src_.get(), pin, row * h, hipMemcpyHostToDevice, stream_));
+        HIP_CHECK(hipEventRecord(copied, stream_));
+    }
     uint8_t* dev = img_dev_.get() + (size_t)slot * kImageSize * kImageSize * 4;
     k::ResizeAxis kx{ax.first.get(), ax.count.get(), ax.coef.get(), ax.taps, rw};
     k::ResizeAxis ky{ay.first.get(), ay.count.get(), ay.coef.get(), ay.taps, rh};
@@ -1065,6 +1089,7 @@ void SamModel::enqueue_masks(MaskSlot& slot, k::PostJob const* jobs, int count, 
     static const bool direct_allowed = [] { const char* e = std::getenv("DLIMGEDIT_DIRECT_MASKS"); return !e || std::atoi(e) != 0; }();
     constexpr int kDirectMasks = 6;
     const bool direct = direct_allowed && (count == 1 || (count <= kDirectMasks && (!board_ || board_->others_idle(lane_index_))));
+    slot.in_place.assign(count, 0);
     if (direct) {
         uint8_t* pin = static_cast<uint8_t*>(slot.pin.get());
         slot.piece_end.clear();
@@ -1074,7 +1099,10 @@ void SamModel::enqueue_masks(MaskSlot& slot, k::PostJob const* jobs, int count, 
                 HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
                 slot.piece_done.push_back(e);
             }
-            dev_jobs[i].dst = pin + off;
+            // a destination in pinned image memory of the library (the Image the reference's wrapper allocates for the
+            // result through create_image): written where the consumer reads it
+            slot.in_place[i] = image_memory_is_pinned(jobs[i].dst, (size_t)jobs[i].out_w * jobs[i].out_h);
+            dev_jobs[i].dst = slot.in_place[i] ? jobs[i].dst : pin + off;
             off += mask_bytes(jobs[i]);
             bytes = (double)kLowRes * kLowRes * 4 + (double)jobs[i].out_w * jobs[i].out_h;
             timed(ST_POST, bytes, [&] { k::postprocess_masks(&dev_jobs[i], 1, stream_); });
@@ -1130,7 +1158,7 @@ void SamModel::finish_masks(MaskSlot& slot, k::PostJob const* jobs, int count, f
         HIP_CHECK(hipEventSynchronize(slot.piece_done[i]));
         waited_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
         for (MaskCopy const& c : mask_copies_in_piece(sizes, begin, slot.piece_end[i], cursor))
-            std::memcpy(jobs[c.mask].dst + c.mask_offset, pin + c.staging_offset, c.bytes);
+            if (!slot.in_place[c.mask]) std::memcpy(jobs[c.mask].dst + c.mask_offset, pin + c.staging_offset, c.bytes);
         begin = slot.piece_end[i];
     }
     HIP_CHECK(hipEventSynchronize(slot.done));

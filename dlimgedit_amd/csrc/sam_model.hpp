@@ -166,7 +166,10 @@ class SamModel {
 
     // Host image (already at its encoder resolution: longest side 1024) -> slot `slot` of the patch
     // matrix.  Copies through pinned staging and runs the pre-processing kernel.
+    // Pixels in pinned image memory of the library with packed rows are sent from where they lie; the caller waits for
+    // that copy (wait_caller_copies) before it hands the pixels back to their owner.
     void upload_image(int slot, int batch, uint8_t const* pixels, int w, int h, int stride, int channels);
+    void wait_caller_copies();           // mutex() held or not: the event is this lane's own, re-recorded under mutex()
     // Host image whose longest side is not 1024: uploaded at its own size and resampled on the device to
     // rw x rh (reference: dlimg::resize through stb, /root/reference/src/image.cpp:37-51).
     void upload_and_resize_image(int slot, int batch, uint8_t const* pixels, int w, int h, int stride, int channels,
@@ -202,6 +205,9 @@ class SamModel {
         PinnedBuffer pin;
         hipEvent_t done = nullptr;
         size_t iou_offset = 0;
+        // masks whose destination is pinned image memory of the library (csrc/image_memory.hpp) and were written there by
+        // the kernel itself: finish_masks has nothing to copy for them
+        std::vector<char> in_place;
         // the staging area travels to the host in a few pieces, each with its own event, so that the host copies piece i
         // to the caller's buffers while piece i + 1 is still on the bus (enqueue_masks / finish_masks)
         std::vector<hipEvent_t> piece_done;
@@ -283,6 +289,8 @@ class SamModel {
     struct ImageStage { PinnedBuffer pin; hipEvent_t copied = nullptr; };
     ImageStage stage_[kStageRing];
     unsigned stage_seq_ = 0;
+    hipEvent_t caller_copied_ = nullptr;     // behind the last copy that read a caller's pinned pixels directly
+    bool caller_copy_pending_ = false;
     uint8_t* stage_rows(uint8_t const* pixels, size_t row_bytes, int rows, int stride, hipEvent_t* copied);
     DeviceBuffer<half_t> patches_, xn_, xlo_, qkv_, att_, hid_;
     DeviceBuffer<float> x_, xstat_, neck_f32_, emb_;

@@ -300,6 +300,7 @@ void SegmentationImpl::process_batch(EnvironmentImpl& env, SegmentationImpl* con
                     roctx::Range r("dlimg.encode");
                     model.encode(n, emb.data());
                 }
+                model.wait_caller_copies();       // pixels read in place (pinned image memory): theirs again when this returns
                 if (defer) return Queued{nullptr, nullptr, model.defer_last_pass()};
                 const volatile int* overflow = model.last_pass_flag();
                 return Queued{model.completion(), overflow, nullptr};

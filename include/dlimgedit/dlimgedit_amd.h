@@ -75,6 +75,13 @@ DLIMG_API int dlimg_amd_lane_count(dlimg_Environment env);
  * ran in the "GPU to itself" tile configuration (six ints). */
 DLIMG_API int dlimg_amd_queue_config(dlimg_Environment env, int* out);
 
+/* Image memory of the table (load_image / create_image, slots 8 / 10; reference: new[] in src/dlimgedit.cpp:95-118): once a
+ * GPU environment exists in the process such memory is pinned, process_image_for_segmentation reads an image that lies in it
+ * from where it lies and get_segmentation_mask writes a mask whose buffer lies in it in place (csrc/image_memory.hpp).
+ * *out_pinned = 1 when [pixels, pixels + bytes) is inside one live block of that kind, i.e. takes those paths; 0 otherwise
+ * (the program's own buffers: staged through the library's pinned rings as before). */
+DLIMG_API int dlimg_amd_image_memory(void const* pixels, size_t bytes, int* out_pinned);
+
 /* Multi-GPU: number of replicas of the environment (entries of DLIMGEDIT_DEVICES; 1 by default) and, for a
  * segmentation handle, the replica / HIP device index that holds its embedding (either pointer may be null). */
 DLIMG_API int dlimg_amd_replica_count(dlimg_Environment env);

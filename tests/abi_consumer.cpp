@@ -5,8 +5,9 @@
 //
 //   abi_consumer <libdlimgedit.so> probe
 //   abi_consumer <libdlimgedit.so> run <model_dir> <rgba.raw> <w> <h> <px> <py> <out_mask.raw>
-//   abi_consumer <libdlimgedit.so> loop <model_dir> <rgba.raw> <w> <h> <px> <py> <seconds>
-//       the consumer's natural loop -- process(image), compute_mask(point), one thread -- for <seconds>; prints its rate
+//   abi_consumer <libdlimgedit.so> loop <model_dir> <rgba.raw> <w> <h> <px> <py> <seconds> [view]
+//       the consumer's natural loop -- process(image), compute_mask(point), one thread -- for <seconds>; prints its rate.
+//       The pixels are held in a dlimg::Image, as after Image::load ("view": in the program's own buffer instead)
 #define DLIMGEDIT_LOAD_DYNAMIC
 #include <dlimgedit/dlimgedit.hpp>
 
@@ -80,7 +81,7 @@ int main(int argc, char** argv) {
         return 0;
     }
     if (mode == "loop") {
-        if (argc != 10) return fail("loop needs <model_dir> <rgba.raw> <w> <h> <px> <py> <seconds>");
+        if (argc != 10 && argc != 11) return fail("loop needs <model_dir> <rgba.raw> <w> <h> <px> <py> <seconds> [view]");
         const int w = std::atoi(argv[5]), h = std::atoi(argv[6]);
         const dlimg::Point point{std::atoi(argv[7]), std::atoi(argv[8])};
         const double seconds = std::atof(argv[9]);
@@ -92,7 +93,12 @@ int main(int argc, char** argv) {
             opts.backend = dlimg::Backend::gpu;
             opts.model_directory = argv[3];
             dlimg::Environment env(opts);
-            auto view = dlimg::ImageView(pixels.data(), dlimg::Extent{w, h}, dlimg::Channels::rgba);
+            // the pixels as a consumer holds them after Image::load: in an Image (the raw file stands in for a PNG so that
+            // the test needs no encoder); argv[10] == "view" keeps them in the program's own buffer instead
+            dlimg::Image image(dlimg::Extent{w, h}, dlimg::Channels::rgba);
+            std::memcpy(image.pixels(), pixels.data(), pixels.size());
+            const bool own_buffer = argc == 11 && std::string(argv[10]) == "view";
+            auto view = own_buffer ? dlimg::ImageView(pixels.data(), dlimg::Extent{w, h}, dlimg::Channels::rgba) : dlimg::ImageView(image);
             using clock = std::chrono::steady_clock;
             auto elapsed = [](clock::time_point a) { return std::chrono::duration<double>(clock::now() - a).count(); };
             size_t set_pixels = 0;
