@@ -699,6 +699,19 @@ def main() -> None:
             seg.close()
             return 1
 
+        # the same with the pixels held as the reference's wrapper holds a loaded image: in an Image, i.e. in memory from the
+        # table's create_image / load_image, which this library pins and reads in place (csrc/image_memory.hpp); the result
+        # masks are Images in both forms (api.py mirrors the wrapper's compute_mask), written in place
+        held = api.Image(api.Extent(imgs[0].shape[1], imgs[0].shape[0]), api.Channels.rgba)
+        held.pixels()[...] = imgs[0]
+        held_view = held.view()
+
+        def one_image_held():
+            seg = api.Segmentation.process(held_view, env)
+            seg.compute_mask(api.Point(512, 512))
+            seg.close()
+            return 1
+
         # slot 3 alone, one thread: process() returns once its pass is enqueued (csrc/segmentation.hpp), so a loop over images
         # keeps the lanes fed by itself; a handle is closed (which waits for its pass) eight images later
         open_handles = []
@@ -754,8 +767,11 @@ def main() -> None:
         }
         cached.close()
         result["abi_path"] = {
-            "unit": "images/s", "note": "host pixels in, host masks out through dlimg_Api; PCIe and host copies included",
+            "unit": "images/s", "note": "host pixels in, host masks out through dlimg_Api; PCIe and host copies included; pixels in a numpy buffer "
+                                        "of the program's own (staged through the library's pinned ring) unless the key says "
+                                        "otherwise, result masks in Images from create_image as the reference's wrapper makes them",
             "slots_3_4_one_thread": rate(one_image, 1),
+            "slots_3_4_one_thread_pixels_in_an_Image": rate(one_image_held, 1),
             f"slots_3_4_{lanes}_threads": rate(one_image, lanes),
             "slots_13_14_batch8_one_thread": rate(batch8, 1),
             "slots_13_14_batch8_two_threads": rate(batch8, 2),

@@ -333,9 +333,11 @@ class Segmentation:
         api().get_segmentation_extent(self._handle, out)
         return Extent(out[0], out[1])
 
-    def _query(self, point, region, n_masks):
+    def _query(self, point, region, n_masks, out=None):
         e = self.extent()
-        masks = [_mask_image(e) for _ in range(n_masks)]
+        masks = [_mask_image(e) for _ in range(n_masks)] if out is None else list(out)
+        assert len(masks) == n_masks and all(m.shape == (e.height, e.width) and m.dtype == np.uint8 and
+                                              m.flags.c_contiguous for m in masks)
         ptrs = (C.c_void_p * 3)(*([m.ctypes.data for m in masks] + [None] * (3 - n_masks)))
         acc = (C.c_float * 3)(0.0, 0.0, 0.0)
         p = (C.c_int * 2)(point.x, point.y) if point is not None else None
@@ -344,12 +346,14 @@ class Segmentation:
         _check(api().get_segmentation_mask(self._handle, p, r, ptrs, acc))
         return masks, list(acc)
 
-    def compute_mask(self, prompt) -> np.ndarray:
-        """Point -> best mask; Region -> mask of the largest object in the box."""
+    def compute_mask(self, prompt, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """Point -> best mask; Region -> mask of the largest object in the box.  `out`: the caller's own (h, w) uint8 buffer
+        (the wrapper's compute_mask(point, uint8_t*) form) instead of a new Image of the library."""
+        outs = None if out is None else [out]
         if isinstance(prompt, Point):
-            return self._query(prompt, None, 1)[0][0]
+            return self._query(prompt, None, 1, outs)[0][0]
         if isinstance(prompt, Region):
-            return self._query(None, prompt, 1)[0][0]
+            return self._query(None, prompt, 1, outs)[0][0]
         raise TypeError("prompt must be a Point or a Region")
 
     def compute_masks(self, point: Point) -> list:
@@ -358,10 +362,11 @@ class Segmentation:
 
     @staticmethod
     def compute_mask_batch(segs: Sequence["Segmentation"], points: Optional[Sequence[Point]] = None,
-                           regions: Optional[Sequence[Region]] = None) -> list:
+                           regions: Optional[Sequence[Region]] = None, out: Optional[Sequence[np.ndarray]] = None) -> list:
         n = len(segs)
         handles = (C.c_void_p * n)(*[s._handle for s in segs])
-        outs = [_mask_image(s.extent()) for s in segs]
+        outs = [_mask_image(s.extent()) for s in segs] if out is None else list(out)
+        assert len(outs) == n and all(o.dtype == np.uint8 and o.flags.c_contiguous for o in outs)
         ptrs = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
         p = r = None
         if points is not None:

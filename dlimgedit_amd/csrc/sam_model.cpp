@@ -1124,6 +1124,32 @@ void SamModel::enqueue_masks(MaskSlot& slot, k::PostJob const* jobs, int count, 
     if (iou_count > 0)
         HIP_CHECK(hipMemcpyAsync(slot.dev.get() + total, iou_.get(), (size_t)iou_count * sizeof(float),
                                  hipMemcpyDeviceToDevice, stream_));
+    // every destination is pinned image memory of the library (Images of the reference's wrapper): one copy command per mask
+    // from the device buffer to where the consumer reads it, nothing for the host to copy afterwards
+    bool all_pinned = true;
+    for (int i = 0; i < count && all_pinned; ++i)
+        all_pinned = image_memory_is_pinned(jobs[i].dst, (size_t)jobs[i].out_w * jobs[i].out_h);
+    if (all_pinned) {
+        slot.in_place.assign(count, 1);
+        size_t from = 0;
+        for (int i = 0; i < count; ++i) {
+            HIP_CHECK(hipMemcpyAsync(jobs[i].dst, slot.dev.get() + from, (size_t)jobs[i].out_w * jobs[i].out_h, hipMemcpyDeviceToHost, stream_));
+            from += mask_bytes(jobs[i]);
+        }
+        if (iou_count > 0)
+            HIP_CHECK(hipMemcpyAsync(static_cast<uint8_t*>(slot.pin.get()) + total, slot.dev.get() + total,
+                                     (size_t)iou_count * sizeof(float), hipMemcpyDeviceToHost, stream_));
+        if (slot.piece_done.empty()) {
+            hipEvent_t e = nullptr;
+            HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            slot.piece_done.push_back(e);
+        }
+        slot.piece_end.assign(1, with_iou);
+        HIP_CHECK(hipEventRecord(slot.piece_done[0], stream_));
+        HIP_CHECK(hipEventRecord(slot.done, stream_));
+        mark_activity();
+        return;
+    }
     // device -> pinned host in pieces, each with its own event (mask_pieces.hpp)
     slot.piece_end = mask_piece_ends(with_iou);
     size_t a = 0;

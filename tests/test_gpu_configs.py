@@ -140,6 +140,11 @@ def test_config5_vit_h_mixed_resolution_five_prompts_on_cached_embedding(api, fu
     flat_pts = [api.Point(*p) for ps in prompts for p in ps]
     masks = api.Segmentation.compute_mask_batch(flat_segs, points=flat_pts)
     assert len(masks) == 80
+    # ... into Images of the library (copied from the device to where they lie); into buffers of the caller's own the masks
+    # pass through the pinned staging pieces: the same bits
+    own = [np.empty(m.shape, dtype=np.uint8) for m in masks]
+    api.Segmentation.compute_mask_batch(flat_segs, points=flat_pts, out=own)
+    assert all(np.array_equal(a, b) for a, b in zip(own, masks))
     for k, (seg, pt, mask) in enumerate(zip(flat_segs, flat_pts, masks)):
         w, h = sizes[k // 5]
         assert seg.extent() == api.Extent(w, h)

@@ -310,8 +310,18 @@ def test_masks_written_straight_to_host_memory_equal_the_copied_ones(api, sessio
     for handle, (w, h) in ((seg, (1024, 1024)), (wide, (1800, 1200))):
         pts = [api.Point(37 + (w - 80) * k // n_prompts, h - 45 - (h - 90) * k // n_prompts) for k in range(n_prompts)]
         together = api.Segmentation.compute_mask_batch([handle] * n_prompts, points=pts)
-        for p, m in zip(pts, together):
-            assert m.shape == (h, w) and np.array_equal(m, handle.compute_mask(p))
+        # the same into buffers of the program's own (staged and copied; the default results are Images of the library,
+        # written in place: csrc/image_memory.hpp), and into a mix of both (one foreign buffer: all staged)
+        own = [np.empty((h, w), dtype=np.uint8) for _ in pts]
+        api.Segmentation.compute_mask_batch([handle] * n_prompts, points=pts, out=own)
+        mixed = [api.Image(api.Extent(w, h), api.Channels.mask).pixels().reshape(h, w) for _ in pts]
+        mixed[n_prompts // 2] = np.empty((h, w), dtype=np.uint8)
+        api.Segmentation.compute_mask_batch([handle] * n_prompts, points=pts, out=mixed)
+        for p, m, o, x in zip(pts, together, own, mixed):
+            assert api.ext.image_memory_is_pinned(m) and not api.ext.image_memory_is_pinned(o)
+            single = handle.compute_mask(p)
+            assert m.shape == (h, w) and np.array_equal(m, single) and np.array_equal(o, single) and np.array_equal(x, single)
+            assert np.array_equal(handle.compute_mask(p, out=np.empty((h, w), dtype=np.uint8)), single)
     three = wide.compute_masks(api.Point(900, 600))
     again = wide.compute_masks(api.Point(900, 600))
     assert all(np.array_equal(a.image, b.image) and a.accuracy == b.accuracy for a, b in zip(three, again))
