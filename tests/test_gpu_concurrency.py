@@ -417,3 +417,58 @@ def test_process_leaves_the_wait_to_the_first_query(setup, monkeypatch):
         if i % 17 == 0 or i >= len(held) - 2:
             assert np.array_equal(seg.compute_mask(pt), want[i % 3][1])
         seg.close()
+
+
+def test_image_memory_under_concurrent_callers(setup):
+    """Six threads for a few seconds: images held in library Images (read in place) or in the thread's own arrays (staged), at
+    three sizes, masks into Images (written in place) or into own buffers, five-prompt batches, and Images of assorted sizes
+    created and dropped all the while (the free lists of csrc/image_memory.cpp).  Every mask equals the one computed up front."""
+    import random
+    import time
+    api, env = setup
+    sizes = [(1024, 1024), (800, 600), (640, 960)]
+    pixels = [synthetic_image(60 + i, width=w, height=h) for i, (w, h) in enumerate(sizes)]
+    pts = [api.Point(w // 2, h // 2) for w, h in sizes]
+    want = []
+    for px, pt in zip(pixels, pts):
+        seg = api.Segmentation.process(api.ImageView(px, api.Channels.rgba), env)
+        want.append(np.array(seg.compute_mask(pt)))
+        seg.close()
+    errors, counts = [], [0] * 6
+    stop = time.perf_counter() + 4.0
+
+    def worker(t):
+        rng = random.Random(t)
+        try:
+            held = []
+            for (w, h), px in zip(sizes, pixels):
+                im = api.Image(api.Extent(w, h), api.Channels.rgba)
+                im.pixels()[...] = px
+                held.append(im)
+            while time.perf_counter() < stop:
+                i = rng.randrange(3)
+                w, h = sizes[i]
+                view = held[i].view() if rng.random() < 0.5 else api.ImageView(pixels[i], api.Channels.rgba)
+                seg = api.Segmentation.process(view, env)
+                churn = [api.Image(api.Extent(rng.randrange(8, 700), rng.randrange(8, 700)), api.Channels.mask) for _ in range(3)]
+                mode = rng.randrange(3)
+                if mode == 0:
+                    got = [seg.compute_mask(pts[i])]
+                elif mode == 1:
+                    got = [seg.compute_mask(pts[i], out=np.empty((h, w), dtype=np.uint8))]
+                else:
+                    got = api.Segmentation.compute_mask_batch([seg] * 5, points=[pts[i]] * 5)
+                del churn
+                for g in got:
+                    if not np.array_equal(g, want[i]):
+                        raise AssertionError(f"thread {t}: mask of size {sizes[i]} differs (mode {mode})")
+                seg.close()
+                counts[t] += 1
+        except Exception as e:       # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
+    assert min(counts) > 0
