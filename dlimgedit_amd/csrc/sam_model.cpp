@@ -635,6 +635,8 @@ void SamModel::upload_image(int slot, int batch, uint8_t const* pixels, int w, i
     HIP_CHECK(hipEventSynchronize(st.copied));       // the copy that last read this entry has run
     st.pin.reserve(row * h);                         // (re-allocation is safe for the same reason)
     uint8_t* pin = static_cast<uint8_t*>(st.pin.get());
+    // (r06, the wrapper's own loop with a 4 MiB image: pieces of 4 / 2 / 1 / 0.5 / 0.25 MiB = 468 / 478 / 478 / 464 / 448 images/s
+    // -- a copy command costs ~9 us of its own; from pinned image memory, one command and no packing: 493)
     const int pieces = (int)std::min<size_t>(8, std::max<size_t>(1, row * h / (1u << 20)));
     for (int p = 0; p < pieces; ++p) {
         const int y0 = (int)((long)h * p / pieces), y1 = (int)((long)h * (p + 1) / pieces);
