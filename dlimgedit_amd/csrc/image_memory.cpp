@@ -19,6 +19,7 @@ struct Registry {
     std::map<uintptr_t, Block> live;                              // by first byte
     std::unordered_map<size_t, std::vector<void*>> cached;        // released pinned blocks by capacity
     size_t cached_bytes = 0, cached_blocks = 0;
+    size_t live_pinned_bytes = 0;
 };
 
 // lives for the whole process (never destroyed: images may be released from static destructors of the host program)
@@ -32,6 +33,9 @@ std::atomic<bool> g_pinned{false};
 // Pinning costs ~0.1-0.3 ms per MiB, so released blocks are kept for the next image of that size; a consumer cycles through
 // a handful of sizes (its images, their masks).  Beyond this much cached memory a released block goes back to the system.
 constexpr size_t kCacheLimitBytes = size_t(512) << 20;
+// Pinned pages cannot be swapped or moved: a consumer that keeps thousands of masks alive gets pageable memory (and the
+// staged path) for what goes beyond this much live pinned image memory.
+constexpr size_t kLivePinnedLimitBytes = size_t(4) << 30;
 constexpr size_t kGranule = 64 * 1024;         // pinned capacities are multiples of this: masks of nearby sizes share blocks
 
 size_t pinned_capacity(size_t bytes) { return (bytes + kGranule - 1) / kGranule * kGranule; }
@@ -53,10 +57,12 @@ uint8_t* image_alloc(size_t bytes) noexcept {
         if (g_pinned.load(std::memory_order_acquire)) {
             const size_t cap = pinned_capacity(bytes);
             void* p = nullptr;
+            bool room = false;
             {
                 std::lock_guard<std::mutex> lock(r.mutex);
+                room = r.live_pinned_bytes + cap <= kLivePinnedLimitBytes;
                 auto it = r.cached.find(cap);
-                if (it != r.cached.end() && !it->second.empty()) {
+                if (room && it != r.cached.end() && !it->second.empty()) {
                     p = it->second.back();
                     it->second.pop_back();
                     r.cached_bytes -= cap;
@@ -64,13 +70,14 @@ uint8_t* image_alloc(size_t bytes) noexcept {
                 }
             }
             // portable: every GPU of a multi-replica environment reads and writes it
-            if (!p && hipHostMalloc(&p, cap, hipHostMallocPortable) != hipSuccess) {
+            if (room && !p && hipHostMalloc(&p, cap, hipHostMallocPortable) != hipSuccess) {
                 (void)hipGetLastError();
                 p = nullptr;                         // no pinned memory to be had: a pageable block serves as well
             }
             if (p) {
                 std::lock_guard<std::mutex> lock(r.mutex);
                 r.live[reinterpret_cast<uintptr_t>(p)] = Block{cap, true};
+                r.live_pinned_bytes += cap;
                 return static_cast<uint8_t*>(p);
             }
         }
@@ -96,6 +103,7 @@ void image_free(uint8_t const* pixels) noexcept {
         if (it == r.live.end()) return;              // not ours (or released twice): the reference would corrupt its heap here
         b = it->second;
         r.live.erase(it);
+        if (b.pinned) r.live_pinned_bytes -= b.capacity;
         if (b.pinned && r.cached_bytes + b.capacity <= kCacheLimitBytes) {
             r.cached[b.capacity].push_back(p);
             r.cached_bytes += b.capacity;

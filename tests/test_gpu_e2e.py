@@ -299,6 +299,21 @@ def test_images_of_the_library_are_read_and_written_in_place(api, session, tmp_p
     api.api().destroy_image(np.zeros(16, dtype=np.uint8).ctypes.data)
 
 
+def test_pinned_image_memory_is_bounded(api, session):
+    """Pinned pages cannot be swapped: beyond 4 GiB of live pinned image memory create_image hands out pageable blocks (which
+    take the staged path), and of the released ones at most 512 MiB stay cached (csrc/image_memory.cpp)."""
+    env, _, _, _, seg, _ = session
+    big = api.Extent(8192, 8192)                 # 64 MiB per mask image
+    held = [api.Image(big, api.Channels.mask) for _ in range(66)]
+    pinned = [api.ext.image_memory_is_pinned(im.pixels()) for im in held]
+    assert all(pinned[:60]) and not any(pinned[64:])
+    held[-1].pixels()[:16, :16] = 7              # pageable blocks are ordinary memory
+    del held
+    small = api.Image(api.Extent(1024, 1024), api.Channels.mask)          # below the limit again: pinned
+    assert api.ext.image_memory_is_pinned(small.pixels())
+    assert np.array_equal(seg.compute_mask(api.Point(512, 512)), seg.compute_mask(api.Point(512, 512), out=np.empty((1024, 1024), np.uint8)))
+
+
 @pytest.mark.parametrize("n_prompts", [2, 5, 6, 7])
 def test_masks_written_straight_to_host_memory_equal_the_copied_ones(api, session, n_prompts):
     """Up to six masks of a call leave as one post-processing launch each, straight into pinned host memory (while the other
