@@ -72,7 +72,10 @@ typedef struct dlimg_Api {
     void (*destroy_environment)(dlimg_Environment);
 
     /* Encodes one image.  *out_seg is assigned before encoding starts, so on dlimg_error the
-     * caller still owns a handle and must destroy it.  Pixels are only read during the call. */
+     * caller still owns a handle and must destroy it.  Pixels are only read during the call.
+     * The call returns once the pixels have been taken and the encoder pass is enqueued; the first call that needs
+     * the embedding (get_segmentation_mask, ...) waits for it, and reports a pass that produced non-finite values
+     * (DLIMGEDIT_SYNC_PROCESS=1: this call waits itself, as the reference's does). */
     dlimg_Result (*process_image_for_segmentation)(dlimg_Segmentation* out_seg, dlimg_ImageView const* image,
                                                    dlimg_Environment env);
 
@@ -92,7 +95,9 @@ typedef struct dlimg_Api {
     dlimg_Result (*load_image)(char const* filepath, int* out_extent, int* out_channels, uint8_t** out_pixels);
     dlimg_Result (*save_image)(dlimg_ImageView const* image, char const* filepath);
 
-    /* w*h*channels uninitialised bytes; release with destroy_image. */
+    /* w*h*channels uninitialised bytes; release with destroy_image.  Once a GPU environment exists in the process this
+     * memory (and load_image's) is pinned: images that lie in it are uploaded from where they lie, masks whose buffer
+     * lies in it are written in place by the GPU.  destroy_image ignores foreign pointers. */
     uint8_t* (*create_image)(int width, int height, int channels);
     void (*destroy_image)(uint8_t const* pixels);
 
