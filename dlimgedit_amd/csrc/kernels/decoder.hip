@@ -12,6 +12,8 @@
 namespace dlimg {
 namespace {
 
+#include "gemm_f16_tile.inc"
+
 constexpr int TOK = 7;        // iou token + 4 mask tokens + 2 prompt tokens
 constexpr int DIM = 256;
 constexpr int INNER = 128;    // cross-attention width (downsample 2)
@@ -443,15 +445,14 @@ DLIMG_DEVICE float sum_over_32_lanes(float v) {
     v += dpp_move<0x140>(v);
     return v + __shfl_xor(v, 16, 64);
 }
-__global__ __launch_bounds__(256) void token_self_attn_out_kernel(const float* __restrict__ q, const float* __restrict__ kx,
-                                                                  const float* __restrict__ v, k::TokenLinear op, int P) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    // prompts are dealt to blockIdx.y in pairs (rows row0 .. row1 of the token matrix; LDS rows are local)
-    const int p0 = blockIdx.y * TL_PROMPT_SLICE, p1 = min(P, p0 + TL_PROMPT_SLICE);
+DLIMG_DEVICE void token_self_attn_out_body(const float* __restrict__ q, const float* __restrict__ kx, const float* __restrict__ v,
+                                           const k::TokenLinear& op, int P, const int block_x, const int block_y, float* lds) {
+    // prompts are dealt to block_y in pairs (rows row0 .. row1 of the token matrix; LDS rows are local)
+    const int p0 = block_y * TL_PROMPT_SLICE, p1 = min(P, p0 + TL_PROMPT_SLICE);
     const int row0 = p0 * TOK, row1 = p1 * TOK;
     float* att = lds;                                   // [rows of this slice][256]
     float2_t* stat_res = reinterpret_cast<float2_t*>(att + (size_t)TL_PROMPT_SLICE * TOK * DIM) - row0;     // indexed by global row
-    const TokenColumn w_first = token_column_prefetch(op, blockIdx.x * 4, row0, row1);
+    const TokenColumn w_first = token_column_prefetch(op, block_x * 4, row0, row1);
     const int c = threadIdx.x;
     const float scale = 0.17677669529663687f;           // 32^-0.5
     for (int p = p0; p < p1; ++p) {
@@ -483,7 +484,35 @@ __global__ __launch_bounds__(256) void token_self_attn_out_kernel(const float* _
     }
     if (op.resid.x && op.resid.ln_w) token_row_stats(op.resid, row1, stat_res, row0);
     __syncthreads();
-    DLIMG_FOR_SLICE_ROWS(row1 - row0, token_linear_columns<NR>(op, blockIdx.x * 4, att, nullptr, stat_res, w_first, row0);)
+    DLIMG_FOR_SLICE_ROWS(row1 - row0, token_linear_columns<NR>(op, block_x * 4, att, nullptr, stat_res, w_first, row0);)
+}
+__global__ __launch_bounds__(256) void token_self_attn_out_kernel(const float* __restrict__ q, const float* __restrict__ kx,
+                                                                  const float* __restrict__ v, k::TokenLinear op, int P) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    token_self_attn_out_body(q, kx, v, op, P, blockIdx.x, blockIdx.y, lds);
+}
+
+// The same launch with the layer's image-side projection riding along: [K | Q | V] = keys . W^T (decoder_image side, an MFMA
+// GEMM of 64 x 64 tiles, gemm_f16_tile) does not depend on the token self-attention and the self-attention not on it, and
+// on their own they are 14 and 19 us one after the other, twice per decode (the stream is in order; a second stream costs
+// more in cross-queue waits than it hides, and hipExtAnyOrderLaunch is not honoured on gfx950: LABNOTES r06).  The first
+// `gemm_tiles` workgroups take one GEMM tile each -- the same code, tile shape and K order as the launch of its own, so the
+// same bits -- the rest are the self-attention's workgroups.  Both parts use 256 threads.
+constexpr int SAG_BM = 64, SAG_BN = 64;
+constexpr size_t SAG_GEMM_LDS = (size_t)2 * (SAG_BM + SAG_BN) * 64 * 2 + aux_bytes(SAG_BM, SAG_BN);
+constexpr size_t SAG_TOKEN_LDS = (size_t)TL_PROMPT_SLICE * TOK * (DIM * 4 + 8);
+constexpr size_t SAG_LDS = SAG_GEMM_LDS > SAG_TOKEN_LDS ? SAG_GEMM_LDS : SAG_TOKEN_LDS;
+static_assert(SAG_LDS <= 48 * 1024, "below the default dynamic-LDS limit: no opt-in needed");
+__global__ __launch_bounds__(256, 4) void self_attn_out_and_gemm_kernel(k::GemmArgs g, int gemm_tiles, const float* __restrict__ q,
+                                                                        const float* __restrict__ kx, const float* __restrict__ v,
+                                                                        k::TokenLinear op, int P, int token_blocks_x) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x < gemm_tiles) {
+        gemm_f16_tile<SAG_BM, SAG_BN, 2, 2, 64, 2, 4, k::ACT_NONE, EPI_PLAIN>(g, xcd_remap(blockIdx.x, gemm_tiles), smem);
+        return;
+    }
+    const int b = (int)blockIdx.x - gemm_tiles;
+    token_self_attn_out_body(q, kx, v, op, P, b % token_blocks_x, b / token_blocks_x, reinterpret_cast<float*>(smem));
 }
 
 // The rest of the token-to-image attention, done by its CONSUMERS (a launch of its own cost 9-16 us for 0.2 MFLOP):
@@ -872,6 +901,21 @@ void token_self_attention_out(const float* q, const float* kx, const float* v, c
     static_assert((size_t)TL_PROMPT_SLICE * TOK * (DIM * 4 + 8) <= 64 * 1024, "below the default dynamic-LDS limit: no opt-in needed");
     hipLaunchKernelGGL(token_self_attn_out_kernel, dim3(out.N / 4, (P + TL_PROMPT_SLICE - 1) / TL_PROMPT_SLICE), dim3(256), lds, s, q, kx,
                        v, out, P);
+}
+
+bool token_self_attention_out_with_gemm(const float* q, const float* kx, const float* v, const TokenLinear& out, int P,
+                                        const GemmArgs& g, hipStream_t s) {
+    if (P <= 0) return true;
+    if (P * TOK > TL_MAX_ROWS || out.K != DIM || out.N % 4) throw_error("token_self_attention_out: unsupported shape");
+    // what the 64 x 64 plain tile computes, and nothing else: otherwise the caller launches the two on their own
+    if (const char* err = gemm_check(g)) throw_error(err);
+    const bool plain = !g.out_l && !g.resid_h && !g.ln_stats && !g.stats_out && g.act == ACT_NONE && g.M % SAG_BM == 0 &&
+                       g.N % SAG_BN == 0 && g.K % 64 == 0 && !(g.resid && g.resid_mod % SAG_BM != 0);
+    if (!plain) return false;
+    const int tiles = (g.M / SAG_BM) * (g.N / SAG_BN);
+    const int bx = out.N / 4, by = (P + TL_PROMPT_SLICE - 1) / TL_PROMPT_SLICE;
+    hipLaunchKernelGGL(self_attn_out_and_gemm_kernel, dim3(tiles + bx * by), dim3(256), SAG_LDS, s, g, tiles, q, kx, v, out, P, bx);
+    return true;
 }
 
 void token_merge_linear(const float* scratch, const TokenLinear& out, const float* out_wt, const TokenLinear& next, int P,

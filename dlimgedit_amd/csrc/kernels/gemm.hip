@@ -70,284 +70,7 @@ constexpr bool kNoStreamStore = true;
 constexpr bool kNoStreamStore = false;
 #endif
 
-// LDS rows hold BKT halves (128 or 64 bytes).  The 16-byte chunk index is XOR-swizzled with row bits so that
-// the 16 rows a ds_read_b128 lane group touches land on 16 different 16-byte slots of the 256-byte bank row.
-template <int BKT> DLIMG_DEVICE int swz(int row) { return BKT == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
-// Variant for the 16x16x32 MFMA fragment pattern on 64-byte rows (a ds_read_b128 lane group then spans two
-// chunk columns): chunk ^= perm[(row>>2)&3], perm = {0,2,3,1}, which again gives 16 distinct slots per group.
-DLIMG_DEVICE int swz16(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
-
-// Issue the DMA copies of one ROWS x BKT operand tile (rows r0.. of `src`, K offset k0) into `lds`.
-// One wave-instruction moves 1 KiB = RPP rows; the pieces are dealt round-robin to the NW waves.
-template <int ROWS, int BKT, int NW, int SW = 0>
-DLIMG_DEVICE void stage_tile(const half_t* __restrict__ src, int ld, int r0, int k0, char* lds, int wave, int lane) {
-    constexpr int ROW_BYTES = BKT * 2;
-    constexpr int RPP = 1024 / ROW_BYTES;       // rows per piece (8 or 16)
-    constexpr int CPR = ROW_BYTES / 16;         // chunks per row (8 or 4)
-    constexpr int PIECES = ROWS / RPP;
-    static_assert(PIECES % NW == 0, "operand tile must split evenly over the waves");
-#pragma unroll
-    for (int q = 0; q < PIECES / NW; ++q) {
-        const int p = q * NW + wave;
-        const int row = p * RPP + lane / CPR;
-        const int chunk = (lane % CPR) ^ (SW ? swz16(row) : swz<BKT>(row));     // source-side swizzle, LDS stays linear
-        const half_t* g = src + (size_t)(r0 + row) * ld + k0 + chunk * 8;
-        glds16(g, lds + p * 1024);
-    }
-}
-
-template <int BKT> DLIMG_DEVICE half8_t read_frag(const char* lds, int row, int chunk) {
-    return *reinterpret_cast<const half8_t*>(lds + row * (BKT * 2) + ((chunk ^ swz<BKT>(row)) << 4));
-}
-
-// Epilogue flavours: compile-time, so the plain GEMM does not carry the registers of the others
-// (the shared epilogue code is in gemm_epilogue.inc).
-enum { EPI_PLAIN = 0, EPI_NORM = 1, EPI_STATS = 2 };
-
-// LayerNorm folded into the GEMMs around it.
-//   EPI_STATS (the GEMM that writes the residual stream): besides the result, every workgroup leaves for each of its
-//     rows the (sum, sum of squared deviations from the tile mean) over the tile's BN columns -- reduced over 8 lanes
-//     by DPP per 32 columns in the epilogue, merged per row in LDS in a fixed order -> stats[N/BN][M] in HBM, a few
-//     bytes per row.
-//   EPI_NORM (the GEMM that consumes the normalised stream): A is the raw stream (its f16 copy), W carries the
-//     LayerNorm scale; the workgroup merges the N/BN partials of its rows (Chan et al.) into (mean, rstd) while the
-//     first operand tiles are in flight, and the epilogue applies  y = rstd_m * (acc - mean_m * colsum_n) + bias'_n .
-// No atomics, fixed summation order: results do not depend on timing.  Nothing is added to the MFMA loops (VALU work
-// there costs the GEMM 10-20 %, measured).
-constexpr int kStatRegs = 12;                    // partials per lane: N/BN <= 12 * (threads per row)
-
-template <int BM, int NTHREADS, int EPI>
-struct RowStats {
-    static constexpr int TPR = NTHREADS / BM;    // adjacent lanes that share a row
-    static_assert(TPR >= 1 && TPR <= 8 && (TPR & (TPR - 1)) == 0 && BM * TPR == NTHREADS, "row statistics layout");
-    float2_t q[EPI == EPI_NORM ? kStatRegs : 1];
-
-    DLIMG_DEVICE void issue(const k::GemmArgs& a, int m0) {
-        if (EPI != EPI_NORM) return;
-        const int r = threadIdx.x / TPR, sub = threadIdx.x % TPR;
-        // [group][row]: the lanes of one load instruction read runs of consecutive rows
-        const float2_t* p = reinterpret_cast<const float2_t*>(a.ln_stats) + (size_t)sub * a.M + (m0 + r);
-#pragma unroll
-        for (int u = 0; u < kStatRegs; ++u) {
-            q[u] = float2_t{0.f, -1.f};          // M2 < 0 marks "no such group"
-            if (sub + u * TPR < a.ln_groups) q[u] = p[(size_t)u * TPR * a.M];
-        }
-    }
-    DLIMG_DEVICE void finish(const k::GemmArgs& a, float* rowstat) {
-        if (EPI != EPI_NORM) return;
-        float s1 = 0.f;
-#pragma unroll
-        for (int u = 0; u < kStatRegs; ++u) s1 += q[u][0];
-#pragma unroll
-        for (int o = 1; o < TPR; o <<= 1) s1 += __shfl_xor(s1, o, 64);
-        const float n_g = (float)(a.K / a.ln_groups), inv_n_g = 1.0f / n_g;
-        const float mean = s1 / (float)a.K;
-        float m2 = 0.f;
-#pragma unroll
-        for (int u = 0; u < kStatRegs; ++u) {
-            const float dm = q[u][0] * inv_n_g - mean;
-            m2 += q[u][1] >= 0.f ? q[u][1] + n_g * dm * dm : 0.f;
-        }
-#pragma unroll
-        for (int o = 1; o < TPR; o <<= 1) m2 += __shfl_xor(m2, o, 64);
-        if (threadIdx.x % TPR == 0)
-            reinterpret_cast<float2_t*>(rowstat)[threadIdx.x / TPR] = float2_t{mean, rsqrtf(m2 / (float)a.K + a.ln_eps)};
-    }
-};
-
-// EPI_STATS, after the last slab: one thread per row merges the 32-column partials of the tile (LDS, [BM][BN/32])
-// in column order and writes the tile's (sum, M2) of that row.
-template <int BM, int BN>
-DLIMG_DEVICE void write_tile_stats(const k::GemmArgs& a, const float2_t* rowpart, int m0, int n0) {
-    constexpr int G = BN / 32;
-    for (int r = threadIdx.x; r < BM; r += blockDim.x) {
-        float s1 = 0.f;
-#pragma unroll
-        for (int g = 0; g < G; ++g) s1 += rowpart[r * G + g][0];
-        const float mean = s1 * (1.0f / (float)BN);
-        float m2 = 0.f;
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const float dm = rowpart[r * G + g][0] * (1.0f / 32.0f) - mean;
-            m2 += rowpart[r * G + g][1] + 32.0f * dm * dm;
-        }
-        reinterpret_cast<float2_t*>(a.stats_out)[(size_t)(n0 / BN) * a.M + m0 + r] = float2_t{s1, m2};
-    }
-}
-
-// LDS behind the operand ring: rowstat [BM] x (mean, rstd), then colvec [2][BN] = bias and LayerNorm column sums of
-// the tile's columns (fetched once at kernel start: per-slab global loads would expose their latency every time)
-constexpr int aux_bytes(int bm, int bn) { return bm * 8 + bn * 8; }
-
-template <int BM, int BN, int NTHREADS, int EPI>
-struct ColumnVectors {
-    float4_t b, c;
-    DLIMG_DEVICE void issue(const k::GemmArgs& a, int n0) {
-        b = c = float4_t{0.f, 0.f, 0.f, 0.f};
-        static_assert(BN / 4 <= NTHREADS, "one float4 of the column vectors per thread");
-        if (threadIdx.x < BN / 4) {
-            if (a.bias) b = *reinterpret_cast<const float4_t*>(a.bias + n0 + threadIdx.x * 4);
-            if (EPI == EPI_NORM) c = *reinterpret_cast<const float4_t*>(a.ln_colsum + n0 + threadIdx.x * 4);
-        }
-    }
-    DLIMG_DEVICE void store(float* colvec) {
-        if (threadIdx.x < BN / 4) {
-            *reinterpret_cast<float4_t*>(colvec + threadIdx.x * 4) = b;
-            if (EPI == EPI_NORM) *reinterpret_cast<float4_t*>(colvec + BN + threadIdx.x * 4) = c;
-        }
-    }
-};
-
-// vmcnt(N): wait until at most N of this wave's DMA copies are still in flight
-template <int N> DLIMG_DEVICE void wait_dma() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-// ABL (tuning builds only): 0 = real kernel, 1 = no MFMA / fragment reads (operand streaming alone),
-// 2 = no operand streaming after the first tile (MFMA + LDS reads alone).  Outputs are wrong for ABL != 0.
-// MINW = waves per SIMD the register allocation must leave room for (workgroups per CU x waves / 4).
-template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE, int MINW, int ACT, int EPI = EPI_PLAIN, int ABL = 0>
-__global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_f16_kernel(k::GemmArgs a) {
-    constexpr int NW = WGM * WGN;                   // waves per workgroup (4 or 8)
-    static_assert(NW == 4 || NW == 8, "four or eight waves per workgroup");
-    static_assert(NSTAGE >= 2 && NSTAGE <= 5, "2..5 LDS stages");
-    static_assert(BKT == 32 || BKT == 64, "K tile of 32 or 64");
-    constexpr int ROW_BYTES = BKT * 2;
-    constexpr int WM = BM / WGM, WN = BN / WGN;     // wave tile
-    constexpr int TM = WM / 32, TN = WN / 32;       // 32x32 MFMA tiles per wave
-    constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
-    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;  // stage b: A tile at b*STAGE_BYTES, B tile behind it
-    constexpr int LOADS = (BM + BN) * ROW_BYTES / 1024 / NW;    // DMA wave-instructions per wave per K-tile
-    // epilogue staging: one 32-row tile band x JG column tiles of the wave tile at a time
-    constexpr int JG = (TN % 3 == 0) ? 3 : ((TN % 2 == 0) ? 2 : 1);
-    constexpr int CHUNKS = JG * 8;                  // 16-byte column chunks per staged row
-    constexpr int OUT_BYTES = 32 * CHUNKS * 16;     // per-wave fp32 staging slab
-    static_assert(NW * OUT_BYTES <= NSTAGE * STAGE_BYTES, "output staging must fit in the operand buffers");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int lane = lane_id();
-    const int wave = wave_id();
-    const int wr = wave / WGN, wc = wave % WGN;
-    const int hi = lane >> 5, l31 = lane & 31;
-
-    const int ntn = a.N / BN;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile / ntn) * BM;
-    const int n0 = (tile % ntn) * BN;
-
-    float16_t acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = zero16();
-
-    float* rowstat = reinterpret_cast<float*>(smem + NSTAGE * STAGE_BYTES);      // auxiliary area behind the ring
-    float* colvec = rowstat + 2 * BM;
-    const int nk = a.K / BKT;
-    auto stage = [&](int kt) {
-        char* dst = smem + (kt % NSTAGE) * STAGE_BYTES;
-        stage_tile<BM, BKT, NW>(a.A, a.lda, m0, kt * BKT, dst, wave, lane);
-        stage_tile<BN, BKT, NW>(a.W, a.ldw, n0, kt * BKT, dst + A_BYTES, wave, lane);
-    };
-    ColumnVectors<BM, BN, 64 * NW, EPI> column_vectors;
-    RowStats<BM, 64 * NW, EPI> row_stats;
-    column_vectors.issue(a, n0);                 // ahead of the operand tiles, consumed behind them
-    row_stats.issue(a, m0);
-    // prologue: NSTAGE-1 tiles in flight
-#pragma unroll
-    for (int t = 0; t < NSTAGE - 1; ++t)
-        if (t < nk) stage(t);
-    column_vectors.store(colvec);
-    row_stats.finish(a, rowstat);
-
-    for (int kt = 0; kt < nk; ++kt) {
-        // tile kt has landed once at most `later` newer tiles of this wave are still in flight
-        const int later = min(NSTAGE - 2, nk - 1 - kt);
-        if (later >= 4) wait_dma<4 * LOADS>();
-        else if (later == 3) wait_dma<3 * LOADS>();
-        else if (later == 2) wait_dma<2 * LOADS>();
-        else if (later == 1) wait_dma<LOADS>();
-        else wait_dma<0>();
-        __builtin_amdgcn_s_barrier();            // ... for every wave; and everyone is done reading stage (kt-1)%NSTAGE
-        const char* la = smem + (kt % NSTAGE) * STAGE_BYTES;
-        const char* lb = la + A_BYTES;
-        if (ABL == 1) {
-            if (kt + NSTAGE - 1 < nk) stage(kt + NSTAGE - 1);
-            continue;
-        }
-        // fragment reads run one 16-wide k-step ahead of the MFMAs that consume them; the DMA requests of
-        // the next tile are issued behind the first reads so they do not delay them
-        constexpr int KS = BKT / 16;
-        half8_t fa[2][TM], fb[2][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[0][i] = read_frag<BKT>(la, wr * WM + i * 32 + l31, hi);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb[0][j] = read_frag<BKT>(lb, wc * WN + j * 32 + l31, hi);
-        if (kt + NSTAGE - 1 < nk && ABL != 2) stage(kt + NSTAGE - 1);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int cur = ks & 1, nxt = cur ^ 1;
-            if (ks + 1 < KS) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) fa[nxt][i] = read_frag<BKT>(la, wr * WM + i * 32 + l31, (ks + 1) * 2 + hi);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) fb[nxt][j] = read_frag<BKT>(lb, wc * WN + j * 32 + l31, (ks + 1) * 2 + hi);
-            }
-            // swapped roles: D[row = n][col = m]; lane <-> m, registers <-> 4-groups of consecutive n
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(fb[cur][j], fa[cur][i], acc[i][j]);
-        }
-    }
-
-    // ---- epilogue: accumulators -> LDS (row-major slab, chunk ^= row&7) -> coalesced rows -----------
-    __syncthreads();                             // operand buffers are dead for every wave; aux area is complete
-    char* slab = smem + wave * OUT_BYTES;
-    float2_t* rowpart = reinterpret_cast<float2_t*>(smem + NW * OUT_BYTES);   // EPI_STATS: [BM][BN/32] behind the slabs
-    static_assert(NW * OUT_BYTES + BM * (BN / 32) * 8 <= NSTAGE * STAGE_BYTES, "tile statistics must fit behind the slabs");
-    const int resid_row0 = a.resid ? m0 % a.resid_mod : 0;
-    static_assert((32 * CHUNKS) % 64 == 0, "staged slab must split evenly over 64 lanes");
-    constexpr int NIT = 32 * CHUNKS / 64;        // float4 items per lane per slab
-    constexpr int NJ = TN / JG, NSLAB = TM * NJ; // slabs per 32-row band, per wave
-    // the residual of the next slab is requested while the current one is worked on -- unless the register budget
-    // of the tile (MINW waves per SIMD) has no room for a second buffer
-    constexpr int RV_BUFS = (MINW >= 4 && NIT > 4) ? 1 : 2;
-    float4_t rv[RV_BUFS][NIT];
-    if (RV_BUFS == 2) {
-        const int pf_row_base = wr * WM, pf_col_base = wc * WN;
-        float4_t(&pf_dst)[NIT] = rv[0];
-#include "gemm_epilogue_prefetch.inc"
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int jg = 0; jg < NJ; ++jg) {
-            const int sl = i * NJ + jg;
-#pragma unroll
-            for (int jj = 0; jj < JG; ++jj)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int chunk = jj * 8 + g4 * 2 + hi;         // columns 4*chunk .. 4*chunk+3 of the slab
-                    const float16_t& t = acc[i][jg * JG + jj];
-                    float4_t v = {t[g4 * 4 + 0], t[g4 * 4 + 1], t[g4 * 4 + 2], t[g4 * 4 + 3]};
-                    *reinterpret_cast<float4_t*>(slab + (l31 * CHUNKS + (chunk ^ (l31 & 7))) * 16) = v;
-                }
-            if (sl + RV_BUFS - 1 < NSLAB) {
-                constexpr int AHEAD = RV_BUFS - 1;
-                const int pf_row_base = wr * WM + ((sl + AHEAD) / NJ) * 32;
-                const int pf_col_base = wc * WN + ((sl + AHEAD) % NJ) * JG * 32;
-                float4_t(&pf_dst)[NIT] = rv[(sl + AHEAD) % RV_BUFS];
-#include "gemm_epilogue_prefetch.inc"
-            }
-            const int row_local_base = wr * WM + i * 32, col_local_base = wc * WN + jg * JG * 32;
-            float4_t(&rv_cur)[NIT] = rv[sl % RV_BUFS];
-#include "gemm_epilogue.inc"
-        }
-    }
-    if (EPI == EPI_STATS) {
-        __syncthreads();
-        write_tile_stats<BM, BN>(a, rowpart, m0, n0);
-    }
-}
+#include "gemm_f16_tile.inc"
 
 typedef float float4v __attribute__((ext_vector_type(4)));
 

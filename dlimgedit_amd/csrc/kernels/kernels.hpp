@@ -178,6 +178,11 @@ void decoder_start(const DecoderPrompts& prompts, const float* gauss, const floa
 void token_linears(const TokenLinear* ops, int count, int rows, hipStream_t);
 // self-attention among the 7 tokens of each prompt + its output projection `out` (K = 256) in one launch
 void token_self_attention_out(const float* q, const float* k, const float* v, const TokenLinear& out, int P, hipStream_t);
+// The same launch carrying a plain GEMM (no activation, no folded LayerNorm, fp32 bias / residual, f16 or fp32 result) that
+// neither depends on it nor it on the GEMM: its 64 x 64 tiles are extra workgroups of the launch (decoder.hip).  Returns false
+// without launching anything when `g` is not of that kind (the caller then launches both on their own).
+bool token_self_attention_out_with_gemm(const float* q, const float* k, const float* v, const TokenLinear& out, int P,
+                                        const GemmArgs& g, hipStream_t);
 // token-to-image attention.  partials: per key group (max, sum, output) of every (prompt, head, token); the queries
 // are q [P,7,128], or are computed in the launch as q_proj (256 -> 128, LayerNorm / positional part on the fly).  The
 // fold of the partials + output projection `out` (128 -> 256, out_wt = its weight transposed [128][256]) + residual is

@@ -940,15 +940,16 @@ void SamModel::decode_chunk(float const* const* emb, float const* coords, float 
         };
         // image side of the attentions: all projections of the keys in one MFMA GEMM, the positional part of
         // (keys + pos) W as the constant addend SamWeights prepared
-        auto img_gemm = [&](LinearH const& l, DeviceBuffer<float> const& pos) {
+        auto img_gemm_args = [&](LinearH const& l, DeviceBuffer<float> const& pos) {
             k::GemmArgs g;
             g.A = keys_h_.get(); g.lda = 256; g.W = l.w.get(); g.ldw = 256; g.bias = l.b.get();
             g.resid = pos.get(); g.ldr = l.out; g.resid_mod = kTokens;
             g.out_h = kqv_h_.get(); g.ldc16 = l.out; g.M = M; g.N = l.out; g.K = 256;
             g.shared_gpu = shared_gpu_;
             g.unit_rows = kTokens;
-            k::gemm(g, s);
+            return g;
         };
+        auto img_gemm = [&](LinearH const& l, DeviceBuffer<float> const& pos) { k::gemm(img_gemm_args(l, pos), s); };
 
         // First launch: prompt tokens (= the positional part `qpe` of every later query), keys = image_embedding +
         // no_mask_embed (has_mask_input == 0, segmentation.cpp:43-45), and the q / k / v projections of the first
@@ -964,12 +965,17 @@ void SamModel::decode_chunk(float const* const* emb, float const* coords, float 
             DecoderLayer const& L = W.dec_[i];
             // (1) self attention of the tokens; the first layer has no residual.  The q / k / v projections were computed
             // by the launch that produced their input rows (decoder_start, or the first layer's step (4)).
-            k::token_self_attention_out(sq_.get(), sk_.get(), sv_.get(),
-                                        lin({}, 256, L.self_attn.o, i == 0 ? k::TokenRows{} : cur, tsa_.get(), 0), P, s);
-            const k::TokenRows q1 = normed(tsa_.get(), L.ln1);
             // (2) tokens -> image: [K | Q of step 4 | V] = [(keys + pos) Wk | (keys + pos) Wq | keys Wv]; the query
-            // projection runs inside the attention launch, the fold + output projection inside the MLP's first launch
-            img_gemm(L.img_kqv, L.pos_kqv);
+            // projection runs inside the attention launch, the fold + output projection inside the MLP's first launch.
+            // The projection of the keys depends on (1) as little as (1) on it: its tiles ride in (1)'s launch (r06)
+            const k::TokenLinear self_out = lin({}, 256, L.self_attn.o, i == 0 ? k::TokenRows{} : cur, tsa_.get(), 0);
+            // (DLIMGEDIT_DECODER_RIDE=0: measurement aid, the two launches on their own)
+            static const bool ride = [] { const char* e = std::getenv("DLIMGEDIT_DECODER_RIDE"); return !e || std::atoi(e) != 0; }();
+            if (!ride || !k::token_self_attention_out_with_gemm(sq_.get(), sk_.get(), sv_.get(), self_out, P, img_gemm_args(L.img_kqv, L.pos_kqv), s)) {
+                k::token_self_attention_out(sq_.get(), sk_.get(), sv_.get(), self_out, P, s);
+                img_gemm(L.img_kqv, L.pos_kqv);
+            }
+            const k::TokenRows q1 = normed(tsa_.get(), L.ln1);
             const k::TokenLinear tq = lin(rows_of(q1, true), 256, L.t2i_q, {}, nullptr, 0);
             k::token_to_image_partials(nullptr, &tq, kqv_h_.get(), 384, kqv_h_.get() + 256, 384, t2i_part_.get(), P, s);
             const k::TokenRows q2 = normed(tt2i_.get(), L.ln2);
