@@ -495,9 +495,9 @@ __global__ __launch_bounds__(256) void token_self_attn_out_kernel(const float* _
 // The same launch with the layer's image-side projection riding along: [K | Q | V] = keys . W^T (decoder_image side, an MFMA
 // GEMM of 64 x 64 tiles, gemm_f16_tile) does not depend on the token self-attention and the self-attention not on it, and
 // on their own they are 14 and 19 us one after the other, twice per decode (the stream is in order; a second stream costs
-// more in cross-queue waits than it hides, and hipExtAnyOrderLaunch is not honoured on gfx950: LABNOTES r06).  The first
+// more in cross-queue waits than it hides, and hipExtAnyOrderLaunch is not honoured on gfx950: LABNOTES r06).  The last
 // `gemm_tiles` workgroups take one GEMM tile each -- the same code, tile shape and K order as the launch of its own, so the
-// same bits -- the rest are the self-attention's workgroups.  Both parts use 256 threads.
+// same bits -- in front of them the self-attention's workgroups.  Both parts use 256 threads.
 constexpr int SAG_BM = 64, SAG_BN = 64;
 constexpr size_t SAG_GEMM_LDS = (size_t)2 * (SAG_BM + SAG_BN) * 64 * 2 + aux_bytes(SAG_BM, SAG_BN);
 constexpr size_t SAG_TOKEN_LDS = (size_t)TL_PROMPT_SLICE * TOK * (DIM * 4 + 8);
@@ -507,12 +507,14 @@ __global__ __launch_bounds__(256, 4) void self_attn_out_and_gemm_kernel(k::GemmA
                                                                         const float* __restrict__ kx, const float* __restrict__ v,
                                                                         k::TokenLinear op, int P, int token_blocks_x) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if ((int)blockIdx.x < gemm_tiles) {
-        gemm_f16_tile<SAG_BM, SAG_BN, 2, 2, 64, 2, 4, k::ACT_NONE, EPI_PLAIN>(g, xcd_remap(blockIdx.x, gemm_tiles), smem);
+    // the self-attention's workgroups come first: with many prompts the GEMM has thousands of tiles, and workgroups are
+    // dispatched in index order -- behind them the long chain of the token part would start when the GEMM is all but done
+    const int token_blocks = (int)gridDim.x - gemm_tiles;        // a multiple of 8: the tiles keep their XCDs
+    if ((int)blockIdx.x < token_blocks) {
+        token_self_attn_out_body(q, kx, v, op, P, blockIdx.x % token_blocks_x, blockIdx.x / token_blocks_x, reinterpret_cast<float*>(smem));
         return;
     }
-    const int b = (int)blockIdx.x - gemm_tiles;
-    token_self_attn_out_body(q, kx, v, op, P, b % token_blocks_x, b / token_blocks_x, reinterpret_cast<float*>(smem));
+    gemm_f16_tile<SAG_BM, SAG_BN, 2, 2, 64, 2, 4, k::ACT_NONE, EPI_PLAIN>(g, xcd_remap((int)blockIdx.x - token_blocks, gemm_tiles), smem);
 }
 
 // The rest of the token-to-image attention, done by its CONSUMERS (a launch of its own cost 9-16 us for 0.2 MFLOP):
